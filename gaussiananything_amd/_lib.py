@@ -1,0 +1,77 @@
+"""ctypes binding of the C-ABI in include/ga_surfel.h (libga_mi355.so, built in-tree by csrc/Makefile).
+
+There is NO fallback: if the HIP library is missing or does not export a declared symbol this module raises, and
+every product entry point that needs it fails loudly (the oracle under oracle/ is test infrastructure, never a
+substitute).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libga_mi355.so")
+
+GA_OK = 0
+GA_STATUS_NUM_RENDERED, GA_STATUS_OVERFLOW, GA_STATUS_MAX_TILE, GA_STATUS_WORDS = 0, 1, 2, 4
+GA_SURFEL_RECORD_FLOATS = 20
+_ERR = {-1: "GA_ERR_NULL_ARG", -2: "GA_ERR_BAD_SHAPE", -3: "GA_ERR_WORKSPACE", -4: "GA_ERR_LAUNCH"}
+
+
+class GaSurfelForwardArgs(ctypes.Structure):
+    _fields_ = [
+        ("num_points", ctypes.c_int32), ("num_views", ctypes.c_int32),
+        ("image_height", ctypes.c_int32), ("image_width", ctypes.c_int32),
+        ("scale_modifier", ctypes.c_float), ("flags", ctypes.c_int32),
+        ("means3D", ctypes.c_void_p), ("opacities", ctypes.c_void_p), ("colors", ctypes.c_void_p),
+        ("scales", ctypes.c_void_p), ("rotations", ctypes.c_void_p),
+        ("viewmatrix", ctypes.c_void_p), ("projmatrix", ctypes.c_void_p), ("bg", ctypes.c_void_p),
+        ("out_color", ctypes.c_void_p), ("out_others", ctypes.c_void_p), ("radii", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t), ("capacity", ctypes.c_int64),
+    ]
+
+
+class GaSurfelWorkspaceLayout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_size_t) for n in (
+        "status", "tile_count", "tile_start", "tile_cursor", "rect", "depth", "bbox", "record", "keys",
+        "point_list", "total_bytes")]
+
+
+EXPORTS = ("ga_surfel_version", "ga_surfel_workspace_layout", "ga_surfel_forward")
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP translation unit for gfx950 (hipcc cross-compiles without a GPU) into LIB_PATH."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc")] + ([] if verbose else ["-s"])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the MI355X HIP library has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C gaussiananything_amd/csrc`). "
+                "There is no CPU fallback for the product path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            if not hasattr(L, name):
+                raise RuntimeError(f"{LIB_PATH} does not export {name}")
+        L.ga_surfel_version.restype = ctypes.c_char_p
+        L.ga_surfel_workspace_layout.restype = ctypes.c_int
+        L.ga_surfel_workspace_layout.argtypes = [ctypes.c_int32] * 4 + [ctypes.c_int64,
+                                                                       ctypes.POINTER(GaSurfelWorkspaceLayout)]
+        L.ga_surfel_forward.restype = ctypes.c_int
+        L.ga_surfel_forward.argtypes = [ctypes.POINTER(GaSurfelForwardArgs), ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != GA_OK:
+        raise RuntimeError(f"{what} failed: {_ERR.get(rc, rc)}")

@@ -1,0 +1,51 @@
+// surfel_common.h -- internal definitions shared by the surfel rasterizer translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ga_surfel.h"
+
+namespace ga {
+
+constexpr int kTile = 16;              // tile edge in pixels: fixes which pixels a splat may touch (upstream BLOCK_X/Y)
+constexpr int kRec = GA_SURFEL_RECORD_FLOATS;
+// blend-ready record, 80 bytes, 16-byte aligned:
+//   [0..2] Tu  [3..5] Tv  [6..8] Tw  [9..10] centre xy  [11] opacity | [12..14] view normal  [15] -  [16..18] rgb  [19] -
+constexpr int kRecTu = 0, kRecTv = 3, kRecTw = 6, kRecXY = 9, kRecOpa = 11, kRecNrm = 12, kRecRgb = 16;
+
+constexpr float kNear = 0.2f;          // upstream near_n
+constexpr float kFar = 100.0f;         // upstream far_n
+constexpr float kCutoff = 3.0f;
+constexpr float kFilterSize = 0.707106f;
+constexpr float kFilterInvSquare = 2.0f;
+
+constexpr int kSortCap = 8192;         // per-tile entries sorted in one LDS pass (64 KiB of u64 keys)
+
+struct Dims {
+    int N, V, H, W, gx, gy, tiles;     // tiles = gx*gy per view
+};
+
+struct Workspace {
+    int64_t *status;
+    uint32_t *tile_count, *tile_start, *tile_cursor;
+    uint16_t *rect;
+    float *depth, *bbox, *record;
+    uint64_t *keys;
+    uint32_t *point_list;
+};
+
+// Bijective XCD-aware remap: consecutive workgroup ids land on different XCDs (id % 8); give each XCD one contiguous
+// span of logical ids so that neighbouring tiles (which share splat records) share that XCD's L2.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg)
+{
+    constexpr uint32_t X = 8;
+    const uint32_t q = nwg / X, r = nwg % X, xcd = bid % X, k = bid / X;
+    const uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+void launch_preprocess(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &ws, hipStream_t s);
+void launch_binning(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &ws, hipStream_t s);
+void launch_blend(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &ws, hipStream_t s);
+
+}  // namespace ga

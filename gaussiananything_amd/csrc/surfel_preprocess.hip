@@ -1,0 +1,155 @@
+// surfel_preprocess.hip -- per-(view, Gaussian) preprocess of the 2D-surfel rasterizer, gfx950.
+//
+// Replaces upstream preprocessCUDA (+ compute_transmat / compute_aabb / getRect) of diff_surfel_rasterization, the
+// extension called at /root/reference/nsr/gs_surfel.py:100-114; algorithm per SURVEY.md Appendix A.1 steps 1-7.
+//
+// This translation unit is built with -ffp-contract=off: radii, tile rects and depth keys must be BIT-IDENTICAL to
+// the oracle (oracle/surfel_raster.c), so every expression below keeps the oracle's operation order, one IEEE
+// rounding per operation, correctly rounded division and sqrt (hipcc default), no FMA.
+//
+// MI355X notes: HBM-bound streaming kernel, one thread per (view, Gaussian), view-major so a wave reads 64
+// consecutive Gaussians (768 contiguous bytes of means3D).  Outputs are written as ONE 80-byte record per splat
+// (what the blend kernel fetches through the scalar path) plus the small SoA side arrays the binning passes stream
+// (depth, rect, bbox).  Tile occupancy is counted here with fire-and-forget L2 atomics, which replaces upstream's
+// tiles_touched array + device-wide inclusive scan.
+#include "surfel_common.h"
+
+#pragma clang fp contract(off)
+
+namespace ga {
+
+__device__ __forceinline__ int f2i(float f) { return (int)f; }  // v_cvt_i32_f32: toward zero, saturating, NaN -> 0
+
+__global__ __launch_bounds__(256) void surfel_preprocess_kernel(
+    const float *__restrict__ means3D, const float *__restrict__ opacities, const float *__restrict__ colors,
+    const float *__restrict__ scales, const float *__restrict__ rotations, const float *__restrict__ viewmatrix,
+    const float *__restrict__ projmatrix, float scale_modifier, Dims dm, int32_t *__restrict__ radii,
+    uint16_t *__restrict__ rect_out, float *__restrict__ depth_out, float *__restrict__ bbox_out,
+    float *__restrict__ rec_out, uint32_t *__restrict__ tile_count)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)dm.N * dm.V) return;
+    const int v = (int)(idx / dm.N), i = (int)(idx - (int64_t)v * dm.N);
+    const float *vm = viewmatrix + 16 * v, *pm = projmatrix + 16 * v;
+
+    radii[idx] = 0;
+    ushort4 rc = make_ushort4(0, 0, 0, 0);
+    *reinterpret_cast<ushort4 *>(rect_out + 4 * idx) = rc;
+
+    const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+    const float vx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
+    const float vy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
+    const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
+    if (vz <= 0.2f) return;
+
+    const float4 q = *reinterpret_cast<const float4 *>(rotations + 4 * i);
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    const float tu[3] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y + r * z), 2.f * (x * z - r * y)};
+    const float tv[3] = {2.f * (x * y - r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + r * x)};
+    const float nn[3] = {2.f * (x * z + r * y), 2.f * (y * z - r * x), 1.f - 2.f * (x * x + y * y)};
+    const float2 sc = *reinterpret_cast<const float2 *>(scales + 2 * i);
+    const float su = scale_modifier * sc.x, sv = scale_modifier * sc.y;
+
+    const float halfW = (float)dm.W / 2.0f, halfH = (float)dm.H / 2.0f;
+    const float cW = (float)(dm.W - 1) / 2.0f, cH = (float)(dm.H - 1) / 2.0f;
+    const float Hm[3][3] = {{tu[0] * su, tu[1] * su, tu[2] * su}, {tv[0] * sv, tv[1] * sv, tv[2] * sv}, {px, py, pz}};
+    float M[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float A[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = Hm[a][0] * pm[0 + j] + Hm[a][1] * pm[4 + j] + Hm[a][2] * pm[8 + j];
+            if (a == 2) s = s + pm[12 + j];
+            A[j] = s;
+        }
+        M[a][0] = A[0] * halfW + A[3] * cW;
+        M[a][1] = A[1] * halfH + A[3] * cH;
+        M[a][2] = A[3];
+    }
+    const float Tu[3] = {M[0][0], M[1][0], M[2][0]};
+    const float Tv[3] = {M[0][1], M[1][1], M[2][1]};
+    const float Tw[3] = {M[0][2], M[1][2], M[2][2]};
+
+    float nvx = vm[0] * nn[0] + vm[4] * nn[1] + vm[8] * nn[2];
+    float nvy = vm[1] * nn[0] + vm[5] * nn[1] + vm[9] * nn[2];
+    float nvz = vm[2] * nn[0] + vm[6] * nn[1] + vm[10] * nn[2];
+    const float cs = -((vx * nvx + vy * nvy) + vz * nvz);
+    if (cs == 0.0f) return;
+    const float mult = cs > 0.0f ? 1.0f : -1.0f;
+    nvx = mult * nvx; nvy = mult * nvy; nvz = mult * nvz;
+
+    const float t0 = kCutoff * kCutoff, t1 = kCutoff * kCutoff, t2 = -1.0f;
+    const float d = (t0 * (Tw[0] * Tw[0]) + t1 * (Tw[1] * Tw[1])) + t2 * (Tw[2] * Tw[2]);
+    if (d == 0.0f) return;
+    const float inv = 1.0f / d;
+    const float f0 = inv * t0, f1 = inv * t1, f2 = inv * t2;
+    const float cx = (f0 * (Tu[0] * Tw[0]) + f1 * (Tu[1] * Tw[1])) + f2 * (Tu[2] * Tw[2]);
+    const float cy = (f0 * (Tv[0] * Tw[0]) + f1 * (Tv[1] * Tw[1])) + f2 * (Tv[2] * Tw[2]);
+    const float hx0 = cx * cx - ((f0 * (Tu[0] * Tu[0]) + f1 * (Tu[1] * Tu[1])) + f2 * (Tu[2] * Tu[2]));
+    const float hy0 = cy * cy - ((f0 * (Tv[0] * Tv[0]) + f1 * (Tv[1] * Tv[1])) + f2 * (Tv[2] * Tv[2]));
+    const float ex = sqrtf(fmaxf(1e-4f, hx0)), ey = sqrtf(fmaxf(1e-4f, hy0));
+    const float radius = ceilf(fmaxf(fmaxf(ex, ey), kCutoff * kFilterSize));
+
+    const int rminx = min(dm.gx, max(0, f2i((cx - radius) / kTile)));
+    const int rminy = min(dm.gy, max(0, f2i((cy - radius) / kTile)));
+    const int rmaxx = min(dm.gx, max(0, f2i((cx + radius + kTile - 1) / kTile)));
+    const int rmaxy = min(dm.gy, max(0, f2i((cy + radius + kTile - 1) / kTile)));
+    if ((rmaxx - rminx) * (rmaxy - rminy) == 0) return;
+
+    radii[idx] = f2i(radius);
+    depth_out[idx] = vz;
+    rc = make_ushort4((unsigned short)rminx, (unsigned short)rminy, (unsigned short)rmaxx, (unsigned short)rmaxy);
+    *reinterpret_cast<ushort4 *>(rect_out + 4 * idx) = rc;
+
+    const float opa = opacities[i];
+    float4 *rec = reinterpret_cast<float4 *>(rec_out + (size_t)idx * kRec);
+    rec[0] = make_float4(Tu[0], Tu[1], Tu[2], Tv[0]);
+    rec[1] = make_float4(Tv[1], Tv[2], Tw[0], Tw[1]);
+    rec[2] = make_float4(Tw[2], cx, cy, opa);
+    rec[3] = make_float4(nvx, nvy, nvz, 0.0f);
+    rec[4] = make_float4(colors[3 * i], colors[3 * i + 1], colors[3 * i + 2], 0.0f);
+
+    // Conservative pixel bounding box of {alpha >= 1/255}: the blend loop rejects (pixel, splat) pairs outside it
+    // without evaluating them.  alpha = min(.99, opa*exp(-rho/2)) >= 1/255  <=>  rho = min(rho3d, rho2d) <= c2 with
+    // c2 = 2 ln(255 opa): union of the low-pass disc (rho2d) and the projected c-sigma ellipse (rho3d, same AABB
+    // formula as above with cutoff c).  Margins make rounding irrelevant; anything doubtful falls back to "everything".
+    const float kInf = __builtin_inff();
+    float4 bb = make_float4(-kInf, -kInf, kInf, kInf);  // xmin ymin xmax ymax
+    if (opa < 1.0f / 255.0f) {
+        bb = make_float4(kInf, kInf, -kInf, -kInf);     // can never pass the alpha threshold
+    } else {
+        const float c2 = (2.0f * __logf(255.0f * opa)) * 1.02f + 0.05f;
+        const float dd = (c2 * (Tw[0] * Tw[0]) + c2 * (Tw[1] * Tw[1])) - (Tw[2] * Tw[2]);
+        if (c2 < 1e30f && dd < 0.0f) {
+            const float iv = 1.0f / dd;
+            const float g0 = iv * c2, g2 = -iv;
+            const float bx = (g0 * (Tu[0] * Tw[0]) + g0 * (Tu[1] * Tw[1])) + g2 * (Tu[2] * Tw[2]);
+            const float by = (g0 * (Tv[0] * Tw[0]) + g0 * (Tv[1] * Tw[1])) + g2 * (Tv[2] * Tw[2]);
+            const float hx = bx * bx - ((g0 * (Tu[0] * Tu[0]) + g0 * (Tu[1] * Tu[1])) + g2 * (Tu[2] * Tu[2]));
+            const float hy = by * by - ((g0 * (Tv[0] * Tv[0]) + g0 * (Tv[1] * Tv[1])) + g2 * (Tv[2] * Tv[2]));
+            const float e3x = sqrtf(fmaxf(hx, 0.0f)) * 1.01f + 0.5f, e3y = sqrtf(fmaxf(hy, 0.0f)) * 1.01f + 0.5f;
+            const float r2 = sqrtf(0.5f * c2) + 0.5f;
+            const float xmin = fminf(bx - e3x, cx - r2), xmax = fmaxf(bx + e3x, cx + r2);
+            const float ymin = fminf(by - e3y, cy - r2), ymax = fmaxf(by + e3y, cy + r2);
+            if (xmin == xmin && xmax == xmax && ymin == ymin && ymax == ymax && hx == hx && hy == hy)
+                bb = make_float4(xmin, ymin, xmax, ymax);
+        }
+    }
+    *reinterpret_cast<float4 *>(bbox_out + 4 * idx) = bb;
+
+    uint32_t *tc = tile_count + (size_t)v * dm.tiles;
+    for (int ty = rminy; ty < rmaxy; ++ty)
+        for (int tx = rminx; tx < rmaxx; ++tx) atomicAdd(tc + ty * dm.gx + tx, 1u);
+}
+
+void launch_preprocess(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &ws, hipStream_t s)
+{
+    const int64_t total = (int64_t)d.N * d.V;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(surfel_preprocess_kernel, dim3(blocks), dim3(256), 0, s, a.means3D, a.opacities, a.colors,
+                       a.scales, a.rotations, a.viewmatrix, a.projmatrix, a.scale_modifier, d, a.radii, ws.rect,
+                       ws.depth, ws.bbox, ws.record, ws.tile_count);
+}
+
+}  // namespace ga

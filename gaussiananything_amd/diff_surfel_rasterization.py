@@ -1,0 +1,180 @@
+"""MI355X-native stand-in for the third-party ``diff_surfel_rasterization`` package.
+
+Exports the two names the reference imports (``/root/reference/nsr/gs_surfel.py:15``) with the same call convention
+(``:85-114``): ``GaussianRasterizationSettings`` (NamedTuple, 12 fields) and ``GaussianRasterizer(raster_settings)``
+whose call returns ``(color[3,H,W], radii[N], allmap[7,H,W])``.  The arithmetic runs in hand-written HIP kernels behind
+the C-ABI of ``include/ga_surfel.h``; there is no CPU path -- CPU tensors or a missing library raise.
+
+``rasterize_views`` is the batched form the MI355X design is built around (all views of one Gaussian set in one
+launch sequence); the per-view ``GaussianRasterizer`` call is a V=1 special case of it.
+"""
+from __future__ import annotations
+
+import ctypes
+import warnings
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class SurfelWorkspace:
+    """Caller-owned device scratch for ``ga_surfel_forward`` (the C-ABI allocates nothing).
+
+    ``capacity`` is the number of binned (tile, splat) entries the buffers can hold.  The device reports the real count
+    D and an overflow flag in ``status``; on overflow nothing was rendered and the caller grows the workspace and
+    re-runs (``rasterize_views`` does that).
+    """
+
+    def __init__(self, device, num_points, num_views, height, width, capacity):
+        self.key = (num_points, num_views, height, width)
+        self.capacity = int(capacity)
+        self.layout = _lib.GaSurfelWorkspaceLayout()
+        _lib.check(_lib.lib().ga_surfel_workspace_layout(num_points, num_views, height, width, self.capacity,
+                                                         ctypes.byref(self.layout)), "ga_surfel_workspace_layout")
+        self.buffer = torch.empty(self.layout.total_bytes + 256, dtype=torch.uint8, device=device)
+        self.offset = (-self.buffer.data_ptr()) % 256
+        self.ptr = self.buffer.data_ptr() + self.offset
+
+    def section(self, name, dtype, count):
+        """Typed view of one workspace section (tests read the integer artefacts through this)."""
+        off = self.offset + getattr(self.layout, name)
+        nbytes = count * torch.empty((), dtype=dtype).element_size()
+        return self.buffer[off:off + nbytes].view(dtype)
+
+    def status(self):
+        return self.section("status", torch.int64, _lib.GA_STATUS_WORDS)
+
+
+_ws_cache = {}
+
+
+def _get_workspace(device, n, v, h, w, min_capacity=0):
+    key = (str(device), n, v, h, w)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.capacity < min_capacity:
+        cap = max(int(min_capacity), 4 * n * v, 1 << 16)
+        ws = SurfelWorkspace(device, n, v, h, w, cap)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _f32c(t: torch.Tensor, name: str, device) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if t.device.type != "cuda":
+        raise RuntimeError(f"{name} is on {t.device}: the surfel rasterizer only runs on an MI355X (HIP) device; "
+                           "there is no CPU path")
+    if t.device != device:
+        raise RuntimeError(f"{name} is on {t.device}, expected {device}")
+    return t.detach().contiguous().float()
+
+
+_warned_grad = False
+
+
+def rasterize_views(means3D, opacities, colors_precomp, scales, rotations, viewmatrix, projmatrix, bg,
+                    image_height, image_width, scale_modifier=1.0, workspace: Optional[SurfelWorkspace] = None,
+                    check_overflow: bool = True):
+    """Rasterize V views of one Gaussian set.  ``viewmatrix`` / ``projmatrix``: ``[V,4,4]`` row-vector matrices
+    (``cam_view`` / ``cam_view_proj``).  Returns ``color [V,3,H,W]``, ``radii [V,N] int32``, ``allmap [V,7,H,W]`` and
+    the workspace used (its ``status()`` holds D / overflow / longest tile list).
+
+    ``check_overflow=True`` reads the device status word after the launch (one host sync, as upstream's read-back of
+    ``num_rendered``) and transparently re-runs with a larger workspace; with ``False`` nothing synchronises and the
+    caller inspects ``workspace.status()`` itself.
+    """
+    global _warned_grad
+    device = means3D.device
+    if torch.is_grad_enabled() and any(getattr(t, "requires_grad", False) for t in
+                                       (means3D, opacities, colors_precomp, scales, rotations)) and not _warned_grad:
+        warnings.warn("gaussiananything_amd surfel rasterizer is forward-only in this tier: outputs carry no grad_fn")
+        _warned_grad = True
+    means3D = _f32c(means3D, "means3D", device)
+    n = means3D.shape[0]
+    opacities = _f32c(opacities, "opacities", device).reshape(-1)
+    colors = _f32c(colors_precomp, "colors_precomp", device)
+    scales = _f32c(scales, "scales", device)
+    rotations = _f32c(rotations, "rotations", device)
+    if means3D.shape != (n, 3) or opacities.shape != (n,) or colors.shape != (n, 3) or scales.shape != (n, 2) \
+            or rotations.shape != (n, 4):
+        raise ValueError("expected means3D[N,3], opacities[N,1], colors_precomp[N,3], scales[N,2], rotations[N,4]")
+    vm = _f32c(viewmatrix, "viewmatrix", device).reshape(-1, 16)
+    pm = _f32c(projmatrix, "projmatrix", device).reshape(-1, 16)
+    v = vm.shape[0]
+    if pm.shape[0] != v:
+        raise ValueError("viewmatrix and projmatrix must hold the same number of views")
+    bg = _f32c(bg, "bg", device).reshape(3)
+    h, w = int(image_height), int(image_width)
+
+    color = torch.empty((v, 3, h, w), dtype=torch.float32, device=device)
+    allmap = torch.empty((v, 7, h, w), dtype=torch.float32, device=device)
+    radii = torch.empty((v, n), dtype=torch.int32, device=device)
+    L = _lib.lib()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    ws = workspace if workspace is not None else _get_workspace(device, n, v, h, w)
+    if ws.key != (n, v, h, w):
+        raise ValueError("workspace was laid out for a different problem size")
+    with torch.cuda.device(device):
+        while True:
+            args = _lib.GaSurfelForwardArgs(
+                n, v, h, w, float(scale_modifier), 0, means3D.data_ptr(), opacities.data_ptr(), colors.data_ptr(),
+                scales.data_ptr(), rotations.data_ptr(), vm.data_ptr(), pm.data_ptr(), bg.data_ptr(),
+                color.data_ptr(), allmap.data_ptr(), radii.data_ptr(), ws.ptr, ws.layout.total_bytes, ws.capacity)
+            _lib.check(L.ga_surfel_forward(ctypes.byref(args), ctypes.c_void_p(stream)), "ga_surfel_forward")
+            if not check_overflow:
+                break
+            st = ws.status().cpu()
+            if int(st[_lib.GA_STATUS_OVERFLOW]) == 0:
+                break
+            need = int(st[_lib.GA_STATUS_NUM_RENDERED])
+            if need > 0xFFFFFFFF:
+                raise RuntimeError(f"{need} binned entries exceed the 2^32 limit of the tile ranges")
+            if workspace is not None:
+                raise RuntimeError(f"workspace capacity {ws.capacity} < {need} binned entries")
+            ws = _get_workspace(device, n, v, h, w, min_capacity=need + need // 4)
+    return color, radii, allmap, ws
+
+
+class GaussianRasterizer(nn.Module):
+    """Same surface as ``diff_surfel_rasterization.GaussianRasterizer`` (forward only)."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if shs is not None:
+            raise NotImplementedError("spherical-harmonics colours are not on the GaussianAnything path "
+                                      "(nsr/gs_surfel.py always passes colors_precomp, sh_degree=0)")
+        if cov3D_precomp is not None:
+            raise NotImplementedError("precomputed transforms are not on the GaussianAnything path "
+                                      "(nsr/gs_surfel.py always passes scales/rotations)")
+        color, radii, allmap, _ = rasterize_views(
+            means3D, opacities, colors_precomp, scales, rotations, rs.viewmatrix.reshape(1, 4, 4),
+            rs.projmatrix.reshape(1, 4, 4), rs.bg, rs.image_height, rs.image_width, rs.scale_modifier)
+        return color[0], radii[0], allmap[0]

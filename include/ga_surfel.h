@@ -1,0 +1,100 @@
+/*
+ * ga_surfel.h -- C-ABI of the MI355X-native 2D-surfel ("2DGS") rasterizer forward.
+ *
+ * Drop-in boundary for the render half of GaussianAnything's render-and-denoise hot path.  A binding of this
+ * ABI replaces the third-party CUDA extension `diff_surfel_rasterization._C.rasterize_gaussians` that the
+ * reference reaches through
+ *     GaussianRasterizer(raster_settings)(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+ *                                         cov3D_precomp)            /root/reference/nsr/gs_surfel.py:85-114
+ * and, one level up, the per-(batch, view) Python loop of
+ *     GaussianRenderer2DGS.render(...)                              /root/reference/nsr/gs_surfel.py:41-202
+ * (one call here rasterizes ALL views of one Gaussian set; see INTEGRATION.md for the ctypes binding).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP, gfx950) unless it says "host"; all tensors are contiguous fp32 /
+ *     int32 exactly as the reference passes them; the caller owns every buffer, nothing is allocated inside;
+ *   - all work is enqueued on `stream`; there is no host synchronisation, no internal thread, no exception: the
+ *     return value is 0 or a negative GA_ERR_* code for host-detectable argument errors; run-time conditions that
+ *     only the device can see (binned-list overflow) are reported through the device-side `status` words;
+ *   - matrices are the reference's row-vector 4x4 (`p_view = [p,1] @ viewmatrix`, 16 floats row-major).
+ */
+#ifndef GA_SURFEL_H
+#define GA_SURFEL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GA_OK 0
+#define GA_ERR_NULL_ARG (-1)       /* a required pointer is NULL                                   */
+#define GA_ERR_BAD_SHAPE (-2)      /* N, V, H, W or capacity out of range (H, W <= 4096*16, V*tiles < 2^24) */
+#define GA_ERR_WORKSPACE (-3)      /* workspace_bytes smaller than ga_surfel_workspace_layout() says */
+#define GA_ERR_LAUNCH (-4)         /* a HIP launch failed (hipGetLastError is left set)            */
+
+/* status words written by the device (int64 each) */
+#define GA_STATUS_NUM_RENDERED 0   /* D = sum over views of tiles touched (upstream `num_rendered`) */
+#define GA_STATUS_OVERFLOW 1       /* 1 if D > capacity: outputs are then NOT written; retry with more capacity */
+#define GA_STATUS_MAX_TILE 2       /* longest per-tile list (diagnostic)                           */
+#define GA_STATUS_WORDS 4
+
+typedef struct GaSurfelForwardArgs {
+    int32_t num_points;      /* N Gaussians                                                       */
+    int32_t num_views;       /* V views rendered from the same Gaussians                          */
+    int32_t image_height;    /* H                                                                 */
+    int32_t image_width;     /* W                                                                 */
+    float scale_modifier;    /* GaussianRasterizationSettings.scale_modifier                      */
+    int32_t flags;           /* GA_SURFEL_FLAG_*                                                  */
+    const float *means3D;    /* [N,3]                                                             */
+    const float *opacities;  /* [N] (reference passes [N,1])                                      */
+    const float *colors;     /* [N,3] colors_precomp (sh_degree 0 path; shs unsupported as in the reference call) */
+    const float *scales;     /* [N,2]                                                             */
+    const float *rotations;  /* [N,4] quaternion (w,x,y,z), used as given (normalised by the caller) */
+    const float *viewmatrix; /* [V,16]                                                            */
+    const float *projmatrix; /* [V,16] full view-projection                                       */
+    const float *bg;         /* [3]                                                               */
+    float *out_color;        /* [V,3,H,W]                                                         */
+    float *out_others;       /* [V,7,H,W] allmap: depth, alpha, normal xyz, median depth, distortion */
+    int32_t *radii;          /* [V,N]                                                             */
+    void *workspace;         /* see ga_surfel_workspace_layout                                    */
+    size_t workspace_bytes;
+    int64_t capacity;        /* max binned entries D the workspace was sized for                  */
+} GaSurfelForwardArgs;
+
+#define GA_SURFEL_FLAG_NONE 0
+
+/* Byte offsets of the workspace sections (all 256-byte aligned).  Tests read the integer artefacts
+ * (rect, tile ranges, sorted point list) straight out of the workspace through these offsets. */
+typedef struct GaSurfelWorkspaceLayout {
+    size_t status;      /* int64[GA_STATUS_WORDS]                                                  */
+    size_t tile_count;  /* uint32[V*tiles]   entries per (view, tile)                             */
+    size_t tile_start;  /* uint32[V*tiles+1] exclusive scan of tile_count                         */
+    size_t tile_cursor; /* uint32[V*tiles]   scratch of the fill pass                             */
+    size_t rect;        /* uint16[V*N*4]     tile rect min.x min.y max.x max.y (0 when culled)    */
+    size_t depth;       /* float[V*N]        view-space depth (sort key)                          */
+    size_t bbox;        /* float[V*N*4]      conservative pixel bbox of alpha >= 1/255            */
+    size_t record;      /* float[V*N*GA_SURFEL_RECORD_FLOATS] blend-ready splat records           */
+    size_t keys;        /* uint64[capacity]  (depth bits << 32 | gaussian index), binned per tile */
+    size_t point_list;  /* uint32[capacity]  gaussian indices, per tile in (depth, index) order   */
+    size_t total_bytes;
+} GaSurfelWorkspaceLayout;
+
+#define GA_SURFEL_RECORD_FLOATS 20
+
+/* host: fills `out` for the given problem size; returns GA_OK or GA_ERR_BAD_SHAPE */
+int ga_surfel_workspace_layout(int32_t num_points, int32_t num_views, int32_t image_height, int32_t image_width,
+                               int64_t capacity, GaSurfelWorkspaceLayout *out);
+
+/* host: enqueue the whole forward (preprocess, tile binning, per-tile depth sort, blend) on `stream`
+ * (a hipStream_t passed as void* so that this header needs no HIP include). */
+int ga_surfel_forward(const GaSurfelForwardArgs *args, void *stream);
+
+/* host: library identification, e.g. "ga_mi355 surfel gfx950 r1" */
+const char *ga_surfel_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GA_SURFEL_H */

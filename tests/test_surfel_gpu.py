@@ -1,0 +1,199 @@
+"""GPU parity of the HIP surfel rasterizer (through the C-ABI) against the CPU oracle.
+
+Bars (BASELINE.json north_star): integer artefacts -- radii, tile rects, per-tile ranges and depth-ordered index
+lists -- BIT-IDENTICAL; pixels MSE <= 1e-5 per output (colour and each allmap channel).
+"""
+import numpy as np
+import pytest
+import torch
+
+from gaussiananything_amd import synthetic
+from tests import _util
+
+pytestmark = pytest.mark.gpu
+
+MSE_TOL = 1e-5
+
+
+def _compare_view(o, color, radii, allmap, art, v, N, tiles):
+    assert np.array_equal(radii, o["radii"]), "radii differ"
+    assert np.array_equal(art["rect"][v].astype(np.uint32), o["rect"]), "tile rects differ"
+    ts = art["tile_start"][v * tiles:(v + 1) * tiles + 1]
+    base = ts[0]
+    cnt_o = (o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0].astype(np.int64))
+    assert np.array_equal(np.diff(ts), cnt_o), "per-tile list lengths differ"
+    nz = cnt_o > 0
+    assert np.array_equal((ts[:-1] - base)[nz], o["ranges"][nz, 0].astype(np.int64)), "tile range starts differ"
+    pl = art["point_list"][base:base + o["D"]]
+    assert np.array_equal(pl.astype(np.uint32), o["point_list"]), "depth-ordered point lists differ"
+    mse_c = float(np.mean((color - o["color"]) ** 2))
+    assert mse_c <= MSE_TOL, f"colour MSE {mse_c}"
+    for ch in range(7):
+        mse = float(np.mean((allmap[ch] - o["allmap"][ch]) ** 2))
+        assert mse <= MSE_TOL, f"allmap[{ch}] MSE {mse}"
+    return mse_c
+
+
+def _run_case(g, cams, views, H, W, device, scale_modifier=1.0, bg=(1.0, 1.0, 1.0)):
+    N = g.shape[0]
+    color, radii, allmap, ws = _util.hip_views(g, cams, views, H, W, device, bg=bg, scale_modifier=scale_modifier)
+    art = _util.ws_artifacts(ws, N, len(views), H, W)
+    assert art["overflow"] == 0
+    color, radii, allmap = color.cpu().numpy(), radii.cpu().numpy(), allmap.cpu().numpy()
+    total = 0
+    for k, v in enumerate(views):
+        o = _util.oracle_view(g, cams, v, H, W, bg=bg, scale_modifier=scale_modifier)
+        _compare_view(o, color[k], radii[k], allmap[k], art, k, N, art["tiles"])
+        total += o["D"]
+    assert total == art["D"]
+    return art
+
+
+def test_config1_1k_256(gpu_device):
+    cams = synthetic.eval_cameras(8)
+    g = synthetic.random_surfels(1000, seed=0)[0]
+    _run_case(g, cams, [0], 256, 256, gpu_device)
+
+
+def test_config1_matches_frozen_golden(gpu_device):
+    """HIP output against the committed fixture (tests/golden/surfel_cfg1_oracle.npz), without running the oracle."""
+    z = np.load(synthetic.fixture_path("surfel_cfg1_oracle.npz"))
+    cams = synthetic.eval_cameras(1)
+    g = synthetic.random_surfels(1000, seed=0)[0]
+    color, radii, allmap, ws = _util.hip_views(g, cams, [0], 256, 256, gpu_device)
+    art = _util.ws_artifacts(ws, 1000, 1, 256, 256)
+    assert np.array_equal(radii[0].cpu().numpy(), z["radii"])
+    assert np.array_equal(art["point_list"].astype(np.uint32), z["point_list"])
+    assert np.array_equal(art["rect"][0].astype(np.uint32), z["rect"])
+    assert float(np.mean((color[0].cpu().numpy() - z["color_f16"].astype(np.float32)) ** 2)) < 1e-5
+    assert np.allclose(color[0].double().sum((1, 2)).cpu().numpy(), z["color_sum"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("H,W", [(250, 300), (16, 16), (33, 17)])
+def test_ragged_image_sizes(gpu_device, H, W):
+    cams = synthetic.eval_cameras(8)
+    g = synthetic.random_surfels(2000, seed=3)[0]
+    _run_case(g, cams, [1, 5], H, W, gpu_device)
+
+
+def test_multi_view_batch_equals_oracle_per_view(gpu_device):
+    cams = synthetic.eval_cameras(8)
+    g = synthetic.random_surfels(20000, seed=5)[0]
+    _run_case(g, cams, list(range(8)), 256, 256, gpu_device, bg=(0.2, 0.5, 0.9))
+
+
+def test_scale_modifier_and_big_splats(gpu_device):
+    cams = synthetic.eval_cameras(8)
+    g = synthetic.random_surfels(3000, seed=7)[0].clone()
+    g[:, 4:6] *= 8.0  # large splats: hundreds of tiles each
+    _run_case(g, cams, [2], 128, 128, gpu_device, scale_modifier=1.5)
+
+
+def test_long_tile_lists_take_the_run_merge_path(gpu_device):
+    """> 8192 entries in one tile: exercises the multi-run rank-merge of the per-tile sort."""
+    cams = synthetic.eval_cameras(8)
+    g = synthetic.random_surfels(30000, seed=11)[0].clone()
+    g[:, 0:3] *= 0.05  # everything lands in a couple of tiles
+    art = _run_case(g, cams, [0], 64, 64, gpu_device)
+    assert art["max_tile"] > 8192
+
+
+def test_degenerate_inputs(gpu_device):
+    """behind-camera, zero-scale, zero / tiny opacity, duplicate depths (tie-break by index), edge-on splats."""
+    cams = synthetic.eval_cameras(8)
+    g = synthetic.random_surfels(512, seed=13)[0].clone()
+    g[0:32, 0:3] = torch.tensor([5.0, 5.0, 5.0])      # far off / behind for some views
+    g[32:64, 4:6] = 0.0                                # zero scale
+    g[64:96, 3] = 0.0                                  # zero opacity
+    g[96:128, 3] = 1.0 / 300.0                         # below the alpha threshold
+    g[128:192, 0:3] = g[128:129, 0:3]                  # identical centres -> identical depth keys
+    g[192:224, 6:10] = torch.tensor([1.0, 0.0, 0.0, 0.0])
+    for v in (0, 3):
+        _run_case(g, cams, [v], 128, 128, gpu_device)
+
+
+def test_empty_scene(gpu_device):
+    cams = synthetic.eval_cameras(8)
+    g = synthetic.random_surfels(8, seed=1)[0].clone()
+    g[:, 0:3] = 100.0
+    color, radii, allmap, ws = _util.hip_views(g, cams, [0], 64, 64, gpu_device, bg=(0.1, 0.2, 0.3))
+    assert int(ws.status().cpu()[0]) == 0
+    assert torch.all(radii == 0)
+    assert torch.allclose(color[0, 1], torch.full((64, 64), 0.2, device=gpu_device))
+    assert torch.all(allmap == 0)
+
+
+def test_cull_box_is_conservative(gpu_device):
+    """Every (pixel, splat) pair the oracle blends (alpha >= 1/255) lies inside the HIP path's cull box."""
+    from oracle import surfel as osurf  # noqa: F401
+    cams = synthetic.eval_cameras(8)
+    g = synthetic.random_surfels(4000, seed=17)[0]
+    H = W = 128
+    _, _, _, ws = _util.hip_views(g, cams, [4], H, W, gpu_device)
+    art = _util.ws_artifacts(ws, 4000, 1, H, W)
+    o = _util.oracle_view(g, cams, 4, H, W)
+    vis = np.nonzero(o["radii"] > 0)[0]
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+    bad = 0
+    for i in vis[:600]:
+        Tu, Tv, Tw = o["trans"][i, 0:3], o["trans"][i, 3:6], o["trans"][i, 6:9]
+        k = xs[..., None] * Tw - Tu
+        l = ys[..., None] * Tw - Tv
+        p = np.cross(k, l)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            s = p[..., :2] / p[..., 2:3]
+        rho3d = (s ** 2).sum(-1)
+        d = o["xy"][i] - np.stack([xs, ys], -1)
+        rho = np.fmin(rho3d, 2.0 * (d ** 2).sum(-1))
+        alpha = np.minimum(0.99, o["normal_opacity"][i, 3] * np.exp(-0.5 * rho))
+        live = alpha >= 1.0 / 255.0
+        # restrict to the tiles the splat is binned into (the only pixels that can see it)
+        rc = o["rect"][i].astype(int)
+        tmask = (xs >= rc[0] * 16) & (xs < rc[2] * 16) & (ys >= rc[1] * 16) & (ys < rc[3] * 16)
+        live &= tmask
+        bb = art["bbox"][0, i]
+        inside = (xs >= bb[0]) & (xs <= bb[2]) & (ys >= bb[1]) & (ys <= bb[3])
+        bad += int(np.count_nonzero(live & ~inside))
+    assert bad == 0
+
+
+def test_drop_in_rasterizer_call(gpu_device):
+    """The reference's exact call sequence (nsr/gs_surfel.py:85-114) through the import shim."""
+    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    cams = synthetic.eval_cameras(8)
+    g = synthetic.random_surfels(1000, seed=0)[0].to(gpu_device)
+    m, op, sc, rot, rgb = synthetic.split_gaussians(g)
+    rs = GaussianRasterizationSettings(
+        image_height=256, image_width=256, tanfovx=cams["tanfov"], tanfovy=cams["tanfov"],
+        bg=torch.ones(3, device=gpu_device), scale_modifier=1, viewmatrix=cams["cam_view"][0].to(gpu_device),
+        projmatrix=cams["cam_view_proj"][0].to(gpu_device), sh_degree=0, campos=cams["cam_pos"][0].to(gpu_device),
+        prefiltered=False, debug=False)
+    image, radii, allmap = GaussianRasterizer(raster_settings=rs)(
+        means3D=m, means2D=torch.zeros_like(m), shs=None, colors_precomp=rgb, opacities=op, scales=sc,
+        rotations=rot, cov3D_precomp=None)
+    assert image.shape == (3, 256, 256) and allmap.shape == (7, 256, 256) and radii.shape == (1000,)
+    o = _util.oracle_view(g.cpu(), cams, 0, 256, 256)
+    assert float(np.mean((image.cpu().numpy() - o["color"]) ** 2)) <= MSE_TOL
+    with pytest.raises(Exception):
+        GaussianRasterizer(raster_settings=rs)(means3D=m, means2D=None, opacities=op, scales=sc, rotations=rot)
+    with pytest.raises(RuntimeError):
+        GaussianRasterizer(raster_settings=rs)(means3D=m.cpu(), means2D=None, opacities=op, colors_precomp=rgb,
+                                               scales=sc, rotations=rot)
+
+
+def test_renderer_2dgs_dict(gpu_device):
+    """GaussianRenderer2DGS.render: same keys/shapes/post-processing as nsr/gs_surfel.py:41-202."""
+    from gaussiananything_amd.gs_surfel import GaussianRenderer2DGS
+    cams = synthetic.eval_cameras(4)
+    g = synthetic.random_surfels(3000, seed=2).to(gpu_device)
+    r = GaussianRenderer2DGS(128, 3, {})
+    out = r.render(g, cams["cam_view"][None].to(gpu_device), cams["cam_view_proj"][None].to(gpu_device),
+                   cams["cam_pos"][None].to(gpu_device), cams["tanfov"])
+    assert out["image"].shape == (1, 4, 3, 128, 128) and out["rend_normal"].shape == (1, 4, 3, 128, 128)
+    for v in range(4):
+        o = _util.oracle_view(g[0].cpu(), cams, v, 128, 128)
+        view = cams["cam_view"][v].numpy()
+        nrm = np.einsum("chw,dc->dhw", o["allmap"][2:5], view[:3, :3])
+        assert float(np.mean((out["rend_normal"][0, v].cpu().numpy() - nrm) ** 2)) <= MSE_TOL
+        assert float(np.mean((out["image"][0, v].cpu().numpy() - np.clip(o["color"], 0, 1)) ** 2)) <= MSE_TOL
+        assert float(np.mean((out["depth"][0, v, 0].cpu().numpy() - o["allmap"][5]) ** 2)) <= MSE_TOL
