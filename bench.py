@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the render half of the hot path (BASELINE.json metric "Msplats/s rasterize").
+
+One STEP = one full forward of the MI355X surfel rasterizer (preprocess, tile binning, per-tile depth sort, blend)
+over BASELINE.json configs[1]: 100 000 surface-like surfels x 8 posed 512x512 views, inputs resident in HBM.
+    value = N_splats * V * steps * n_gpus / wall / 1e6          [Msplats/s]
+Multi-GPU (N>1, launched by torch.distributed.run): every rank renders its own independent sample (weak scaling, no
+data-path collective); the rendered RGB-D-N images of the last step are collected on rank 0 with ONE RCCL gather
+inside the timed region ("final image collection").
+
+Also on the JSON line:
+  roofline     -- the dominant kernel (surfel_blend_kernel): algorithmic bytes (76*D + 40*P per view) over its
+                  mean duration measured with HIP events on the launch stream during the timed steps; HBM peak 8 TB/s.
+  cpu_baseline -- the CPU oracle (oracle/surfel_raster.c, kind "port": the reference has no CPU rasterizer) timed on
+                  this host's cores on a bounded sample of the same workload.  Rank 0, N=1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_VALU_PEAK_TFLOPS = 157.3  # same guide: peak FP32 vector
+
+
+class HipEvents:
+    """hipEvent_t handles through ctypes (torch.cuda.Event only sees torch's own record calls)."""
+
+    def __init__(self, n):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.arr = (ctypes.c_void_p * n)()
+        for i in range(n):
+            ev = ctypes.c_void_p()
+            assert self.hip.hipEventCreate(ctypes.byref(ev)) == 0
+            self.arr[i] = ev
+
+    def elapsed(self, i, j):
+        ms = ctypes.c_float()
+        self.hip.hipEventSynchronize(ctypes.c_void_p(self.arr[j]))
+        rc = self.hip.hipEventElapsedTime(ctypes.byref(ms), ctypes.c_void_p(self.arr[i]), ctypes.c_void_p(self.arr[j]))
+        assert rc == 0, rc
+        return ms.value
+
+
+def cpu_baseline(g, cams, H, W, min_seconds=3.0):
+    """CPU oracle on the host cores: whole views of the SAME scene until >= min_seconds of wall time."""
+    from gaussiananything_amd import synthetic
+    from oracle import surfel as osurf
+    m, o, s, r, c = [t.numpy() for t in synthetic.split_gaussians(g)]
+    cores = osurf.lib().oracle_set_threads(0)
+    osurf.rasterize(m[:1000], o[:1000], c[:1000], s[:1000], r[:1000], cams["cam_view"][0].numpy(),
+                    cams["cam_view_proj"][0].numpy(), np.ones(3, np.float32), 64, 64)  # warm the library
+    t0 = time.perf_counter()
+    views = 0
+    while True:
+        v = views % cams["cam_view"].shape[0]
+        osurf.rasterize(m, o, c, s, r, cams["cam_view"][v].numpy(), cams["cam_view_proj"][v].numpy(),
+                        np.ones(3, np.float32), H, W)
+        views += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds and views >= 2:
+            break
+    return {"value": round(m.shape[0] * views / dt / 1e6, 4), "unit": "Msplats/s", "cores": int(cores),
+            "kind": "port",
+            "sample": f"{views} whole 512x512 views of the same 100k-surfel scene, {dt:.1f} s wall; preprocess+binning "
+                      f"single-threaded, blend OpenMP over tiles ({cores} threads); includes numpy buffer setup"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--scene", default="surface", choices=["surface", "stress"])
+    ap.add_argument("--points", type=int, default=100_000)
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-events", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from gaussiananything_amd import synthetic
+    from gaussiananything_amd.diff_surfel_rasterization import SurfelForwardPlan
+
+    H = W = a.size
+    cams = synthetic.eval_cameras(a.views)
+    # every rank renders its own independent sample (different seed), as the 8-sample cascade does
+    if a.scene == "surface":
+        g = synthetic.surface_surfels(a.points, seed=1 + rank)[0]
+    else:
+        g = synthetic.random_surfels(a.points, seed=rank)[0]
+    m, o, s, r, c = [t.to(dev) for t in synthetic.split_gaussians(g)]
+    plan = SurfelForwardPlan(m, o, c, s, r, cams["cam_view"].to(dev), cams["cam_view_proj"].to(dev),
+                             torch.ones(3, device=dev), H, W)
+    plan.run()
+    D = plan.ensure_capacity()
+    ev = None
+    if not a.no_stage_events:
+        ev = [HipEvents(5) for _ in range(a.steps)]
+    gathered = None
+    payload = None
+    if world > 1:
+        payload = torch.empty((a.views, 10, H, W), dtype=torch.float32, device=dev)
+        gathered = torch.empty((world, a.views, 10, H, W), dtype=torch.float32, device=dev) if rank == 0 else None
+
+    for _ in range(a.warmup):
+        plan.run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        if ev is not None:
+            plan.set_stage_events(ev[k].arr)
+        plan.run()
+    if world > 1:
+        payload[:, 0:3].copy_(plan.color)
+        payload[:, 3:10].copy_(plan.allmap)
+        dist.gather(payload, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    plan.set_stage_events(None)
+    st = plan.ws.status().cpu()
+    assert int(st[1]) == 0, "binned-list overflow inside the timed region"
+
+    if rank == 0:
+        n, v = a.points, a.views
+        value = n * v * a.steps * world / dt / 1e6
+        out = {
+            "metric": "Msplats/s rasterize (full forward: preprocess+binning+sort+blend)",
+            "value": round(value, 2), "unit": "Msplats/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {n} {a.scene}-scene surfel Gaussians x {v} posed {H}x{W} "
+                                   f"views, forward raster, 1 sample per GPU",
+                       "scene": a.scene, "points": n, "views": v, "image": [H, W], "num_rendered_D": int(st[0]),
+                       "longest_tile_list": int(st[2]),
+                       "multi_gpu": "independent samples per rank; one RCCL gather of [V,10,H,W] fp32 per rank to "
+                                    "rank 0 inside the timed region" if world > 1 else "single GPU"},
+        }
+        if ev is not None:
+            names = ["preprocess", "tile_scan_fill", "tile_sort", "blend"]
+            stage = {nm: float(np.mean([e.elapsed(i, i + 1) for e in ev])) for i, nm in enumerate(names)}
+            total_dev = float(np.mean([e.elapsed(0, 4) for e in ev]))
+            P = H * W
+            blend_bytes = 76.0 * int(st[0]) + 40.0 * P * v      # per launch (all V views), SURVEY.md 8d
+            achieved = blend_bytes / (stage["blend"] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "surfel_blend_kernel", "achieved": round(achieved, 2),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                               "traffic": None, "algorithmic_bytes_per_launch": int(blend_bytes),
+                               "avg_launch_ms": round(stage["blend"], 5),
+                               "note": "blend is VALU/latency-bound, not HBM-bound (SURVEY.md 8d): see blend_valu"}
+            # upper bound on evaluated (pixel, splat) pairs and the ~60 flop/pair estimate of SURVEY.md 8d
+            pairs_ub = 256.0 * int(st[0])
+            out["blend_valu"] = {"pairs_upper_bound": int(pairs_ub),
+                                 "tflops_at_60flop_per_pair": round(pairs_ub * 60 / (stage["blend"] * 1e-3) / 1e12, 3),
+                                 "peak_fp32_valu_tflops": FP32_VALU_PEAK_TFLOPS,
+                                 "frac": round(pairs_ub * 60 / (stage["blend"] * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4)}
+            out["stage_ms"] = {k: round(x, 5) for k, x in stage.items()}
+            out["stage_ms"]["device_total"] = round(total_dev, 5)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(g, cams, H, W)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libga_mi355.so")
 GA_OK = 0
 GA_STATUS_NUM_RENDERED, GA_STATUS_OVERFLOW, GA_STATUS_MAX_TILE, GA_STATUS_WORDS = 0, 1, 2, 4
 GA_SURFEL_RECORD_FLOATS = 20
+GA_SURFEL_STAGE_EVENTS = 5
 _ERR = {-1: "GA_ERR_NULL_ARG", -2: "GA_ERR_BAD_SHAPE", -3: "GA_ERR_WORKSPACE", -4: "GA_ERR_LAUNCH"}
 
 
@@ -29,6 +30,7 @@ class GaSurfelForwardArgs(ctypes.Structure):
         ("viewmatrix", ctypes.c_void_p), ("projmatrix", ctypes.c_void_p), ("bg", ctypes.c_void_p),
         ("out_color", ctypes.c_void_p), ("out_others", ctypes.c_void_p), ("radii", ctypes.c_void_p),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t), ("capacity", ctypes.c_int64),
+        ("stage_events", ctypes.POINTER(ctypes.c_void_p)),
     ]
 
 

@@ -80,11 +80,21 @@ int ga_surfel_forward(const GaSurfelForwardArgs *a, void *stream_v)
     ws.point_list = reinterpret_cast<uint32_t *>(w + L.point_list);
 
     (void)hipGetLastError();
+    // (event 0 is recorded after this memset so that it brackets kernels only)
     // status + tile counters are contiguous at the head of the workspace: one memset node clears both
     if (hipMemsetAsync(w + L.status, 0, L.tile_start - L.status, s) != hipSuccess) return GA_ERR_LAUNCH;
+    auto mark = [&](int k) {
+        if (a->stage_events && a->stage_events[k]) (void)hipEventRecord(static_cast<hipEvent_t>(a->stage_events[k]), s);
+    };
+    mark(0);
     if (d.N > 0) ga::launch_preprocess(*a, d, ws, s);
+    mark(1);
     ga::launch_binning(*a, d, ws, s);
+    mark(2);
+    ga::launch_tile_sort(*a, d, ws, s);
+    mark(3);
     ga::launch_blend(*a, d, ws, s);
+    mark(4);
     return hipGetLastError() == hipSuccess ? GA_OK : GA_ERR_LAUNCH;
 }
 

@@ -182,6 +182,11 @@ void launch_binning(const GaSurfelForwardArgs &a, const Dims &d, const Workspace
     const int64_t total = (int64_t)d.N * d.V;
     hipLaunchKernelGGL(surfel_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws.rect, ws.depth,
                        d, ws.tile_cursor, ws.keys, ws.status);
+}
+
+void launch_tile_sort(const GaSurfelForwardArgs &, const Dims &d, const Workspace &ws, hipStream_t s)
+{
+    const int nt = d.V * d.tiles;
     hipLaunchKernelGGL(surfel_tile_sort_kernel, dim3(nt), dim3(256), kSortCap * sizeof(uint64_t), s, ws.tile_start,
                        nt, ws.keys, ws.point_list, ws.status);
 }

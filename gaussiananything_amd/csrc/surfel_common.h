@@ -46,6 +46,7 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg)
 
 void launch_preprocess(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &ws, hipStream_t s);
 void launch_binning(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &ws, hipStream_t s);
+void launch_tile_sort(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &ws, hipStream_t s);
 void launch_blend(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &ws, hipStream_t s);
 
 }  // namespace ga

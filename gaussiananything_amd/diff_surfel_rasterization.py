@@ -92,14 +92,15 @@ _warned_grad = False
 
 def rasterize_views(means3D, opacities, colors_precomp, scales, rotations, viewmatrix, projmatrix, bg,
                     image_height, image_width, scale_modifier=1.0, workspace: Optional[SurfelWorkspace] = None,
-                    check_overflow: bool = True):
+                    check_overflow: bool = True, stage_events=None):
     """Rasterize V views of one Gaussian set.  ``viewmatrix`` / ``projmatrix``: ``[V,4,4]`` row-vector matrices
     (``cam_view`` / ``cam_view_proj``).  Returns ``color [V,3,H,W]``, ``radii [V,N] int32``, ``allmap [V,7,H,W]`` and
     the workspace used (its ``status()`` holds D / overflow / longest tile list).
 
     ``check_overflow=True`` reads the device status word after the launch (one host sync, as upstream's read-back of
     ``num_rendered``) and transparently re-runs with a larger workspace; with ``False`` nothing synchronises and the
-    caller inspects ``workspace.status()`` itself.
+    caller inspects ``workspace.status()`` itself.  ``stage_events``: optional ctypes array of 5 ``hipEvent_t`` (see
+    ``include/ga_surfel.h``), measurement only.
     """
     global _warned_grad
     device = means3D.device
@@ -137,7 +138,8 @@ def rasterize_views(means3D, opacities, colors_precomp, scales, rotations, viewm
             args = _lib.GaSurfelForwardArgs(
                 n, v, h, w, float(scale_modifier), 0, means3D.data_ptr(), opacities.data_ptr(), colors.data_ptr(),
                 scales.data_ptr(), rotations.data_ptr(), vm.data_ptr(), pm.data_ptr(), bg.data_ptr(),
-                color.data_ptr(), allmap.data_ptr(), radii.data_ptr(), ws.ptr, ws.layout.total_bytes, ws.capacity)
+                color.data_ptr(), allmap.data_ptr(), radii.data_ptr(), ws.ptr, ws.layout.total_bytes, ws.capacity,
+                stage_events)
             _lib.check(L.ga_surfel_forward(ctypes.byref(args), ctypes.c_void_p(stream)), "ga_surfel_forward")
             if not check_overflow:
                 break
@@ -178,3 +180,63 @@ class GaussianRasterizer(nn.Module):
             means3D, opacities, colors_precomp, scales, rotations, rs.viewmatrix.reshape(1, 4, 4),
             rs.projmatrix.reshape(1, 4, 4), rs.bg, rs.image_height, rs.image_width, rs.scale_modifier)
         return color[0], radii[0], allmap[0]
+
+
+class SurfelForwardPlan:
+    """Pre-bound ``ga_surfel_forward`` call for repeated rendering of a fixed problem shape: inputs are converted
+    once, outputs and workspace are allocated once, ``run()`` is a single C-ABI call that enqueues the five kernels on
+    the current stream without any host synchronisation (so it can also be captured into a HIP graph).
+
+    The sampling scripts render 50 cameras x 4 LoDs per sample (/root/reference/nsr/lsgm/flow_matching_trainer.py:
+    1545-1616); a plan per LoD removes the per-call tensor juggling of the reference's Python loop.
+    """
+
+    def __init__(self, means3D, opacities, colors_precomp, scales, rotations, viewmatrix, projmatrix, bg,
+                 image_height, image_width, scale_modifier=1.0, capacity=None):
+        device = means3D.device
+        self.device = device
+        self.means3D = _f32c(means3D, "means3D", device)
+        self.n = n = self.means3D.shape[0]
+        self.opacities = _f32c(opacities, "opacities", device).reshape(-1)
+        self.colors = _f32c(colors_precomp, "colors_precomp", device)
+        self.scales = _f32c(scales, "scales", device)
+        self.rotations = _f32c(rotations, "rotations", device)
+        self.vm = _f32c(viewmatrix, "viewmatrix", device).reshape(-1, 16)
+        self.pm = _f32c(projmatrix, "projmatrix", device).reshape(-1, 16)
+        self.v = v = self.vm.shape[0]
+        self.bg = _f32c(bg, "bg", device).reshape(3)
+        self.h, self.w = int(image_height), int(image_width)
+        self.scale_modifier = float(scale_modifier)
+        self.color = torch.empty((v, 3, self.h, self.w), dtype=torch.float32, device=device)
+        self.allmap = torch.empty((v, 7, self.h, self.w), dtype=torch.float32, device=device)
+        self.radii = torch.empty((v, n), dtype=torch.int32, device=device)
+        self.ws = SurfelWorkspace(device, n, v, self.h, self.w, capacity or max(4 * n * v, 1 << 16))
+        self._L = _lib.lib()
+        self._bind(None)
+
+    def _bind(self, stage_events):
+        ws = self.ws
+        self._args = _lib.GaSurfelForwardArgs(
+            self.n, self.v, self.h, self.w, self.scale_modifier, 0, self.means3D.data_ptr(),
+            self.opacities.data_ptr(), self.colors.data_ptr(), self.scales.data_ptr(), self.rotations.data_ptr(),
+            self.vm.data_ptr(), self.pm.data_ptr(), self.bg.data_ptr(), self.color.data_ptr(),
+            self.allmap.data_ptr(), self.radii.data_ptr(), ws.ptr, ws.layout.total_bytes, ws.capacity, stage_events)
+        self._argp = ctypes.byref(self._args)
+
+    def set_stage_events(self, stage_events):
+        self._bind(stage_events)
+
+    def run(self):
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._L.ga_surfel_forward(self._argp, ctypes.c_void_p(stream)), "ga_surfel_forward")
+
+    def ensure_capacity(self):
+        """One synchronising check (call once after the first run): grow the workspace and re-run on overflow."""
+        while True:
+            st = self.ws.status().cpu()
+            if int(st[_lib.GA_STATUS_OVERFLOW]) == 0:
+                return int(st[_lib.GA_STATUS_NUM_RENDERED])
+            need = int(st[_lib.GA_STATUS_NUM_RENDERED])
+            self.ws = SurfelWorkspace(self.device, self.n, self.v, self.h, self.w, need + need // 4)
+            self._bind(None)
+            self.run()

@@ -61,7 +61,12 @@ typedef struct GaSurfelForwardArgs {
     void *workspace;         /* see ga_surfel_workspace_layout                                    */
     size_t workspace_bytes;
     int64_t capacity;        /* max binned entries D the workspace was sized for                  */
+    void **stage_events;     /* host, optional (NULL = none): GA_SURFEL_STAGE_EVENTS hipEvent_t handles recorded on
+                                `stream` at the stage boundaries: [0] start, [1] after preprocess, [2] after tile scan +
+                                fill, [3] after per-tile sort, [4] after blend.  Measurement only.          */
 } GaSurfelForwardArgs;
+
+#define GA_SURFEL_STAGE_EVENTS 5
 
 #define GA_SURFEL_FLAG_NONE 0
 
