@@ -3,19 +3,27 @@
 // /root/reference/nsr/gs_surfel.py:100-114; consumer of the 7 allmap channels :121-142); arithmetic per
 // SURVEY.md Appendix A.1 "Blend".
 //
-// MI355X-first formulation ("wave-autonomous" blend), not the CUDA block-cooperative one:
+// MI355X-first formulation ("wave-autonomous" blend), not the CUDA block-cooperative one.  What the measurements on
+// MI355X showed (profiles/r1a_*): the kernel is bound by the SERIAL CHAIN of the longest tile lists and by VALU issue,
+// never by HBM; so the design minimises latency on the chain and instructions per (pixel, splat) pair:
 //   * a 256-thread workgroup still owns one 16x16 tile (that granularity is part of the semantics: the tile rect
 //     decides which pixels a splat may touch), but each of its four 64-lane wavefronts owns one 8x8 quadrant and runs
-//     completely on its own -- no LDS staging, no workgroup barrier, independent early termination;
-//   * the tile's depth-ordered list is consumed 64 entries at a time with lanes = entries: every lane fetches one
-//     entry's conservative {alpha >= 1/255} pixel box (16 B) and tests it against the quadrant; a 64-bit ballot is
-//     the list of entries that can contribute.  For the small splats of real scenes this removes about half of
-//     the (pixel, splat) evaluations, and it shortens the serial per-tile chain, which -- not HBM -- is the critical
-//     path;
-//   * survivors are walked with s_ff1 on the ballot; the entry index is then wave-uniform, so its 80-byte record is
-//     fetched through the SCALAR path (s_load_dwordx4 into SGPRs): per-splat data never occupies VGPRs or LDS
-//     bandwidth, and the inner loop is pure VALU with lanes = pixels;
-//   * rejected lanes are handled by EXEC masking; a wave leaves the list as soon as its 64 pixels are saturated.
+//     completely on its own -- no workgroup barrier, independent early termination; workgroups are scheduled longest
+//     list first (tile_order);
+//   * the tile's depth-ordered list is consumed 64 entries at a time with LANES = ENTRIES: every lane fetches one
+//     entry's conservative {alpha >= 1/255} pixel box and its 96-byte record (vector loads, all 64 in flight at
+//     once, issued one chunk AHEAD of use), tests the box against the quadrant, rebases the record's plane
+//     coefficients to the quadrant origin and parks it in a wave-private LDS slot.  A 64-bit ballot of the box test
+//     is the list of entries that can contribute (about half are culled for the sub-pixel splats of real scenes,
+//     which also halves the serial chain);
+//   * survivors are walked with s_ff1 on the ballot with LANES = PIXELS; a survivor's record is read back from LDS with
+//     broadcast ds_read_b128 (uniform address, conflict-free), double-buffered in registers one survivor ahead so the
+//     LDS latency is off the chain;
+//   * the ray/splat intersection uses the plane form p = C' + dx*A + dy*B (6 FMAs) instead of two 3-vector affine
+//     maps and a cross product (18 ops); A, B, C come from the preprocess kernel;
+//   * upstream's chain of `continue` filters is evaluated branch-free into one predicate, so a pair costs ~25 VALU
+//     instructions and one EXEC-masked region (~25 more) when it contributes; a wave leaves the list as soon as its
+//     64 pixels are saturated.
 // Pixel results are compared with the oracle by MSE (<= 1e-5, tests/), so this TU may contract to FMA and uses
 // v_rcp_f32 / v_exp_f32 instead of IEEE division and libm expf.
 #include "surfel_common.h"
@@ -26,7 +34,59 @@ struct PixelAcc {
     float T, C0, C1, C2, N0, N1, N2, Dp, M1, M2, dist, median;
 };
 
+struct Rec {  // one staged record (quadrant-relative, see the staging step) in registers
+    float4 q0, q1, q2, q3, q4;
+    float cb;
+};
+
+__device__ __forceinline__ Rec lds_read_rec(const float4 *slot)
+{
+    return Rec{slot[0], slot[1], slot[2], slot[3], slot[4], reinterpret_cast<const float *>(slot)[20]};
+}
+
+// One (pixel, splat) evaluation -- SURVEY.md A.1 "Blend".  dx, dy: this lane's pixel relative to the quadrant origin.
+// Upstream's chain of `continue` filters is evaluated branch-free into one predicate (the filters commute: each one
+// only decides whether the pair is skipped), leaving a single divergent region for the pairs that contribute.
+__device__ __forceinline__ void blend_one(const Rec &r, float dx, float dy, PixelAcc &a, bool &done)
+{
+    const float kM = kFar / (kFar - kNear);
+    // p = C' + dx*A + dy*B
+    const float p0 = fmaf(dy, r.q0.w, fmaf(dx, r.q0.x, r.q1.z));
+    const float p1 = fmaf(dy, r.q1.x, fmaf(dx, r.q0.y, r.q1.w));
+    const float p2 = fmaf(dy, r.q1.y, fmaf(dx, r.q0.z, r.q2.x));
+    const float rz = __builtin_amdgcn_rcpf(p2);
+    const float sx = p0 * rz, sy = p1 * rz;
+    const float rho3d = sx * sx + sy * sy;
+    const float ex = r.q2.y - dx, ey = r.q2.z - dy;  // centre - pixel
+    const float rho2d = kFilterInvSquare * (ex * ex + ey * ey);
+    const float rho = fminf(rho3d, rho2d);
+    const float alpha = fminf(0.99f, r.q2.w * __builtin_amdgcn_exp2f(rho * -0.72134752044f));
+    // upstream: p.z == 0 -> skip ; power = -0.5*rho > 0 -> skip (a NaN rho passes) ; alpha < 1/255 -> skip
+    const bool pass = !done && p2 != 0.0f && !(rho < 0.0f) && !(alpha < 1.0f / 255.0f);
+    if (pass) {
+        const float depth = (rho3d <= rho2d) ? fmaf(sx, r.q3.x, sy * r.q3.y) + r.q3.z : r.q3.z;
+        const float test_T = a.T * (1.0f - alpha);
+        const bool near_ok = !(depth < kNear);            // upstream: depth < near -> skip (before the alpha test)
+        const bool stop = near_ok && test_T < 0.0001f;    // upstream: done = true
+        done = done || stop;
+        if (near_ok && !stop) {
+            const float w = alpha * a.T;
+            const float A = 1.0f - a.T;
+            const float m = kM * (1.0f - kNear * __builtin_amdgcn_rcpf(depth));
+            a.dist += (m * m * A + a.M2 - 2.0f * m * a.M1) * w;
+            a.Dp += depth * w;
+            a.M1 += m * w;
+            a.M2 += m * m * w;
+            if (a.T > 0.5f) a.median = depth;
+            a.N0 += r.q3.w * w; a.N1 += r.q4.x * w; a.N2 += r.q4.y * w;
+            a.C0 += r.q4.z * w; a.C1 += r.q4.w * w; a.C2 += r.cb * w;
+            a.T = test_T;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void surfel_blend_kernel(const uint32_t *__restrict__ tile_start,
+                                                           const uint32_t *__restrict__ tile_order,
                                                            const uint32_t *__restrict__ point_list,
                                                            const float *__restrict__ bbox,
                                                            const float *__restrict__ record,
@@ -35,9 +95,9 @@ __global__ __launch_bounds__(256) void surfel_blend_kernel(const uint32_t *__res
                                                            float *__restrict__ out_others,
                                                            const int64_t *__restrict__ status)
 {
+    __shared__ __attribute__((aligned(16))) float4 stage[4][64][6];  // wave-private record slots, 24 KiB
     if (status[GA_STATUS_OVERFLOW]) return;
-    const uint32_t nt = (uint32_t)(dm.V * dm.tiles);
-    const uint32_t vt = xcd_remap(blockIdx.x, nt);
+    const uint32_t vt = tile_order[blockIdx.x];  // longest lists first (surfel_tile_scan_kernel)
     const int v = (int)(vt / (uint32_t)dm.tiles), tile = (int)(vt - (uint32_t)v * dm.tiles);
     const int tx = tile % dm.gx, ty = tile / dm.gx;
     const int lane = threadIdx.x & 63;
@@ -46,75 +106,86 @@ __global__ __launch_bounds__(256) void surfel_blend_kernel(const uint32_t *__res
     if (qx0 >= dm.W || qy0 >= dm.H) return;
     const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
     const bool inside = pxi < dm.W && pyi < dm.H;
-    const float pxf = (float)pxi, pyf = (float)pyi;
+    const float dx = (float)(lane & 7), dy = (float)(lane >> 3);
     const float qxlo = (float)qx0, qxhi = (float)(qx0 + 7), qylo = (float)qy0, qyhi = (float)(qy0 + 7);
 
     const uint32_t beg = tile_start[vt], end = tile_start[vt + 1];
     const size_t vbase = (size_t)v * dm.N;
     const float4 *__restrict__ bbox4 = reinterpret_cast<const float4 *>(bbox) + vbase;
-    const float *__restrict__ recv = record + vbase * kRec;
+    const float4 *__restrict__ rec4 = reinterpret_cast<const float4 *>(record) + vbase * (kRec / 4);
+    float4(*myslots)[6] = stage[wave];
 
     PixelAcc a = {1.0f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool done = !inside;
-    const float kM = kFar / (kFar - kNear);
+
+    // ---- software pipeline over 64-entry chunks (lanes = entries) ------------------------------------------------
+    //   iteration k consumes {bb, g0..g5} of chunk k (issued during k-1), issues them for chunk k+1 (whose ids were
+    //   issued during k-1) and issues the ids of chunk k+2
+    // Loads are unconditional (out-of-range lanes re-read entry `beg`, always valid when the list is non-empty) so that
+    // the loop body is straight-line code and the loaded registers stay untouched until the next iteration.
+    float4 bb, g0, g1, g2, g3, g4, g5;
+    uint32_t id_next;
+    {
+        const uint32_t e0 = beg + lane < end ? beg + lane : beg;
+        const uint32_t e1 = beg + 64 + lane < end ? beg + 64 + lane : beg;
+        bb = g0 = g1 = g2 = g3 = g4 = g5 = make_float4(0, 0, 0, 0);
+        id_next = 0;
+        if (beg < end) {  // wave-uniform
+            const uint32_t id0 = point_list[e0];
+            id_next = point_list[e1];
+            bb = bbox4[id0];
+            const float4 *r = rec4 + (size_t)id0 * 6;
+            g0 = r[0]; g1 = r[1]; g2 = r[2]; g3 = r[3]; g4 = r[4]; g5 = r[5];
+        }
+    }
 
     for (uint32_t base = beg; base < end; base += 64) {
         if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
-        const uint32_t e = base + lane;
-        uint32_t id = 0;
-        bool hit = false;
-        if (e < end) {
-            id = point_list[e];
-            const float4 bb = bbox4[id];
-            hit = bb.x <= qxhi && bb.z >= qxlo && bb.y <= qyhi && bb.w >= qylo;
-        }
+        const bool hit = base + lane < end && bb.x <= qxhi && bb.z >= qxlo && bb.y <= qyhi && bb.w >= qylo;
         unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-        while (mask) {
-            const int j = __builtin_ctzll(mask);
+        if (hit) {
+            // rebase to the quadrant origin: C' = C + (q0.x - ox)*A + (q0.y - oy)*B with o = rint(centre); centre -= q0
+            const float ox = rintf(g2.y), oy = rintf(g2.z);
+            const float ux = qxlo - ox, uy = qylo - oy;
+            float4 *slot = myslots[lane];
+            const float Cx = fmaf(uy, g0.w, fmaf(ux, g0.x, g1.z));
+            const float Cy = fmaf(uy, g1.x, fmaf(ux, g0.y, g1.w));
+            const float Cz = fmaf(uy, g1.y, fmaf(ux, g0.z, g2.x));
+            slot[0] = g0;
+            slot[1] = make_float4(g1.x, g1.y, Cx, Cy);
+            slot[2] = make_float4(Cz, g2.y - qxlo, g2.z - qylo, g2.w);
+            slot[3] = g3;
+            slot[4] = g4;
+            slot[5] = g5;
+        }
+        {   // issue the next chunk's loads (ids arrived during the previous iteration) and the ids after that
+            const uint32_t idn = id_next;
+            const uint32_t e2 = base + 128 + lane < end ? base + 128 + lane : beg;
+            id_next = point_list[e2];
+            bb = bbox4[idn];
+            const float4 *r = rec4 + (size_t)idn * 6;
+            g0 = r[0]; g1 = r[1]; g2 = r[2]; g3 = r[3]; g4 = r[4]; g5 = r[5];
+        }
+        if (mask == 0) continue;
+        // ---- survivors (lanes = pixels): records ping-pong between two register sets, one survivor ahead.  The
+        // look-ahead read is unconditional (it re-reads the current slot when the list is exhausted) so that the
+        // number of LDS reads in flight is the same on every path and the waits stay counted.
+        int ja = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        Rec ra = lds_read_rec(myslots[ja]);
+        while (true) {
+            const bool has_b = mask != 0;
+            const int jb = has_b ? __builtin_ctzll(mask) : ja;
             mask &= mask - 1;
-            const uint32_t sid = (uint32_t)__builtin_amdgcn_readlane((int)id, j);
-            const float4 *__restrict__ r = reinterpret_cast<const float4 *>(recv + (size_t)sid * kRec);
-            const float4 r0 = r[0], r1 = r[1], r2 = r[2];
-            const float Tux = r0.x, Tuy = r0.y, Tuz = r0.z, Tvx = r0.w, Tvy = r1.x, Tvz = r1.y;
-            const float Twx = r1.z, Twy = r1.w, Twz = r2.x, cx = r2.y, cy = r2.z, opa = r2.w;
-            if (!done) {
-                const float kx = pxf * Twx - Tux, ky = pxf * Twy - Tuy, kz = pxf * Twz - Tuz;
-                const float lx = pyf * Twx - Tvx, ly = pyf * Twy - Tvy, lz = pyf * Twz - Tvz;
-                const float p0 = ky * lz - kz * ly, p1 = kz * lx - kx * lz, p2 = kx * ly - ky * lx;
-                if (p2 != 0.0f) {
-                    const float rz = __builtin_amdgcn_rcpf(p2);
-                    const float sx = p0 * rz, sy = p1 * rz;
-                    const float rho3d = sx * sx + sy * sy;
-                    const float dx = cx - pxf, dy = cy - pyf;
-                    const float rho2d = kFilterInvSquare * (dx * dx + dy * dy);
-                    const float rho = fminf(rho3d, rho2d);
-                    const float depth = (rho3d <= rho2d) ? (sx * Twx + sy * Twy) + Twz : Twz;
-                    // power = -0.5*rho ; (power > 0) <=> rho < 0 ; NaN rho fails both tests below like upstream's min()
-                    if (!(depth < kNear) && !(rho < 0.0f)) {
-                        const float alpha = fminf(0.99f, opa * __builtin_amdgcn_exp2f(rho * -0.72134752044f));
-                        if (alpha >= 1.0f / 255.0f) {
-                            const float test_T = a.T * (1.0f - alpha);
-                            if (test_T < 0.0001f) {
-                                done = true;
-                            } else {
-                                const float4 r3 = r[3], r4 = r[4];
-                                const float w = alpha * a.T;
-                                const float A = 1.0f - a.T;
-                                const float m = kM * (1.0f - kNear * __builtin_amdgcn_rcpf(depth));
-                                a.dist += (m * m * A + a.M2 - 2.0f * m * a.M1) * w;
-                                a.Dp += depth * w;
-                                a.M1 += m * w;
-                                a.M2 += m * m * w;
-                                if (a.T > 0.5f) a.median = depth;
-                                a.N0 += r3.x * w; a.N1 += r3.y * w; a.N2 += r3.z * w;
-                                a.C0 += r4.x * w; a.C1 += r4.y * w; a.C2 += r4.z * w;
-                                a.T = test_T;
-                            }
-                        }
-                    }
-                }
-            }
-            if (__builtin_amdgcn_ballot_w64(!done) == 0) { mask = 0; }
+            const Rec rb = lds_read_rec(myslots[jb]);
+            blend_one(ra, dx, dy, a, done);
+            if (!has_b || __builtin_amdgcn_ballot_w64(!done) == 0) break;
+            const bool has_a = mask != 0;
+            ja = has_a ? __builtin_ctzll(mask) : jb;
+            mask &= mask - 1;
+            ra = lds_read_rec(myslots[ja]);
+            blend_one(rb, dx, dy, a, done);
+            if (!has_a || __builtin_amdgcn_ballot_w64(!done) == 0) break;
         }
     }
 
@@ -138,8 +209,8 @@ __global__ __launch_bounds__(256) void surfel_blend_kernel(const uint32_t *__res
 void launch_blend(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &ws, hipStream_t s)
 {
     const int nt = d.V * d.tiles;
-    hipLaunchKernelGGL(surfel_blend_kernel, dim3(nt), dim3(256), 0, s, ws.tile_start, ws.point_list, ws.bbox,
-                       ws.record, a.bg, d, a.out_color, a.out_others, ws.status);
+    hipLaunchKernelGGL(surfel_blend_kernel, dim3(nt), dim3(256), 0, s, ws.tile_start, ws.tile_order, ws.point_list,
+                       ws.bbox, ws.record, a.bg, d, a.out_color, a.out_others, ws.status);
 }
 
 }  // namespace ga

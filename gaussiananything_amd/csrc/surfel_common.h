@@ -9,16 +9,20 @@ namespace ga {
 
 constexpr int kTile = 16;              // tile edge in pixels: fixes which pixels a splat may touch (upstream BLOCK_X/Y)
 constexpr int kRec = GA_SURFEL_RECORD_FLOATS;
-// blend-ready record, 80 bytes, 16-byte aligned:
-//   [0..2] Tu  [3..5] Tv  [6..8] Tw  [9..10] centre xy  [11] opacity | [12..14] view normal  [15] -  [16..18] rgb  [19] -
-constexpr int kRecTu = 0, kRecTv = 3, kRecTw = 6, kRecXY = 9, kRecOpa = 11, kRecNrm = 12, kRecRgb = 16;
-
+// blend-ready record, 96 bytes (6 x float4), 16-byte aligned.  The ray/splat intersection of upstream's blend,
+//   k = px*Tw - Tu ; l = py*Tw - Tv ; p = cross(k, l),   is bilinear in the pixel:  p = (px-ox)*A + (py-oy)*B + C
+//   with (ox,oy) = rint(centre), U = Tu - ox*Tw, V = Tv - oy*Tw, A = V x Tw, B = Tw x U, C = U x V  (pixel-independent,
+//   so computed once per splat by the preprocess kernel):
+//   q0 = A.x A.y A.z B.x | q1 = B.y B.z C.x C.y | q2 = C.z cx cy opacity      <- needed for every evaluated pair
+//   q3 = Tw.x Tw.y Tw.z n.x | q4 = n.y n.z r g | q5 = b - - -                 <- only for pairs that contribute
 constexpr float kNear = 0.2f;          // upstream near_n
 constexpr float kFar = 100.0f;         // upstream far_n
 constexpr float kCutoff = 3.0f;
 constexpr float kFilterSize = 0.707106f;
 constexpr float kFilterInvSquare = 2.0f;
 
+constexpr int kBinSplats = 8;           // splats per thread in the preprocess / fill kernels (2048 per workgroup)
+constexpr int kLdsTiles = 8192;         // per-view tile counters aggregated in LDS up to this many tiles (32 KiB)
 constexpr int kSortCap = 8192;         // per-tile entries sorted in one LDS pass (64 KiB of u64 keys)
 
 struct Dims {
@@ -27,7 +31,7 @@ struct Dims {
 
 struct Workspace {
     int64_t *status;
-    uint32_t *tile_count, *tile_start, *tile_cursor;
+    uint32_t *tile_count, *tile_start, *tile_cursor, *tile_order;
     uint16_t *rect;
     float *depth, *bbox, *record;
     uint64_t *keys;

@@ -77,6 +77,7 @@ typedef struct GaSurfelWorkspaceLayout {
     size_t tile_count;  /* uint32[V*tiles]   entries per (view, tile)                             */
     size_t tile_start;  /* uint32[V*tiles+1] exclusive scan of tile_count                         */
     size_t tile_cursor; /* uint32[V*tiles]   scratch of the fill pass                             */
+    size_t tile_order;  /* uint32[V*tiles]   (view,tile) ids, longest lists first: workgroup -> tile schedule */
     size_t rect;        /* uint16[V*N*4]     tile rect min.x min.y max.x max.y (0 when culled)    */
     size_t depth;       /* float[V*N]        view-space depth (sort key)                          */
     size_t bbox;        /* float[V*N*4]      conservative pixel bbox of alpha >= 1/255            */
@@ -86,7 +87,7 @@ typedef struct GaSurfelWorkspaceLayout {
     size_t total_bytes;
 } GaSurfelWorkspaceLayout;
 
-#define GA_SURFEL_RECORD_FLOATS 20
+#define GA_SURFEL_RECORD_FLOATS 24
 
 /* host: fills `out` for the given problem size; returns GA_OK or GA_ERR_BAD_SHAPE */
 int ga_surfel_workspace_layout(int32_t num_points, int32_t num_views, int32_t image_height, int32_t image_width,
