@@ -41,6 +41,7 @@ int ga_surfel_workspace_layout(int32_t num_points, int32_t num_views, int32_t im
     out->tile_start = off;  off += align256((nt + 1) * 4);
     out->tile_cursor = off; off += align256(nt * 4);
     out->tile_order = off;  off += align256(nt * 4);
+    out->run_table = off;   off += align256((cap / GA_SURFEL_SORT_RUN + 1) * 8);
     out->rect = off;        off += align256(nv * 4 * sizeof(uint16_t));
     out->depth = off;       off += align256(nv * 4);
     out->bbox = off;        off += align256(nv * 16);
@@ -74,6 +75,7 @@ int ga_surfel_forward(const GaSurfelForwardArgs *a, void *stream_v)
     ws.tile_start = reinterpret_cast<uint32_t *>(w + L.tile_start);
     ws.tile_cursor = reinterpret_cast<uint32_t *>(w + L.tile_cursor);
     ws.tile_order = reinterpret_cast<uint32_t *>(w + L.tile_order);
+    ws.run_table = reinterpret_cast<uint32_t *>(w + L.run_table);
     ws.rect = reinterpret_cast<uint16_t *>(w + L.rect);
     ws.depth = reinterpret_cast<float *>(w + L.depth);
     ws.bbox = reinterpret_cast<float *>(w + L.bbox);

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void surfel_blend_kernel(const uint32_t *__res
     const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
     const bool inside = pxi < dm.W && pyi < dm.H;
     const float dx = (float)(lane & 7), dy = (float)(lane >> 3);
-    const float qxlo = (float)qx0, qxhi = (float)(qx0 + 7), qylo = (float)qy0, qyhi = (float)(qy0 + 7);
+    const float qxlo = (float)qx0, qylo = (float)qy0;
 
     const uint32_t beg = tile_start[vt], end = tile_start[vt + 1];
     const size_t vbase = (size_t)v * dm.N;
@@ -139,11 +139,29 @@ __global__ __launch_bounds__(256) void surfel_blend_kernel(const uint32_t *__res
         }
     }
 
+    // loop-invariant lane predicates "my column / row is c" as wave masks (SGPR pairs)
+    unsigned long long colsel[8], rowsel[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        colsel[c] = __builtin_amdgcn_ballot_w64((lane & 7) == c);
+        rowsel[c] = __builtin_amdgcn_ballot_w64((lane >> 3) == c);
+    }
+
     for (uint32_t base = beg; base < end; base += 64) {
         if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
-        const bool hit = base + lane < end && bb.x <= qxhi && bb.z >= qxlo && bb.y <= qyhi && bb.w >= qylo;
-        unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-        if (hit) {
+        // ---- lanes = entries: which pixel columns / rows of the quadrant does my entry's cull box cover? ----------
+        const bool valid = base + lane < end;
+        unsigned long long xm[8], ym[8], xany = 0, yany = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float fx = qxlo + (float)c, fy = qylo + (float)c;
+            xm[c] = __builtin_amdgcn_ballot_w64(valid && bb.x <= fx && bb.z >= fx);
+            ym[c] = __builtin_amdgcn_ballot_w64(valid && bb.y <= fy && bb.w >= fy);
+            xany |= xm[c];
+            yany |= ym[c];
+        }
+        const unsigned long long hitmask = xany & yany;
+        if ((hitmask >> lane) & 1ull) {
             // rebase to the quadrant origin: C' = C + (q0.x - ox)*A + (q0.y - oy)*B with o = rint(centre); centre -= q0
             const float ox = rintf(g2.y), oy = rintf(g2.z);
             const float ux = qxlo - ox, uy = qylo - oy;
@@ -166,26 +184,36 @@ __global__ __launch_bounds__(256) void surfel_blend_kernel(const uint32_t *__res
             const float4 *r = rec4 + (size_t)idn * 6;
             g0 = r[0]; g1 = r[1]; g2 = r[2]; g3 = r[3]; g4 = r[4]; g5 = r[5];
         }
-        if (mask == 0) continue;
-        // ---- survivors (lanes = pixels): records ping-pong between two register sets, one survivor ahead.  The
-        // look-ahead read is unconditional (it re-reads the current slot when the list is exhausted) so that the
-        // number of LDS reads in flight is the same on every path and the waits stay counted.
-        int ja = __builtin_ctzll(mask);
-        mask &= mask - 1;
+        if (hitmask == 0) continue;
+        // ---- lanes = pixels: my own survivor list = entries whose box covers MY column and MY row ---------------
+        unsigned long long mx = xm[0], my = ym[0];
+#pragma unroll
+        for (int c = 1; c < 8; ++c) {
+            mx = ((colsel[c] >> lane) & 1ull) ? xm[c] : mx;
+            my = ((rowsel[c] >> lane) & 1ull) ? ym[c] : my;
+        }
+        unsigned long long m = done ? 0ull : (mx & my);
+        // Records ping-pong between two register sets, one entry ahead; lanes walk their own lists independently
+        // (compositing order only matters per pixel).  A lane whose list is exhausted re-reads its last slot.
+        int ja = m ? __builtin_ctzll(m) : lane;
+        bool live_a = m != 0;
+        m &= m - 1;
         Rec ra = lds_read_rec(myslots[ja]);
         while (true) {
-            const bool has_b = mask != 0;
-            const int jb = has_b ? __builtin_ctzll(mask) : ja;
-            mask &= mask - 1;
+            const bool live_b = m != 0;
+            const int jb = live_b ? __builtin_ctzll(m) : ja;
+            m &= m - 1;
             const Rec rb = lds_read_rec(myslots[jb]);
-            blend_one(ra, dx, dy, a, done);
-            if (!has_b || __builtin_amdgcn_ballot_w64(!done) == 0) break;
-            const bool has_a = mask != 0;
-            ja = has_a ? __builtin_ctzll(mask) : jb;
-            mask &= mask - 1;
+            if (live_a) blend_one(ra, dx, dy, a, done);
+            if (done) m = 0;
+            if (__builtin_amdgcn_ballot_w64(live_b && !done) == 0) break;
+            live_a = m != 0;
+            ja = live_a ? __builtin_ctzll(m) : jb;
+            m &= m - 1;
             ra = lds_read_rec(myslots[ja]);
-            blend_one(rb, dx, dy, a, done);
-            if (!has_a || __builtin_amdgcn_ballot_w64(!done) == 0) break;
+            if (live_b) blend_one(rb, dx, dy, a, done);
+            if (done) m = 0;
+            if (__builtin_amdgcn_ballot_w64(live_a && !done) == 0) break;
         }
     }
 

@@ -23,7 +23,7 @@ constexpr float kFilterInvSquare = 2.0f;
 
 constexpr int kBinSplats = 8;           // splats per thread in the preprocess / fill kernels (2048 per workgroup)
 constexpr int kLdsTiles = 8192;         // per-view tile counters aggregated in LDS up to this many tiles (32 KiB)
-constexpr int kSortCap = 8192;         // per-tile entries sorted in one LDS pass (64 KiB of u64 keys)
+constexpr int kSortCap = GA_SURFEL_SORT_RUN;         // per-tile entries sorted in one LDS pass (16 KiB of u64 keys: 8+ workgroups per CU)
 
 struct Dims {
     int N, V, H, W, gx, gy, tiles;     // tiles = gx*gy per view
@@ -31,7 +31,7 @@ struct Dims {
 
 struct Workspace {
     int64_t *status;
-    uint32_t *tile_count, *tile_start, *tile_cursor, *tile_order;
+    uint32_t *tile_count, *tile_start, *tile_cursor, *tile_order, *run_table;
     uint16_t *rect;
     float *depth, *bbox, *record;
     uint64_t *keys;

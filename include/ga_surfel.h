@@ -38,6 +38,7 @@ extern "C" {
 #define GA_STATUS_NUM_RENDERED 0   /* D = sum over views of tiles touched (upstream `num_rendered`) */
 #define GA_STATUS_OVERFLOW 1       /* 1 if D > capacity: outputs are then NOT written; retry with more capacity */
 #define GA_STATUS_MAX_TILE 2       /* longest per-tile list (diagnostic)                           */
+#define GA_STATUS_EXTRA_RUNS 3     /* number of entries of run_table (internal)                    */
 #define GA_STATUS_WORDS 4
 
 typedef struct GaSurfelForwardArgs {
@@ -78,6 +79,7 @@ typedef struct GaSurfelWorkspaceLayout {
     size_t tile_start;  /* uint32[V*tiles+1] exclusive scan of tile_count                         */
     size_t tile_cursor; /* uint32[V*tiles]   scratch of the fill pass                             */
     size_t tile_order;  /* uint32[V*tiles]   (view,tile) ids, longest lists first: workgroup -> tile schedule */
+    size_t run_table;   /* uint32[2*(capacity/GA_SURFEL_SORT_RUN+1)] (tile id, run index) of the 2nd.. sort runs of long lists */
     size_t rect;        /* uint16[V*N*4]     tile rect min.x min.y max.x max.y (0 when culled)    */
     size_t depth;       /* float[V*N]        view-space depth (sort key)                          */
     size_t bbox;        /* float[V*N*4]      conservative pixel bbox of alpha >= 1/255            */
@@ -88,6 +90,7 @@ typedef struct GaSurfelWorkspaceLayout {
 } GaSurfelWorkspaceLayout;
 
 #define GA_SURFEL_RECORD_FLOATS 24
+#define GA_SURFEL_SORT_RUN 2048    /* entries sorted per LDS pass of the per-tile sort */
 
 /* host: fills `out` for the given problem size; returns GA_OK or GA_ERR_BAD_SHAPE */
 int ga_surfel_workspace_layout(int32_t num_points, int32_t num_views, int32_t image_height, int32_t image_width,

@@ -90,7 +90,7 @@ def test_scale_modifier_and_big_splats(gpu_device):
 
 
 def test_long_tile_lists_take_the_run_merge_path(gpu_device):
-    """> 8192 entries in one tile: exercises the multi-run rank-merge of the per-tile sort."""
+    """> 8192 entries in one tile (several LDS runs): exercises the multi-run rank-merge of the per-tile sort."""
     cams = synthetic.eval_cameras(8)
     g = synthetic.random_surfels(30000, seed=11)[0].clone()
     g[:, 0:3] *= 0.05  # everything lands in a couple of tiles
