@@ -39,9 +39,11 @@ struct Rec {  // one staged record (quadrant-relative, see the staging step) in 
     float cb;
 };
 
-__device__ __forceinline__ Rec lds_read_rec(const float4 *slot)
+// LDS image of a wave's staged chunk: six planes of 64 float4 (plane q holds quad q of every slot), so that the
+// staging writes are contiguous and a gather of 16 different slots spreads over all 64 banks.
+__device__ __forceinline__ Rec lds_read_rec(const float4 (*planes)[64], int j)
 {
-    return Rec{slot[0], slot[1], slot[2], slot[3], slot[4], reinterpret_cast<const float *>(slot)[20]};
+    return Rec{planes[0][j], planes[1][j], planes[2][j], planes[3][j], planes[4][j], planes[5][j].x};
 }
 
 // One (pixel, splat) evaluation -- SURVEY.md A.1 "Blend".  dx, dy: this lane's pixel relative to the quadrant origin.
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void surfel_blend_kernel(const uint32_t *__res
                                                            float *__restrict__ out_others,
                                                            const int64_t *__restrict__ status)
 {
-    __shared__ __attribute__((aligned(16))) float4 stage[4][64][6];  // wave-private record slots, 24 KiB
+    __shared__ __attribute__((aligned(16))) float4 stage[4][6][64];  // wave-private record planes, 24 KiB
     if (status[GA_STATUS_OVERFLOW]) return;
     const uint32_t vt = tile_order[blockIdx.x];  // longest lists first (surfel_tile_scan_kernel)
     const int v = (int)(vt / (uint32_t)dm.tiles), tile = (int)(vt - (uint32_t)v * dm.tiles);
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void surfel_blend_kernel(const uint32_t *__res
     const size_t vbase = (size_t)v * dm.N;
     const float4 *__restrict__ bbox4 = reinterpret_cast<const float4 *>(bbox) + vbase;
     const float4 *__restrict__ rec4 = reinterpret_cast<const float4 *>(record) + vbase * (kRec / 4);
-    float4(*myslots)[6] = stage[wave];
+    float4(*planes)[64] = stage[wave];
 
     PixelAcc a = {1.0f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool done = !inside;
@@ -165,16 +167,15 @@ __global__ __launch_bounds__(256) void surfel_blend_kernel(const uint32_t *__res
             // rebase to the quadrant origin: C' = C + (q0.x - ox)*A + (q0.y - oy)*B with o = rint(centre); centre -= q0
             const float ox = rintf(g2.y), oy = rintf(g2.z);
             const float ux = qxlo - ox, uy = qylo - oy;
-            float4 *slot = myslots[lane];
             const float Cx = fmaf(uy, g0.w, fmaf(ux, g0.x, g1.z));
             const float Cy = fmaf(uy, g1.x, fmaf(ux, g0.y, g1.w));
             const float Cz = fmaf(uy, g1.y, fmaf(ux, g0.z, g2.x));
-            slot[0] = g0;
-            slot[1] = make_float4(g1.x, g1.y, Cx, Cy);
-            slot[2] = make_float4(Cz, g2.y - qxlo, g2.z - qylo, g2.w);
-            slot[3] = g3;
-            slot[4] = g4;
-            slot[5] = g5;
+            planes[0][lane] = g0;
+            planes[1][lane] = make_float4(g1.x, g1.y, Cx, Cy);
+            planes[2][lane] = make_float4(Cz, g2.y - qxlo, g2.z - qylo, g2.w);
+            planes[3][lane] = g3;
+            planes[4][lane] = g4;
+            planes[5][lane] = g5;
         }
         {   // issue the next chunk's loads (ids arrived during the previous iteration) and the ids after that
             const uint32_t idn = id_next;
@@ -198,19 +199,19 @@ __global__ __launch_bounds__(256) void surfel_blend_kernel(const uint32_t *__res
         int ja = m ? __builtin_ctzll(m) : lane;
         bool live_a = m != 0;
         m &= m - 1;
-        Rec ra = lds_read_rec(myslots[ja]);
+        Rec ra = lds_read_rec(planes, ja);
         while (true) {
             const bool live_b = m != 0;
             const int jb = live_b ? __builtin_ctzll(m) : ja;
             m &= m - 1;
-            const Rec rb = lds_read_rec(myslots[jb]);
+            const Rec rb = lds_read_rec(planes, jb);
             if (live_a) blend_one(ra, dx, dy, a, done);
             if (done) m = 0;
             if (__builtin_amdgcn_ballot_w64(live_b && !done) == 0) break;
             live_a = m != 0;
             ja = live_a ? __builtin_ctzll(m) : jb;
             m &= m - 1;
-            ra = lds_read_rec(myslots[ja]);
+            ra = lds_read_rec(planes, ja);
             if (live_b) blend_one(rb, dx, dy, a, done);
             if (done) m = 0;
             if (__builtin_amdgcn_ballot_w64(live_a && !done) == 0) break;
