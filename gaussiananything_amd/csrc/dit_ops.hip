@@ -1,0 +1,404 @@
+// dit_ops.hip -- the HBM-bound row kernels around the DiT GEMMs, gfx950.  Each fuses what the reference runs as several
+// elementwise torch ops:
+//   rmsnorm_modulate_kernel : RMSNorm (dit/norm.py:29-43) + t2i_modulate (dit_models_xformers.py:53-54) + bf16 cast
+//   small_linear_kernel     : the conditioning path's few-row Linear layers with SiLU (TimestepEmbedder :88-128,
+//                             pooled_vec_embedder dit_i23d.py:501-509, adaLN_modulation :209-214)
+//   timestep_freq_kernel    : sinusoidal features of t (TimestepEmbedder.timestep_embedding)
+//   layernorm_rows_kernel   : LayerNorm with affine of the pooled image vector (pooled_vec_embedder.0)
+//   mod_table_kernel        : (scale_shift_table[None] + t0.reshape(B,6,-1)) for all blocks at once (:769-770)
+//   embed_tokens_kernel     : x_embedder.fc1 + tanh-GELU (timm Mlp, K = 3 or 10) and the NeRF positional encoding +
+//                             xyz_projection of stage 2 (vit_triplane.py:187-229, utils/nerf_utils.py:16-66)
+//   final_layer_kernel      : T2IFinalLayer (dit_models_xformers.py:62-85): LayerNorm(no affine) + modulate + Linear
+// All are one-wave-per-row with 16-byte accesses where the layout allows.
+#include "dit_common.h"
+
+namespace gadit {
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rmsnorm_modulate_kernel(GaRmsNormArgs a)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= a.M) return;
+    const int D = a.D;
+    const float *x = a.x + (size_t)row * D;
+    float4 v[8];  // D <= 2048, D % 4 == 0: lane owns the float4 at d = c*256 + lane*4 of every 256-wide chunk c
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int d = c * 256 + lane * 4;
+        if (d < D) {
+            v[c] = *reinterpret_cast<const float4 *>(x + d);
+            ss += v[c].x * v[c].x + v[c].y * v[c].y + v[c].z * v[c].z + v[c].w * v[c].w;
+        }
+    }
+    ss = wave_sum(ss);
+    const float rs = rsqrtf(ss / (float)D + 1e-5f);
+    const int b = row / a.rows_per_batch;
+    const float *sc = a.scale ? a.scale + (size_t)b * a.mod_stride : nullptr;
+    const float *sh = a.shift ? a.shift + (size_t)b * a.mod_stride : nullptr;
+    uint16_t *o = a.out + (size_t)row * D;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int d = c * 256 + lane * 4;
+        if (d < D) {
+            const float4 w = *reinterpret_cast<const float4 *>(a.weight + d);
+            float y[4] = {v[c].x * rs * w.x, v[c].y * rs * w.y, v[c].z * rs * w.z, v[c].w * rs * w.w};
+            if (sc) {
+                const float4 s4 = *reinterpret_cast<const float4 *>(sc + d), h4 = *reinterpret_cast<const float4 *>(sh + d);
+                y[0] = y[0] * (1.f + s4.x) + h4.x; y[1] = y[1] * (1.f + s4.y) + h4.y;
+                y[2] = y[2] * (1.f + s4.z) + h4.z; y[3] = y[3] * (1.f + s4.w) + h4.w;
+            }
+            *reinterpret_cast<uint2 *>(o + d) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
+
+__global__ __launch_bounds__(256) void small_linear_kernel(GaSmallLinearArgs a)
+{
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= a.N) return;
+    float acc[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) acc[b] = 0.f;
+    const uint16_t *w = a.W + (size_t)n * a.K;
+    for (int k = lane; k < a.K; k += 64) {
+        const float wv = bf16_to_f32(w[k]);
+#pragma unroll
+        for (int b = 0; b < 16; ++b)
+            if (b < a.B) {
+                float xv = a.x[(size_t)b * a.K + k];
+                if (a.act_in == 1) xv = silu(xv);
+                // the reference runs these Linear layers under bf16 autocast: inputs are rounded to bf16
+                acc[b] += bf16_to_f32(f32_to_bf16(xv)) * wv;
+            }
+    }
+#pragma unroll
+    for (int b = 0; b < 16; ++b)
+        if (b < a.B) {
+            float v = wave_sum(acc[b]);
+            if (lane == 0) {
+                if (a.bias) v += a.bias[n];
+                if (a.act_out == 1) v = silu(v);
+                if (a.add) v += a.add[(size_t)b * a.N + n];
+                a.y[(size_t)b * a.N + n] = v;
+            }
+        }
+}
+
+__global__ void timestep_freq_kernel(const float *__restrict__ t, float *__restrict__ out, int B)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // B * 256
+    if (i >= B * 256) return;
+    const int b = i >> 8, j = i & 255, half = 128;
+    const int f = j < half ? j : j - half;
+    const float freq = expf(-9.210340371976184f * (float)f / (float)half);  // ln(10000)
+    const float arg = t[b] * freq;
+    out[i] = j < half ? cosf(arg) : sinf(arg);
+}
+
+__global__ __launch_bounds__(64) void layernorm_rows_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                            const float *__restrict__ bias, float *__restrict__ y,
+                                                            int D, float eps)
+{
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const float *xr = x + (size_t)row * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += xr[d];
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+    for (int d = lane; d < D; d += 64) { const float c = xr[d] - mean; q += c * c; }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    for (int d = lane; d < D; d += 64) y[(size_t)row * D + d] = (xr[d] - mean) * rs * w[d] + bias[d];
+}
+
+// mod[blk][b][j][d] = table_blk[j][d] + t0[b][j*D + d]      (j = shift_msa scale_msa gate_msa shift_mlp scale_mlp gate_mlp)
+struct ModTableArgs {
+    const float *tables[64];
+    const float *t0;
+    float *mod;
+    int depth, B, D;
+};
+
+__global__ void mod_table_kernel(ModTableArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per_blk = (int64_t)a.B * 6 * a.D;
+    if (i >= per_blk * a.depth) return;
+    const int blk = (int)(i / per_blk);
+    const int64_t r = i - (int64_t)blk * per_blk;
+    const int b = (int)(r / (6 * a.D)), jd = (int)(r - (int64_t)b * 6 * a.D);
+    a.mod[i] = a.tables[blk][jd] + a.t0[(size_t)b * 6 * a.D + jd];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// h[m][n] = gelu_tanh(sum_c x[m][c] W1[n][c] + b1[n]) as bf16 (A operand of the x_embedder.fc2 GEMM) and, for stage 2,
+// xres[m][n] = sum_j PE(xyz[m])[j] Wx[n][j] + bx[n]  (fp32 residual stream start; fc2 is accumulated on top).
+struct EmbedArgs {
+    int M, D, C, stage2;
+    const float *x, *w1, *b1, *xyz, *wx, *bx;
+    uint16_t *h;
+    float *xres;
+};
+
+__global__ __launch_bounds__(256) void embed_tokens_kernel(EmbedArgs a)
+{
+    __shared__ float sx[16];
+    __shared__ float spe[64];
+    const int m = blockIdx.x;
+    if (threadIdx.x < a.C) sx[threadIdx.x] = bf16_to_f32(f32_to_bf16(a.x[(size_t)m * a.C + threadIdx.x]));  // autocast
+    if (a.stage2 && threadIdx.x < 63) {
+        // [x, sin(2^k x), cos(2^k x)]_{k=0..9}: index 3 + 6k + {0..2 sin, 3..5 cos}
+        const int j = threadIdx.x;
+        float v;
+        if (j < 3) v = a.xyz[(size_t)m * 3 + j];
+        else {
+            const int k = (j - 3) / 6, r = (j - 3) % 6, c = r % 3;
+            const float arg = a.xyz[(size_t)m * 3 + c] * (float)(1 << k);
+            v = r < 3 ? sinf(arg) : cosf(arg);
+        }
+        spe[j] = bf16_to_f32(f32_to_bf16(v));
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < a.D; n += 256) {
+        float acc = a.b1[n];
+        for (int c = 0; c < a.C; ++c) acc += sx[c] * bf16_to_f32(f32_to_bf16(a.w1[(size_t)n * a.C + c]));
+        const float u = 0.7978845608028654f * (acc + 0.044715f * acc * acc * acc);
+        a.h[(size_t)m * a.D + n] = f32_to_bf16(0.5f * acc * (1.0f + tanhf(u)));
+        float r = 0.f;
+        if (a.stage2) {
+            r = a.bx[n];
+            for (int j = 0; j < 63; ++j) r += spe[j] * bf16_to_f32(f32_to_bf16(a.wx[(size_t)n * 63 + j]));
+        }
+        a.xres[(size_t)m * a.D + n] = r;
+    }
+}
+
+// out[m][c] = sum_d (LN(x[m])[d] * (1 + scale[b][d]) + shift[b][d]) * W[c][d] + bias[c];  (shift, scale) = table + t
+struct FinalArgs {
+    int M, D, Cout, rows_per_batch;
+    const float *x, *table, *t, *w, *bias;
+    float *out;
+};
+
+__global__ __launch_bounds__(256) void final_layer_kernel(FinalArgs a)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= a.M) return;
+    const int D = a.D, b = row / a.rows_per_batch;
+    const float *x = a.x + (size_t)row * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += x[d];
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+    for (int d = lane; d < D; d += 64) { const float c = x[d] - mean; q += c * c; }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + 1e-6f);
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float shift = a.table[d] + a.t[(size_t)b * D + d];
+        const float scale = a.table[D + d] + a.t[(size_t)b * D + d];
+        const float y = bf16_to_f32(f32_to_bf16((x[d] - mean) * rs * (1.0f + scale) + shift));
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < a.Cout) acc[c] += y * bf16_to_f32(f32_to_bf16(a.w[(size_t)c * D + d]));
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+        if (c < a.Cout) {
+            const float v = wave_sum(acc[c]);
+            if (lane == 0) a.out[(size_t)row * a.Cout + c] = v + a.bias[c];
+        }
+}
+
+}  // namespace gadit
+
+extern "C" int ga_rmsnorm_modulate(const GaRmsNormArgs *a, void *stream)
+{
+    using namespace gadit;
+    if (!a || !a->x || !a->weight || !a->out) return GA_DIT_ERR_NULL_ARG;
+    if (a->M <= 0 || a->D <= 0 || a->D % 4 != 0 || a->D > 2048 || a->rows_per_batch <= 0 ||
+        ((a->scale == nullptr) != (a->shift == nullptr)))
+        return GA_DIT_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(rmsnorm_modulate_kernel, dim3((a->M + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
+    return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
+}
+
+extern "C" int ga_small_linear(const GaSmallLinearArgs *a, void *stream)
+{
+    using namespace gadit;
+    if (!a || !a->x || !a->W || !a->y) return GA_DIT_ERR_NULL_ARG;
+    if (a->B <= 0 || a->B > 16 || a->N <= 0 || a->K <= 0) return GA_DIT_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(small_linear_kernel, dim3((a->N + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
+    return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
+}
+
+// =================================================================================================================
+// Whole forward: launch sequence of one function evaluation (see include/ga_dit.h).  ~11 launches per block; nothing
+// synchronises, so the caller can capture it in a HIP graph.
+namespace gadit {
+
+struct Ws {
+    float *xres, *tfreq, *t1, *pln, *pvec, *tvec, *t0, *mod;
+    uint16_t *xn, *qkv, *att, *hmid;
+    size_t total;
+};
+
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static Ws carve(const GaDitModel *m, int B, int L, void *base)
+{
+    const size_t M = (size_t)B * L, D = m->hidden;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
+    unsigned char *p = static_cast<unsigned char *>(base);
+    Ws w;
+    const size_t o_xres = take(M * D * 4), o_xn = take(M * D * 2), o_qkv = take(M * 3 * D * 2), o_att = take(M * D * 2);
+    const size_t o_hmid = take(M * 4 * D * 2), o_tfreq = take((size_t)B * 256 * 4), o_t1 = take((size_t)B * D * 4);
+    const size_t o_pln = take((size_t)B * m->context_dim * 4), o_pvec = take((size_t)B * D * 4);
+    const size_t o_tvec = take((size_t)B * D * 4), o_t0 = take((size_t)B * 6 * D * 4);
+    const size_t o_mod = take((size_t)m->depth * B * 6 * D * 4);
+    w.total = off;
+    w.xres = reinterpret_cast<float *>(p + o_xres); w.xn = reinterpret_cast<uint16_t *>(p + o_xn);
+    w.qkv = reinterpret_cast<uint16_t *>(p + o_qkv); w.att = reinterpret_cast<uint16_t *>(p + o_att);
+    w.hmid = reinterpret_cast<uint16_t *>(p + o_hmid); w.tfreq = reinterpret_cast<float *>(p + o_tfreq);
+    w.t1 = reinterpret_cast<float *>(p + o_t1); w.pln = reinterpret_cast<float *>(p + o_pln);
+    w.pvec = reinterpret_cast<float *>(p + o_pvec); w.tvec = reinterpret_cast<float *>(p + o_tvec);
+    w.t0 = reinterpret_cast<float *>(p + o_t0); w.mod = reinterpret_cast<float *>(p + o_mod);
+    return w;
+}
+
+static bool model_ok(const GaDitModel *m)
+{
+    return m && m->blocks && m->hidden > 0 && m->hidden % 64 == 0 && m->hidden <= 2048 && m->depth > 0 && m->depth <= 64 &&
+           m->heads * 64 == m->hidden && m->in_channels > 0 && m->in_channels <= 16 && m->out_channels > 0 &&
+           m->out_channels <= 16 && m->context_dim > 0 && m->context_dim % 64 == 0;
+}
+
+}  // namespace gadit
+
+extern "C" const char *ga_dit_version(void) { return "ga_mi355 dit gfx950 r1"; }
+
+extern "C" size_t ga_dit_workspace_bytes(const GaDitModel *m, int32_t batch, int32_t tokens, int32_t ctx_tokens)
+{
+    (void)ctx_tokens;
+    if (!gadit::model_ok(m) || batch <= 0 || tokens <= 0) return 0;
+    return gadit::carve(m, batch, tokens, nullptr).total;
+}
+
+#define GA_TRY(expr) do { const int rc_ = (expr); if (rc_ != GA_DIT_OK) return rc_; } while (0)
+
+extern "C" int ga_dit_cache_context(const GaDitModel *m, int32_t batch, int32_t ctx_tokens, const ga_bf16 *ctx,
+                                    ga_bf16 *ca_kv, void *stream)
+{
+    if (!gadit::model_ok(m) || !ctx || !ca_kv) return GA_DIT_ERR_NULL_ARG;
+    if (batch <= 0 || ctx_tokens <= 0) return GA_DIT_ERR_BAD_SHAPE;
+    const int rows = batch * ctx_tokens, D = m->hidden;
+    for (int i = 0; i < m->depth; ++i) {
+        GaGemmArgs g{};
+        g.M = rows; g.N = 2 * D; g.K = m->context_dim; g.epilogue = GA_GEMM_EPI_STORE_BF16;
+        g.A = ctx; g.lda = m->context_dim; g.W = m->blocks[i].ca_kv_w; g.bias = nullptr;
+        g.out = ca_kv + (size_t)i * rows * 2 * D; g.ldo = 2 * D;
+        GA_TRY(ga_gemm_bf16(&g, stream));
+    }
+    return GA_DIT_OK;
+}
+
+extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, void *stream)
+{
+    using namespace gadit;
+    if (!model_ok(m) || !a) return GA_DIT_ERR_NULL_ARG;
+    if (!a->x || !a->timesteps || !a->img_vector || !a->ca_kv || !a->out || !a->workspace) return GA_DIT_ERR_NULL_ARG;
+    if (m->stage2 && !a->fps_xyz) return GA_DIT_ERR_NULL_ARG;
+    const int B = a->batch, L = a->tokens, D = m->hidden, Mrows = B * L;
+    if (B <= 0 || B > 16 || L <= 0 || a->ctx_tokens <= 0) return GA_DIT_ERR_BAD_SHAPE;
+    const Ws w = carve(m, B, L, a->workspace);
+    if (a->workspace_bytes < w.total || ((uintptr_t)a->workspace & 255)) return GA_DIT_ERR_BAD_SHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    (void)hipGetLastError();
+
+    // ---- conditioning path: t = t_embedder(timesteps) + pooled_vec_embedder(img_vector); t0 = adaLN(SiLU(t))
+    hipLaunchKernelGGL(timestep_freq_kernel, dim3((B * 256 + 255) / 256), dim3(256), 0, s, a->timesteps, w.tfreq, B);
+    GaSmallLinearArgs l1{B, D, 256, 0, 1, w.tfreq, m->t_mlp0_w, m->t_mlp0_b, nullptr, w.t1};
+    GA_TRY(ga_small_linear(&l1, stream));
+    hipLaunchKernelGGL(layernorm_rows_kernel, dim3(B), dim3(64), 0, s, a->img_vector, m->pool_ln_w, m->pool_ln_b, w.pln,
+                       m->context_dim, 1e-5f);
+    GaSmallLinearArgs l2{B, D, m->context_dim, 0, 0, w.pln, m->pool_w, m->pool_b, nullptr, w.pvec};
+    GA_TRY(ga_small_linear(&l2, stream));
+    GaSmallLinearArgs l3{B, D, D, 0, 0, w.t1, m->t_mlp2_w, m->t_mlp2_b, w.pvec, w.tvec};
+    GA_TRY(ga_small_linear(&l3, stream));
+    GaSmallLinearArgs l4{B, 6 * D, D, 1, 0, w.tvec, m->adaln_w, m->adaln_b, nullptr, w.t0};
+    GA_TRY(ga_small_linear(&l4, stream));
+    {
+        ModTableArgs mt{};
+        for (int i = 0; i < m->depth; ++i) mt.tables[i] = m->blocks[i].scale_shift_table;
+        mt.t0 = w.t0; mt.mod = w.mod; mt.depth = m->depth; mt.B = B; mt.D = D;
+        const int64_t tot = (int64_t)m->depth * B * 6 * D;
+        hipLaunchKernelGGL(mod_table_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, mt);
+    }
+    // ---- token embedding: x = fc2(gelu_tanh(fc1(x))) (+ xyz positional embedding)
+    {
+        EmbedArgs e{Mrows, D, m->in_channels, m->stage2, a->x, m->xe_fc1_w, m->xe_fc1_b, a->fps_xyz, m->xyz_w, m->xyz_b,
+                    w.xn, w.xres};
+        hipLaunchKernelGGL(embed_tokens_kernel, dim3(Mrows), dim3(256), 0, s, e);
+        GaGemmArgs g{};
+        g.M = Mrows; g.N = D; g.K = D; g.epilogue = GA_GEMM_EPI_RESIDUAL; g.A = w.xn; g.lda = D; g.W = m->xe_fc2_w;
+        g.bias = m->xe_fc2_b; g.out = w.xres; g.ldo = D; g.gate = nullptr; g.rows_per_batch = L;
+        GA_TRY(ga_gemm_bf16(&g, stream));
+    }
+    const size_t kv_rows = (size_t)B * a->ctx_tokens;
+    for (int i = 0; i < m->depth; ++i) {
+        const GaDitBlockWeights &bw = m->blocks[i];
+        const float *mod = w.mod + (size_t)i * B * 6 * D;  // [B][6][D]: shift_msa scale_msa gate_msa shift_mlp scale_mlp gate_mlp
+        // cross-attention on the image tokens
+        GaRmsNormArgs n0{Mrows, D, L, w.xres, bw.prenorm_ca_w, nullptr, nullptr, 0, w.xn};
+        GA_TRY(ga_rmsnorm_modulate(&n0, stream));
+        GaGemmArgs gq{};
+        gq.M = Mrows; gq.N = D; gq.K = D; gq.epilogue = GA_GEMM_EPI_STORE_BF16; gq.A = w.xn; gq.lda = D; gq.W = bw.ca_q_w;
+        gq.out = w.qkv; gq.ldo = D;
+        GA_TRY(ga_gemm_bf16(&gq, stream));
+        const ga_bf16 *kv = a->ca_kv + (size_t)i * kv_rows * 2 * D;
+        GaAttentionArgs ca{B, m->heads, L, a->ctx_tokens, w.qkv, kv, kv + D, D, 2 * D, 2 * D, bw.ca_q_norm_w,
+                           bw.ca_k_norm_w, w.att, D};
+        GA_TRY(ga_attention_bf16(&ca, stream));
+        GaGemmArgs go{};
+        go.M = Mrows; go.N = D; go.K = D; go.epilogue = GA_GEMM_EPI_RESIDUAL; go.A = w.att; go.lda = D; go.W = bw.ca_out_w;
+        go.bias = bw.ca_out_b; go.out = w.xres; go.ldo = D; go.gate = nullptr; go.rows_per_batch = L;
+        GA_TRY(ga_gemm_bf16(&go, stream));
+        // self-attention
+        GaRmsNormArgs n1{Mrows, D, L, w.xres, bw.norm1_w, mod + 1 * D, mod + 0 * D, 6 * (int64_t)D, w.xn};
+        GA_TRY(ga_rmsnorm_modulate(&n1, stream));
+        GaGemmArgs gqkv{};
+        gqkv.M = Mrows; gqkv.N = 3 * D; gqkv.K = D; gqkv.epilogue = GA_GEMM_EPI_STORE_BF16; gqkv.A = w.xn; gqkv.lda = D;
+        gqkv.W = bw.qkv_w; gqkv.bias = bw.qkv_b; gqkv.out = w.qkv; gqkv.ldo = 3 * D;
+        GA_TRY(ga_gemm_bf16(&gqkv, stream));
+        GaAttentionArgs sa{B, m->heads, L, L, w.qkv, w.qkv + D, w.qkv + 2 * D, 3 * D, 3 * D, 3 * D, bw.q_norm_w,
+                           bw.k_norm_w, w.att, D};
+        GA_TRY(ga_attention_bf16(&sa, stream));
+        GaGemmArgs gp{};
+        gp.M = Mrows; gp.N = D; gp.K = D; gp.epilogue = GA_GEMM_EPI_RESIDUAL; gp.A = w.att; gp.lda = D; gp.W = bw.proj_w;
+        gp.bias = bw.proj_b; gp.out = w.xres; gp.ldo = D; gp.gate = mod + 2 * D; gp.gate_stride = 6 * (int64_t)D;
+        gp.rows_per_batch = L;
+        GA_TRY(ga_gemm_bf16(&gp, stream));
+        // FusedMLP
+        GaRmsNormArgs n2{Mrows, D, L, w.xres, bw.norm2_w, mod + 4 * D, mod + 3 * D, 6 * (int64_t)D, w.xn};
+        GA_TRY(ga_rmsnorm_modulate(&n2, stream));
+        GaGemmArgs g1{};
+        g1.M = Mrows; g1.N = 4 * D; g1.K = D; g1.epilogue = GA_GEMM_EPI_GELU_BF16; g1.A = w.xn; g1.lda = D; g1.W = bw.fc1_w;
+        g1.bias = bw.fc1_b; g1.out = w.hmid; g1.ldo = 4 * D;
+        GA_TRY(ga_gemm_bf16(&g1, stream));
+        GaGemmArgs g2{};
+        g2.M = Mrows; g2.N = D; g2.K = 4 * D; g2.epilogue = GA_GEMM_EPI_RESIDUAL; g2.A = w.hmid; g2.lda = 4 * D;
+        g2.W = bw.fc2_w; g2.bias = bw.fc2_b; g2.out = w.xres; g2.ldo = D; g2.gate = mod + 5 * D;
+        g2.gate_stride = 6 * (int64_t)D; g2.rows_per_batch = L;
+        GA_TRY(ga_gemm_bf16(&g2, stream));
+    }
+    {
+        FinalArgs f{Mrows, D, m->out_channels, L, w.xres, m->final_table, w.tvec, m->final_w, m->final_b, a->out};
+        hipLaunchKernelGGL(final_layer_kernel, dim3((Mrows + 3) / 4), dim3(256), 0, s, f);
+    }
+    return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
+}

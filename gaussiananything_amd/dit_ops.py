@@ -1,0 +1,151 @@
+"""ctypes binding of include/ga_dit.h (same library as the surfel rasterizer) plus thin torch-tensor wrappers of the
+per-op entry points.  No fallback: every function needs the HIP library and CUDA(ROCm) tensors."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+c_p = ctypes.c_void_p
+i32, i64, f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+
+EPI_STORE_BF16, EPI_GELU_BF16, EPI_RESIDUAL, EPI_STORE_F32 = 0, 1, 2, 3
+
+
+class GaGemmArgs(ctypes.Structure):
+    _fields_ = [("M", i32), ("N", i32), ("K", i32), ("epilogue", i32), ("A", c_p), ("lda", i64), ("W", c_p),
+                ("bias", c_p), ("out", c_p), ("ldo", i64), ("gate", c_p), ("gate_stride", i64), ("rows_per_batch", i32)]
+
+
+class GaAttentionArgs(ctypes.Structure):
+    _fields_ = [("batch", i32), ("heads", i32), ("Lq", i32), ("Lk", i32), ("q", c_p), ("k", c_p), ("v", c_p),
+                ("q_stride", i64), ("k_stride", i64), ("v_stride", i64), ("q_norm_weight", c_p), ("k_norm_weight", c_p),
+                ("out", c_p), ("out_stride", i64)]
+
+
+class GaRmsNormArgs(ctypes.Structure):
+    _fields_ = [("M", i32), ("D", i32), ("rows_per_batch", i32), ("x", c_p), ("weight", c_p), ("scale", c_p),
+                ("shift", c_p), ("mod_stride", i64), ("out", c_p)]
+
+
+class GaSmallLinearArgs(ctypes.Structure):
+    _fields_ = [("B", i32), ("N", i32), ("K", i32), ("act_in", i32), ("act_out", i32), ("x", c_p), ("W", c_p),
+                ("bias", c_p), ("add", c_p), ("y", c_p)]
+
+
+class GaDitBlockWeights(ctypes.Structure):
+    _fields_ = [(n, c_p) for n in (
+        "prenorm_ca_w", "ca_q_w", "ca_kv_w", "ca_q_norm_w", "ca_k_norm_w", "ca_out_w", "ca_out_b", "norm1_w", "qkv_w",
+        "qkv_b", "q_norm_w", "k_norm_w", "proj_w", "proj_b", "norm2_w", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+        "scale_shift_table")]
+
+
+class GaDitModel(ctypes.Structure):
+    _fields_ = [("hidden", i32), ("depth", i32), ("heads", i32), ("in_channels", i32), ("out_channels", i32),
+                ("context_dim", i32), ("stage2", i32)] + [(n, c_p) for n in (
+                    "t_mlp0_w", "t_mlp0_b", "t_mlp2_w", "t_mlp2_b", "pool_ln_w", "pool_ln_b", "pool_w", "pool_b",
+                    "adaln_w", "adaln_b", "xe_fc1_w", "xe_fc1_b", "xe_fc2_w", "xe_fc2_b", "xyz_w", "xyz_b",
+                    "final_table", "final_w", "final_b")] + [("blocks", ctypes.POINTER(GaDitBlockWeights))]
+
+
+class GaDitForwardArgs(ctypes.Structure):
+    _fields_ = [("batch", i32), ("tokens", i32), ("ctx_tokens", i32), ("x", c_p), ("timesteps", c_p),
+                ("img_vector", c_p), ("fps_xyz", c_p), ("ca_kv", c_p), ("out", c_p), ("workspace", c_p),
+                ("workspace_bytes", ctypes.c_size_t)]
+
+
+DIT_EXPORTS = ("ga_gemm_bf16", "ga_attention_bf16", "ga_rmsnorm_modulate", "ga_small_linear", "ga_dit_workspace_bytes",
+               "ga_dit_cache_context", "ga_dit_forward", "ga_dit_version")
+_ERR = {-1: "GA_DIT_ERR_NULL_ARG", -2: "GA_DIT_ERR_BAD_SHAPE", -4: "GA_DIT_ERR_LAUNCH"}
+_bound = False
+
+
+def lib():
+    global _bound
+    L = _lib.lib()
+    if not _bound:
+        for name in DIT_EXPORTS:
+            if not hasattr(L, name):
+                raise RuntimeError(f"{_lib.LIB_PATH} does not export {name}")
+        L.ga_dit_version.restype = ctypes.c_char_p
+        L.ga_dit_workspace_bytes.restype = ctypes.c_size_t
+        L.ga_dit_workspace_bytes.argtypes = [ctypes.POINTER(GaDitModel), i32, i32, i32]
+        for name in ("ga_gemm_bf16", "ga_attention_bf16", "ga_rmsnorm_modulate", "ga_small_linear"):
+            getattr(L, name).restype = ctypes.c_int
+        L.ga_dit_cache_context.restype = ctypes.c_int
+        L.ga_dit_cache_context.argtypes = [ctypes.POINTER(GaDitModel), i32, i32, c_p, c_p, c_p]
+        L.ga_dit_forward.restype = ctypes.c_int
+        L.ga_dit_forward.argtypes = [ctypes.POINTER(GaDitModel), ctypes.POINTER(GaDitForwardArgs), c_p]
+        _bound = True
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def _stream(t):
+    return c_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and t.device.type != "cuda":
+            raise RuntimeError("gaussiananything_amd DiT ops only run on an MI355X (HIP) device; there is no CPU path")
+
+
+def gemm(A, W, bias=None, epilogue=EPI_STORE_BF16, out=None, gate=None, rows_per_batch=1):
+    """A [M,K] bf16, W [N,K] bf16 -> see ga_dit.h.  EPI_RESIDUAL accumulates into ``out`` (fp32 [M,N])."""
+    _need_cuda(A, W, bias, out, gate)
+    assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and A.stride(-1) == 1 and W.is_contiguous()
+    M, K = A.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=A.device,
+                          dtype=torch.bfloat16 if epilogue in (EPI_STORE_BF16, EPI_GELU_BF16) else torch.float32)
+    a = GaGemmArgs(M, N, K, epilogue, A.data_ptr(), A.stride(0), W.data_ptr(), _ptr(bias), out.data_ptr(), out.stride(0),
+                   _ptr(gate), gate.stride(0) if gate is not None else 0, rows_per_batch)
+    check(lib().ga_gemm_bf16(ctypes.byref(a), _stream(A)), "ga_gemm_bf16")
+    return out
+
+
+def attention(q, k, v, q_norm_weight=None, k_norm_weight=None):
+    """q [B,Lq,H,64], k/v [B,Lk,H,64] bf16 views (token stride arbitrary, head stride 64) -> [B,Lq,H*64] bf16."""
+    _need_cuda(q, k, v)
+    B, Lq, H, d = q.shape
+    Lk = k.shape[1]
+    assert d == 64 and q.stride(3) == 1 and q.stride(2) == 64 and k.stride(2) == 64 and v.stride(2) == 64
+    assert q.stride(0) == Lq * q.stride(1) and k.stride(0) == Lk * k.stride(1) and v.stride(0) == Lk * v.stride(1)
+    out = torch.empty((B, Lq, H * 64), device=q.device, dtype=torch.bfloat16)
+    a = GaAttentionArgs(B, H, Lq, Lk, q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(1), k.stride(1), v.stride(1),
+                        _ptr(q_norm_weight), _ptr(k_norm_weight), out.data_ptr(), H * 64)
+    check(lib().ga_attention_bf16(ctypes.byref(a), _stream(q)), "ga_attention_bf16")
+    return out
+
+
+def rmsnorm_modulate(x, weight, scale=None, shift=None, rows_per_batch=1):
+    """x [M,D] fp32 -> bf16 [M,D]; scale/shift [B,D] (any row stride)."""
+    _need_cuda(x, weight, scale, shift)
+    M, D = x.shape
+    out = torch.empty((M, D), device=x.device, dtype=torch.bfloat16)
+    a = GaRmsNormArgs(M, D, rows_per_batch, x.data_ptr(), weight.data_ptr(), _ptr(scale), _ptr(shift),
+                      scale.stride(0) if scale is not None else 0, out.data_ptr())
+    check(lib().ga_rmsnorm_modulate(ctypes.byref(a), _stream(x)), "ga_rmsnorm_modulate")
+    return out
+
+
+def small_linear(x, W, bias=None, add=None, act_in=0, act_out=0):
+    _need_cuda(x, W, bias, add)
+    B, K = x.shape
+    N = W.shape[0]
+    y = torch.empty((B, N), device=x.device, dtype=torch.float32)
+    a = GaSmallLinearArgs(B, N, K, act_in, act_out, x.data_ptr(), W.data_ptr(), _ptr(bias), _ptr(add), y.data_ptr())
+    check(lib().ga_small_linear(ctypes.byref(a), _stream(x)), "ga_small_linear")
+    return y

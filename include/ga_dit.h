@@ -1,0 +1,169 @@
+/*
+ * ga_dit.h -- C-ABI of the MI355X-native DiT/SiT denoiser forward (bf16 MFMA, fp32 residual stream).
+ *
+ * Drop-in boundary for the denoise half of GaussianAnything's render-and-denoise hot path: one call of
+ * ga_dit_forward() computes what the reference computes in
+ *     DiT_I23D_PCD_PixelArt_noclip.forward              /root/reference/dit/dit_i23d.py:511-567   (stage 1)
+ *     DiT_I23D_PCD_PixelArt_noclip_clay_stage2.forward  /root/reference/dit/dit_i23d.py:707-750   (stage 2)
+ * i.e. everything torchdiffeq calls per function evaluation through
+ *     transport/integrators.py:104-107 -> Transport.velocity_ode (transport/transport.py:209-218) -> model(x, t, **kw).
+ * The block arithmetic replaces the third-party kernels the reference reaches through
+ *     xformers.ops.memory_efficient_attention   vit/vision_transformer.py:297, ldm/modules/attention.py:538-548
+ *     xformers FusedMLP                         dit/dit_models_xformers.py:281-286
+ *     RMSNorm (apex or dit/norm.py:29-43), t2i_modulate (dit_models_xformers.py:53-54)
+ * The per-op entry points (ga_gemm_bf16, ga_attention_bf16, ...) are exported as well: the parity tests call them
+ * one by one, and a maintainer can bind them individually.
+ *
+ * Conventions: every pointer is a DEVICE pointer unless it says "host"; bf16 tensors are raw uint16 (upper half of the
+ * fp32 bit pattern, round-to-nearest-even); row-major; all work is enqueued on `stream` (hipStream_t as void*), no
+ * host sync, no allocation; return 0 or a negative GA_DIT_ERR_* code.
+ */
+#ifndef GA_DIT_H
+#define GA_DIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GA_DIT_OK 0
+#define GA_DIT_ERR_NULL_ARG (-1)
+#define GA_DIT_ERR_BAD_SHAPE (-2) /* K % 64 != 0, N % 4 != 0, head_dim != 64, ... (see each entry point) */
+#define GA_DIT_ERR_LAUNCH (-4)
+
+typedef uint16_t ga_bf16;
+
+/* epilogues of ga_gemm_bf16:  acc[m][n] = sum_k A[m][k] * W[n][k]  (fp32 accumulate) */
+#define GA_GEMM_EPI_STORE_BF16 0 /* out_bf16[m][n] = acc + bias[n]                                      */
+#define GA_GEMM_EPI_GELU_BF16 1  /* out_bf16[m][n] = gelu_erf(acc + bias[n])            (FusedMLP fc1) */
+#define GA_GEMM_EPI_RESIDUAL 2   /* x_f32[m][n]   += gate[m / rows_per_batch][n] * (acc + bias[n])      */
+#define GA_GEMM_EPI_STORE_F32 3  /* x_f32[m][n]    = acc + bias[n]                                      */
+
+typedef struct GaGemmArgs {
+    int32_t M, N, K;          /* K % 64 == 0, N % 4 == 0                                             */
+    int32_t epilogue;         /* GA_GEMM_EPI_*                                                       */
+    const ga_bf16 *A;         /* [M, lda] activations                                                */
+    int64_t lda;              /* elements; >= K, multiple of 8                                       */
+    const ga_bf16 *W;         /* [N, K] weight as torch.nn.Linear stores it (out_features, in_features) */
+    const float *bias;        /* [N] or NULL                                                         */
+    void *out;                /* ga_bf16[M, ldo] (EPI 0/1) or float[M, ldo] (EPI 2/3)                */
+    int64_t ldo;              /* elements, multiple of 4                                             */
+    const float *gate;        /* EPI 2: [M / rows_per_batch, gate_stride] or NULL (= 1)              */
+    int64_t gate_stride;      /* elements between the gate rows of consecutive batch items           */
+    int32_t rows_per_batch;   /* EPI 2: tokens per batch item                                        */
+} GaGemmArgs;
+
+int ga_gemm_bf16(const GaGemmArgs *args, void *stream);
+
+/* softmax(q k^T / sqrt(64)) v with per-head RMSNorm of q and k fused on load (weights qn/kn, eps 1e-5; NULL = none):
+ * what MemEffAttention / MemoryEfficientCrossAttention compute between their projections.  head_dim must be 64.
+ * q row of (batch b, token i, head h) starts at q + (b*Lq + i)*q_stride + h*64 (same for k, v, out). */
+typedef struct GaAttentionArgs {
+    int32_t batch, heads, Lq, Lk;
+    const ga_bf16 *q, *k, *v;
+    int64_t q_stride, k_stride, v_stride; /* elements between consecutive tokens                     */
+    const float *q_norm_weight, *k_norm_weight; /* [64] each                                        */
+    ga_bf16 *out;
+    int64_t out_stride;
+} GaAttentionArgs;
+
+int ga_attention_bf16(const GaAttentionArgs *args, void *stream);
+
+/* out_bf16[m][:] = rmsnorm(x[m][:]; eps 1e-5) * weight * (1 + scale[b][:]) + shift[b][:],  b = m / rows_per_batch
+ * (scale / shift NULL = plain RMSNorm).  dit/norm.py:29-43 + t2i_modulate.  D % 4 == 0, D <= 2048. */
+typedef struct GaRmsNormArgs {
+    int32_t M, D, rows_per_batch;
+    const float *x;
+    const float *weight;
+    const float *scale, *shift; /* [M / rows_per_batch, mod_stride]                                  */
+    int64_t mod_stride;
+    ga_bf16 *out;
+} GaRmsNormArgs;
+
+int ga_rmsnorm_modulate(const GaRmsNormArgs *args, void *stream);
+
+/* Small dense layer for the conditioning path (a handful of rows):
+ *   y[b][n] = act_out( sum_k act_in(x[b][k]) * W[n][k] + bias[n] ) (+ add[b][n]);  act: 0 none, 1 SiLU.  B <= 16. */
+typedef struct GaSmallLinearArgs {
+    int32_t B, N, K, act_in, act_out;
+    const float *x;      /* [B, K]            */
+    const ga_bf16 *W;    /* [N, K]            */
+    const float *bias;   /* [N] or NULL       */
+    const float *add;    /* [B, N] or NULL    */
+    float *y;            /* [B, N]            */
+} GaSmallLinearArgs;
+
+int ga_small_linear(const GaSmallLinearArgs *args, void *stream);
+
+/* ---- whole forward --------------------------------------------------------------------------------------------- */
+
+typedef struct GaDitBlockWeights {
+    /* cross-attention on the image tokens (cross_attn_dino, prenorm_ca_dino) */
+    const float *prenorm_ca_w;           /* [D]                                         */
+    const ga_bf16 *ca_q_w;               /* [D, D]      to_q (no bias)                  */
+    const ga_bf16 *ca_kv_w;              /* [2D, ctx]   to_k rows then to_v rows        */
+    const float *ca_q_norm_w, *ca_k_norm_w; /* [64]                                     */
+    const ga_bf16 *ca_out_w;             /* [D, D]      to_out.0                        */
+    const float *ca_out_b;               /* [D]                                         */
+    /* self-attention (attn, norm1) */
+    const float *norm1_w;                /* [D]                                         */
+    const ga_bf16 *qkv_w;                /* [3D, D]                                     */
+    const float *qkv_b;                  /* [3D]                                        */
+    const float *q_norm_w, *k_norm_w;    /* [64]                                        */
+    const ga_bf16 *proj_w;               /* [D, D]                                      */
+    const float *proj_b;                 /* [D]                                         */
+    /* FusedMLP (mlp, norm2) */
+    const float *norm2_w;                /* [D]                                         */
+    const ga_bf16 *fc1_w;                /* [4D, D]                                     */
+    const float *fc1_b;                  /* [4D]                                        */
+    const ga_bf16 *fc2_w;                /* [D, 4D]                                     */
+    const float *fc2_b;                  /* [D]                                         */
+    const float *scale_shift_table;      /* [6, D]                                      */
+} GaDitBlockWeights;
+
+typedef struct GaDitModel {
+    int32_t hidden, depth, heads, in_channels, out_channels, context_dim, stage2;
+    const ga_bf16 *t_mlp0_w; const float *t_mlp0_b;     /* [D,256], [D]   t_embedder.mlp.0            */
+    const ga_bf16 *t_mlp2_w; const float *t_mlp2_b;     /* [D,D], [D]     t_embedder.mlp.2            */
+    const float *pool_ln_w, *pool_ln_b;                 /* [ctx]          pooled_vec_embedder.0       */
+    const ga_bf16 *pool_w; const float *pool_b;         /* [D,ctx], [D]   pooled_vec_embedder.1       */
+    const ga_bf16 *adaln_w; const float *adaln_b;       /* [6D,D], [6D]   adaLN_modulation.1          */
+    const float *xe_fc1_w, *xe_fc1_b;                   /* [D,C], [D]     x_embedder.fc1 (fp32, K tiny) */
+    const ga_bf16 *xe_fc2_w; const float *xe_fc2_b;     /* [D,D], [D]     x_embedder.fc2              */
+    const float *xyz_w, *xyz_b;                         /* [D,63], [D]    xyz_pos_embed.xyz_projection (stage 2) */
+    const float *final_table;                           /* [2,D]          final_layer.scale_shift_table */
+    const float *final_w, *final_b;                     /* [Cout,D], [Cout] final_layer.linear (fp32) */
+    const GaDitBlockWeights *blocks;                    /* host array [depth]                          */
+} GaDitModel;
+
+typedef struct GaDitForwardArgs {
+    int32_t batch;            /* B' (CFG batch: 2 x samples), <= 16                                    */
+    int32_t tokens;           /* L latent tokens per batch item                                        */
+    int32_t ctx_tokens;       /* M image tokens per batch item                                         */
+    const float *x;           /* [B', L, C]                                                            */
+    const float *timesteps;   /* [B']                                                                  */
+    const float *img_vector;  /* [B', ctx]                                                             */
+    const float *fps_xyz;     /* [B', L, 3] (stage 2) or NULL                                          */
+    const ga_bf16 *ca_kv;     /* [depth][B'*M, 2D] cached K|V projections of the image tokens: ga_dit_cache_context */
+    float *out;               /* [B', L, Cout] fp32 (the reference returns x.float())                  */
+    void *workspace;          /* ga_dit_workspace_bytes()                                              */
+    size_t workspace_bytes;
+} GaDitForwardArgs;
+
+size_t ga_dit_workspace_bytes(const GaDitModel *model, int32_t batch, int32_t tokens, int32_t ctx_tokens);
+
+/* K/V of every block's cross-attention depend only on the (step-invariant) image tokens: project them once per
+ * sample.  img_crossattn: bf16 [B'*M, ctx]; ca_kv out: [depth][B'*M, 2D]. */
+int ga_dit_cache_context(const GaDitModel *model, int32_t batch, int32_t ctx_tokens, const ga_bf16 *img_crossattn,
+                         ga_bf16 *ca_kv, void *stream);
+
+int ga_dit_forward(const GaDitModel *model, const GaDitForwardArgs *args, void *stream);
+
+const char *ga_dit_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GA_DIT_H */

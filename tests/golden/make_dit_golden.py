@@ -4,7 +4,7 @@ through tests/golden/ref_dit_loader.py).  Run once in the build container:  pyth
 
 Each file holds: the constructor arguments, the reference state_dict (seeded init, zero-initialised tensors re-drawn),
 seeded inputs, and the fp32 outputs of ``model.forward`` and ``model.forward_with_cfg`` computed by the reference code
-on CPU.  Small shapes (hidden 128, 2 heads of 64, depth 3, 48 tokens, 40 context tokens of width 96) keep the
+on CPU.  Small shapes (hidden 128, 2 heads of 64, depth 3, 48 tokens, 40 context tokens of width 64) keep the
 fixtures at a few MB; the arithmetic path is the one the release models take
 (DiT_I23D_PCD_PixelArt_noclip[+_clay_stage2] with ImageCondDiTBlockPixelArtRMSNormClayLRM blocks).
 """
@@ -24,7 +24,7 @@ def make(stage):
     m = L.install()
     torch.manual_seed(100 + stage)
     kw = dict(input_size=8, patch_size=1, in_channels=3 if stage == 1 else 10, hidden_size=128, depth=3, num_heads=2,
-              num_classes=0, learn_sigma=False, context_dim=96, pooling_ctx_dim=64, roll_out=True,
+              num_classes=0, learn_sigma=False, context_dim=64, pooling_ctx_dim=64, roll_out=True,
               vit_blk=m.ImageCondDiTBlockPixelArtRMSNormClayLRM, use_clay_ca=True)
     with contextlib.redirect_stdout(io.StringIO()):
         if stage == 1:
@@ -37,7 +37,7 @@ def make(stage):
     B, Ltok, M = 4, 48, 40
     x = torch.randn(B, Ltok, kw["in_channels"], generator=g)
     t = torch.tensor([0.37, 0.37, 0.37, 0.37])
-    ctx = {"img_crossattn": torch.randn(B, M, 96, generator=g), "img_vector": torch.randn(B, 96, generator=g)}
+    ctx = {"img_crossattn": torch.randn(B, M, 64, generator=g), "img_vector": torch.randn(B, 64, generator=g)}
     ctx["img_crossattn"][B // 2:] = 0   # the unconditional half of a CFG batch is all zeros (sgm conditioner)
     ctx["img_vector"][B // 2:] = 0
     if stage == 2:
