@@ -75,6 +75,68 @@ def cpu_baseline(g, cams, H, W, min_seconds=3.0):
                       f"single-threaded, blend OpenMP over tiles ({cores} threads); includes numpy buffer setup"}
 
 
+def dit_flops_per_nfe(D, depth, L, M, ctx, batch):
+    """Algorithmic FLOPs of one function evaluation with the image-token K/V cached:
+    per block and sequence  SA: 2L*D*3D + 4L^2*D + 2L*D^2 ; CA: 2L*D^2 (q) + 4L*M*D + 2L*D^2 (out) ; MLP: 16L*D^2."""
+    sa = 2 * L * D * 3 * D + 4 * L * L * D + 2 * L * D * D
+    ca = 2 * L * D * D + 4 * L * M * D + 2 * L * D * D
+    mlp = 16 * L * D * D
+    attn_only = 4 * L * L * D + 4 * L * M * D
+    return batch * depth * (sa + ca + mlp), batch * depth * attn_only
+
+
+def bench_dit(dev, arch, nfe, warmup):
+    """ms per function evaluation of forward_with_cfg at the release shapes: CFG batch 2, 768 latent tokens,
+    1369 x 1024 image tokens, seeded random weights (zero-initialised tensors re-drawn)."""
+    from gaussiananything_amd.dit import DiT_models
+    from gaussiananything_amd.transport import Sampler, create_transport
+    torch.manual_seed(0)
+    stage2 = "stage2" in arch
+    C = 10 if stage2 else 3
+    model = DiT_models[arch](input_size=16, in_channels=C, context_dim=1024, pooling_ctx_dim=768, num_classes=0,
+                             learn_sigma=False, roll_out=True)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for p_ in model.parameters():
+            if float(p_.abs().max()) == 0.0:
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.02)
+    model.to(dev)
+    B, L, M = 2, 768, 1369
+    x = torch.randn(B, L, C, generator=g).to(dev)
+    ctx = {"img_crossattn": torch.randn(B, M, 1024, generator=g), "img_vector": torch.randn(B, 1024, generator=g)}
+    ctx["img_crossattn"][1] = 0
+    ctx["img_vector"][1] = 0
+    if stage2:
+        ctx["fps-xyz"] = (torch.rand(B, L, 3, generator=g) - 0.5) * 0.9
+    ctx = {k: v.to(dev) for k, v in ctx.items()}
+    t = torch.full((B,), 0.5, device=dev)
+    with torch.no_grad():
+        for _ in range(warmup):
+            model.forward_with_cfg(x, t, ctx, 4.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nfe):
+            model.forward_with_cfg(x, t, ctx, 4.0)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / nfe * 1e3
+        if os.environ.get("GA_SKIP_SAMPLER"):
+            return {"ms_per_nfe": ms}
+        # the "250-step" sampler in its deterministic form: euler, 250 grid points = 249 function evaluations
+        sampler = Sampler(create_transport("GVP", "velocity", None, None, None, snr_type="uniform"))
+        fn = sampler.sample_ode(sampling_method="euler", num_steps=250)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(x, model.forward_with_cfg, context=ctx, cfg_scale=4.0)
+        torch.cuda.synchronize()
+        sec250 = time.perf_counter() - t0
+    fl, fl_attn = dit_flops_per_nfe(model.embed_dim, model.depth, L, M, 1024, B)
+    tf = fl / (ms * 1e-3) / 1e12
+    return {"arch": arch, "cfg_batch": B, "tokens": L, "ctx_tokens": M, "ms_per_nfe": round(ms, 4),
+            "algorithmic_tflop_per_nfe": round(fl / 1e12, 4), "achieved_tflops": round(tf, 2),
+            "bf16_mfma_peak_tflops": 2500.0, "frac_of_mfma_peak": round(tf / 2500.0, 4),
+            "sec_per_250_step_euler_stage": round(sec250, 4), "nfe_timed": nfe}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,6 +148,8 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true")
+    ap.add_argument("--no-dit", action="store_true", help="skip the DiT/SiT denoiser section of the report")
+    ap.add_argument("--dit-nfe", type=int, default=20)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -190,6 +254,13 @@ def main():
             out["stage_ms"]["device_total"] = round(total_dev, 5)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g, cams, H, W)
+        if world == 1 and not a.no_dit:
+            # second half of the headline metric ("sec/sample 250-step cascaded"): the two release-size denoisers
+            out["dit"] = [bench_dit(dev, arch, a.dit_nfe, 3) for arch in
+                          ("DiT-PixArt-PCD-CLAY-B", "DiT-PixArt-PCD-CLAY-L", "DiT-PixArt-PCD-CLAY-stage2-L")]
+            out["sec_per_sample_250step_cascaded_L"] = round(
+                out["dit"][1]["sec_per_250_step_euler_stage"] + out["dit"][2]["sec_per_250_step_euler_stage"]
+                + dt / a.steps, 4)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

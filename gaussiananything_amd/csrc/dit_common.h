@@ -12,17 +12,16 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;    // one MFMA 16x16 ac
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
 
-__device__ __forceinline__ uint16_t f32_to_bf16(float f)  // round to nearest even (NaN kept quiet)
-{
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
+// fp32 -> bf16, round to nearest even: native __bf16 conversions, which hipcc lowers to v_cvt_pk_bf16_f32 on gfx950
+// (a hand-rolled bit trick with a NaN test costs ~6 VALU ops AND a divergent branch per element).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
 {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 
 __device__ __forceinline__ float wave_sum(float v)

@@ -10,82 +10,124 @@
 // its A and B operands (lane l: row l&15, k-chunk (l>>4)*8..+7), so the same ds_read_b128 fragment load serves both.
 // The MFMA "A" role is given to the WEIGHT rows and the "B" role to the activation rows: the accumulator fragment of a
 // lane is then 4 consecutive n for one m, i.e. 8-byte (bf16) / 16-byte (fp32) contiguous stores in the row-major
-// output.  Workgroup tile 128(n) x 128(m) x 64(k), 4 waves as 2x2, each wave 4x4 fragments (64 accumulator VGPRs);
-// global -> VGPR -> LDS staging one K-tile ahead (16-byte loads), LDS rows padded to 144 B so the 16 rows a fragment
-// read touches fall into 16 different bank groups.
+// output.  Workgroup tile 128(n) x 128(m) x 64(k), 4 waves as 2x2, each wave 4x4 fragments (64 accumulator VGPRs).
+// Staging is LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction straight into LDS, no VGPR round trip) through
+// a 4-deep ring (128 KiB of the CU's 160 KiB): K-tiles t+1..t+3 are in flight while tile t is multiplied, with COUNTED
+// waits (s_waitcnt vmcnt(24/16/8/0): 8 DMA instructions per wave per tile) and a raw s_barrier -- one barrier per
+// K-tile.  At M = 1536 the grid is only 96-384 workgroups, so every workgroup must run at MFMA speed on its own: with a
+// 2-deep ring each K-tile cost a full DMA latency (measured 1.1 us vs 0.22 us of MFMA work).  The DMA writes LDS in
+// lane order, so the bank-conflict-free image is obtained by permuting the SOURCE: slot (row, s) of the 128-byte row
+// holds global 16-byte chunk s ^ (row & 7), and fragment reads apply the same XOR (conflict-free for the hardware's
+// ds_read_b128 lane groups).
 #include "dit_common.h"
 
 namespace gadit {
 
-constexpr int BM = 128, BN = 128, BK = 64, LDS_LD = BK + 8;  // leading dimension in bf16 elements (144 bytes)
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_ELEMS = 128 * BK;  // one operand tile: 128 rows x 64 bf16 = 16 KiB
+constexpr int NSTAGE = 4;
+constexpr int GEMM_LDS_BYTES = NSTAGE * 2 * TILE_ELEMS * 2;  // 128 KiB
+
+struct GemmP {  // by-value kernel parameters (kept flat: no pointer into the argument struct is taken)
+    int M, N, K, rows_per_batch;
+    const uint16_t *A, *W;
+    const float *bias, *gate;
+    void *out;
+    long long lda, ldo, gate_stride;
+    uint16_t *vt;      // optional transposed store of the columns >= vt_col0 (see include/ga_dit.h)
+    int vt_col0, heads;
+    long long vt_ld;
+};
+
+__device__ __forceinline__ void glds16(const uint16_t *gsrc, uint16_t *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
 
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GaGemmArgs a)
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t sW[BN * LDS_LD];
-    __shared__ __attribute__((aligned(16))) uint16_t sA[BM * LDS_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];  // [NSTAGE][W | A][row][slot] = 4 x 32 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wm = wave & 1;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
-    const int M = a.M, N = a.N, K = a.K;
+    const int M = p.M, N = p.N, K = p.K;
 
-    // staging assignment: 1024 16-byte chunks per operand tile, 4 per thread
-    int srow[4], scol[4];
-    const uint16_t *gW[4], *gA[4];
+    // DMA assignment: instruction i of wave w fills rows (w*4+i)*8 .. +7; lane -> row + (lane>>3), slot lane&7,
+    // which receives global chunk (lane&7) ^ (row&7)
+    const uint16_t *srcW[4], *srcA[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int c = tid + 256 * i;
-        srow[i] = c >> 3;
-        scol[i] = (c & 7) * 8;
-        const int rn = min(n0 + srow[i], N - 1), rm = min(m0 + srow[i], M - 1);
-        gW[i] = a.W + (size_t)rn * K + scol[i];
-        gA[i] = a.A + (size_t)rm * a.lda + scol[i];
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (row & 7);
+        srcW[i] = p.W + (size_t)min(n0 + row, N - 1) * K + chunk * 8;
+        srcA[i] = p.A + (size_t)min(m0 + row, M - 1) * p.lda + chunk * 8;
     }
-    uint4 rW[4], rA[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        rW[i] = *reinterpret_cast<const uint4 *>(gW[i]);
-        rA[i] = *reinterpret_cast<const uint4 *>(gA[i]);
-    }
-
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int frow = lane & 15, fk = (lane >> 4) * 8;
+    const int frow = lane & 15, g = lane >> 4;
     const int nk = K / BK;
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();  // previous tile's fragment reads are done
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4 *>(&sW[srow[i] * LDS_LD + scol[i]]) = rW[i];
-            *reinterpret_cast<uint4 *>(&sA[srow[i] * LDS_LD + scol[i]]) = rA[i];
-        }
-        __syncthreads();
-        if (kt + 1 < nk) {  // next K-tile in flight while this one is multiplied
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                rW[i] = *reinterpret_cast<const uint4 *>(gW[i] + (size_t)(kt + 1) * BK);
-                rA[i] = *reinterpret_cast<const uint4 *>(gA[i] + (size_t)(kt + 1) * BK);
-            }
-        }
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 32) {
-            bf16x8 fw[4], fa[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fw[i] = *reinterpret_cast<const bf16x8 *>(&sW[(wn * 64 + i * 16 + frow) * LDS_LD + kk + fk]);
-                fa[i] = *reinterpret_cast<const bf16x8 *>(&sA[(wm * 64 + i * 16 + frow) * LDS_LD + kk + fk]);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
-        }
+
+    // Buffer indices are compile-time constants in every use below (the K loop is unrolled by two): with a run-time
+    // buffer index hipcc cannot separate the DMA destination from the fragment reads and drains the DMA (vmcnt(0))
+    // in front of every ds_read, which serialises load and math.
+#define GA_STAGE(BUF, KT)                                                                             \
+    do {                                                                                              \
+        uint16_t *bw_ = smem + (BUF) * 2 * TILE_ELEMS, *ba_ = bw_ + TILE_ELEMS;                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+            glds16(srcW[i] + (size_t)(KT) * BK, bw_ + (wave * 4 + i) * 8 * BK);                       \
+            glds16(srcA[i] + (size_t)(KT) * BK, ba_ + (wave * 4 + i) * 8 * BK);                       \
+        }                                                                                             \
+    } while (0)
+#define GA_COMPUTE(BUF)                                                                               \
+    do {                                                                                              \
+        const uint16_t *bw_ = smem + (BUF) * 2 * TILE_ELEMS, *ba_ = bw_ + TILE_ELEMS;                  \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                            \
+            bf16x8 fw[4], fa[4];                                                                      \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+                const int rw = wn * 64 + i * 16 + frow, ra = wm * 64 + i * 16 + frow;                 \
+                fw[i] = *reinterpret_cast<const bf16x8 *>(bw_ + rw * BK + (((kk * 4 + g) ^ (rw & 7)) * 8)); \
+                fa[i] = *reinterpret_cast<const bf16x8 *>(ba_ + ra * BK + (((kk * 4 + g) ^ (ra & 7)) * 8)); \
+            }                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                         \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0); \
+        }                                                                                             \
+    } while (0)
+
+    // wait until my DMA of the tile that is `ahead` tiles behind the newest issued one has landed
+#define GA_WAIT_TILES_IN_FLIGHT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((N) * 8) : "memory")
+#define GA_PHASE(BUF, KT)                                                                              \
+    do {                                                                                               \
+        const int rem_ = nk - 1 - (KT); /* tiles issued after KT so far: min(rem_, NSTAGE-2) */          \
+        if (rem_ >= 2) GA_WAIT_TILES_IN_FLIGHT(2);                                                      \
+        else if (rem_ == 1) GA_WAIT_TILES_IN_FLIGHT(1);                                                 \
+        else GA_WAIT_TILES_IN_FLIGHT(0);                                                                \
+        __builtin_amdgcn_s_barrier(); /* everyone's part of tile KT landed; everyone left tile KT-1 */  \
+        if ((KT) + 3 < nk) GA_STAGE(((BUF) + 3) & 3, (KT) + 3);                                         \
+        GA_COMPUTE(BUF);                                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* my fragment reads of this buffer are done */ \
+    } while (0)
+
+    GA_STAGE(0, 0);
+    if (nk > 1) GA_STAGE(1, 1);
+    if (nk > 2) GA_STAGE(2, 2);
+    for (int kt = 0; kt < nk; kt += 4) {
+        GA_PHASE(0, kt);
+        if (kt + 1 < nk) GA_PHASE(1, kt + 1);
+        if (kt + 2 < nk) GA_PHASE(2, kt + 2);
+        if (kt + 3 < nk) GA_PHASE(3, kt + 3);
     }
+#undef GA_PHASE
+#undef GA_WAIT_TILES_IN_FLIGHT
+#undef GA_STAGE
+#undef GA_COMPUTE
 
     // epilogue: lane holds acc[i][j][r] = C[m = m0 + wm*64 + j*16 + (lane&15)][n = n0 + wn*64 + i*16 + (lane>>4)*4 + r]
 #pragma unroll
@@ -93,30 +135,36 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GaGemmArgs a)
         const int m = m0 + wm * 64 + j * 16 + (lane & 15);
         if (m >= M) continue;
         const float *gate_row = nullptr;
-        if (EPI == GA_GEMM_EPI_RESIDUAL && a.gate) gate_row = a.gate + (size_t)(m / a.rows_per_batch) * a.gate_stride;
+        if (EPI == GA_GEMM_EPI_RESIDUAL && p.gate) gate_row = p.gate + (size_t)(m / p.rows_per_batch) * p.gate_stride;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
             if (n >= N) continue;
             f32x4 v = acc[i][j];
-            if (a.bias) {
-                const float4 b = *reinterpret_cast<const float4 *>(a.bias + n);
+            if (p.bias) {
+                const float4 b = *reinterpret_cast<const float4 *>(p.bias + n);
                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
             }
             if (EPI == GA_GEMM_EPI_GELU_BF16) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f));
             }
-            if (EPI == GA_GEMM_EPI_STORE_BF16 || EPI == GA_GEMM_EPI_GELU_BF16) {
-                uint2 p = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                *reinterpret_cast<uint2 *>(static_cast<uint16_t *>(a.out) + (size_t)m * a.ldo + n) = p;
+            if (EPI == GA_GEMM_EPI_STORE_BF16 && p.vt && n >= p.vt_col0) {
+                // V projection: write V^T[(b*heads + h)*64 + d][token]; 16 consecutive lanes hold 16 consecutive tokens
+                const int b = m / p.rows_per_batch, tok = m - b * p.rows_per_batch, dn = n - p.vt_col0;
+                uint16_t *dst = p.vt + ((size_t)b * p.heads * 64 + dn) * p.vt_ld + tok;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(size_t)r * p.vt_ld] = f32_to_bf16(v[r]);
+            } else if (EPI == GA_GEMM_EPI_STORE_BF16 || EPI == GA_GEMM_EPI_GELU_BF16) {
+                uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                *reinterpret_cast<uint2 *>(static_cast<uint16_t *>(p.out) + (size_t)m * p.ldo + n) = pk;
             } else {
-                float4 *dst = reinterpret_cast<float4 *>(static_cast<float *>(a.out) + (size_t)m * a.ldo + n);
+                float4 *dst = reinterpret_cast<float4 *>(static_cast<float *>(p.out) + (size_t)m * p.ldo + n);
                 if (EPI == GA_GEMM_EPI_RESIDUAL) {
-                    float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (gate_row) g = *reinterpret_cast<const float4 *>(gate_row + n);
+                    float4 gt = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (gate_row) gt = *reinterpret_cast<const float4 *>(gate_row + n);
                     const float4 x = *dst;
-                    *dst = make_float4(x.x + g.x * v[0], x.y + g.y * v[1], x.z + g.z * v[2], x.w + g.w * v[3]);
+                    *dst = make_float4(x.x + gt.x * v[0], x.y + gt.y * v[1], x.z + gt.z * v[2], x.w + gt.w * v[3]);
                 } else {
                     *dst = make_float4(v[0], v[1], v[2], v[3]);
                 }
@@ -137,11 +185,24 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
     if (a->epilogue == GA_GEMM_EPI_RESIDUAL && a->gate && a->rows_per_batch <= 0) return GA_DIT_ERR_BAD_SHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((a->N + BN - 1) / BN, (a->M + BM - 1) / BM);
+    if (a->vt && (a->epilogue != GA_GEMM_EPI_STORE_BF16 || a->vt_col0 % 64 != 0 || (a->N - a->vt_col0) % 64 != 0 ||
+                  a->rows_per_batch <= 0 || a->vt_ld < a->rows_per_batch))
+        return GA_DIT_ERR_BAD_SHAPE;
+    const GemmP p{a->M, a->N, a->K, a->rows_per_batch, a->A, a->W, a->bias, a->gate, a->out, a->lda, a->ldo, a->gate_stride,
+                  a->vt, a->vt_col0, a->vt ? (a->N - a->vt_col0) / 64 : 0, a->vt_ld};
+    static bool attr_set = false;
+    if (!attr_set) {  // > 64 KiB of dynamic LDS has to be opted into once per kernel
+        (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        attr_set = true;
+    }
     switch (a->epilogue) {
-    case GA_GEMM_EPI_STORE_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<0>, grid, dim3(256), 0, s, *a); break;
-    case GA_GEMM_EPI_GELU_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<1>, grid, dim3(256), 0, s, *a); break;
-    case GA_GEMM_EPI_RESIDUAL: hipLaunchKernelGGL(gemm_bf16_kernel<2>, grid, dim3(256), 0, s, *a); break;
-    case GA_GEMM_EPI_STORE_F32: hipLaunchKernelGGL(gemm_bf16_kernel<3>, grid, dim3(256), 0, s, *a); break;
+    case GA_GEMM_EPI_STORE_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<0>, grid, dim3(256), GEMM_LDS_BYTES, s, p); break;
+    case GA_GEMM_EPI_GELU_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<1>, grid, dim3(256), GEMM_LDS_BYTES, s, p); break;
+    case GA_GEMM_EPI_RESIDUAL: hipLaunchKernelGGL(gemm_bf16_kernel<2>, grid, dim3(256), GEMM_LDS_BYTES, s, p); break;
+    case GA_GEMM_EPI_STORE_F32: hipLaunchKernelGGL(gemm_bf16_kernel<3>, grid, dim3(256), GEMM_LDS_BYTES, s, p); break;
     default: return GA_DIT_ERR_BAD_SHAPE;
     }
     return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;

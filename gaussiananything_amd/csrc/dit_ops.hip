@@ -243,7 +243,8 @@ namespace gadit {
 
 struct Ws {
     float *xres, *tfreq, *t1, *pln, *pvec, *tvec, *t0, *mod;
-    uint16_t *xn, *qkv, *att, *hmid;
+    uint16_t *xn, *qkv, *att, *hmid, *vt;
+    size_t vt_bytes;
     size_t total;
 };
 
@@ -256,7 +257,9 @@ static Ws carve(const GaDitModel *m, int B, int L, void *base)
     auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
     unsigned char *p = static_cast<unsigned char *>(base);
     Ws w;
-    const size_t o_xres = take(M * D * 4), o_xn = take(M * D * 2), o_qkv = take(M * 3 * D * 2), o_att = take(M * D * 2);
+    const size_t Lp = ((size_t)L + 63) / 64 * 64;
+    const size_t o_xres = take(M * D * 4), o_xn = take(M * D * 2), o_qkv = take(M * 2 * D * 2), o_att = take(M * D * 2);
+    const size_t o_vt = take((size_t)B * D * Lp * 2);
     const size_t o_hmid = take(M * 4 * D * 2), o_tfreq = take((size_t)B * 256 * 4), o_t1 = take((size_t)B * D * 4);
     const size_t o_pln = take((size_t)B * m->context_dim * 4), o_pvec = take((size_t)B * D * 4);
     const size_t o_tvec = take((size_t)B * D * 4), o_t0 = take((size_t)B * 6 * D * 4);
@@ -264,6 +267,7 @@ static Ws carve(const GaDitModel *m, int B, int L, void *base)
     w.total = off;
     w.xres = reinterpret_cast<float *>(p + o_xres); w.xn = reinterpret_cast<uint16_t *>(p + o_xn);
     w.qkv = reinterpret_cast<uint16_t *>(p + o_qkv); w.att = reinterpret_cast<uint16_t *>(p + o_att);
+    w.vt = reinterpret_cast<uint16_t *>(p + o_vt); w.vt_bytes = (size_t)B * D * Lp * 2;
     w.hmid = reinterpret_cast<uint16_t *>(p + o_hmid); w.tfreq = reinterpret_cast<float *>(p + o_tfreq);
     w.t1 = reinterpret_cast<float *>(p + o_t1); w.pln = reinterpret_cast<float *>(p + o_pln);
     w.pvec = reinterpret_cast<float *>(p + o_pvec); w.tvec = reinterpret_cast<float *>(p + o_tvec);
@@ -292,16 +296,18 @@ extern "C" size_t ga_dit_workspace_bytes(const GaDitModel *m, int32_t batch, int
 #define GA_TRY(expr) do { const int rc_ = (expr); if (rc_ != GA_DIT_OK) return rc_; } while (0)
 
 extern "C" int ga_dit_cache_context(const GaDitModel *m, int32_t batch, int32_t ctx_tokens, const ga_bf16 *ctx,
-                                    ga_bf16 *ca_kv, void *stream)
+                                    ga_bf16 *ca_k, ga_bf16 *ca_vt, void *stream)
 {
-    if (!gadit::model_ok(m) || !ctx || !ca_kv) return GA_DIT_ERR_NULL_ARG;
+    if (!gadit::model_ok(m) || !ctx || !ca_k || !ca_vt) return GA_DIT_ERR_NULL_ARG;
     if (batch <= 0 || ctx_tokens <= 0) return GA_DIT_ERR_BAD_SHAPE;
     const int rows = batch * ctx_tokens, D = m->hidden;
+    const int64_t Mp = ((int64_t)ctx_tokens + 63) / 64 * 64;
     for (int i = 0; i < m->depth; ++i) {
         GaGemmArgs g{};
         g.M = rows; g.N = 2 * D; g.K = m->context_dim; g.epilogue = GA_GEMM_EPI_STORE_BF16;
         g.A = ctx; g.lda = m->context_dim; g.W = m->blocks[i].ca_kv_w; g.bias = nullptr;
-        g.out = ca_kv + (size_t)i * rows * 2 * D; g.ldo = 2 * D;
+        g.out = ca_k + (size_t)i * rows * D; g.ldo = D;                    // K columns [0, D)
+        g.vt = ca_vt + (size_t)i * batch * D * Mp; g.vt_col0 = D; g.vt_ld = Mp; g.rows_per_batch = ctx_tokens;
         GA_TRY(ga_gemm_bf16(&g, stream));
     }
     return GA_DIT_OK;
@@ -311,7 +317,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
 {
     using namespace gadit;
     if (!model_ok(m) || !a) return GA_DIT_ERR_NULL_ARG;
-    if (!a->x || !a->timesteps || !a->img_vector || !a->ca_kv || !a->out || !a->workspace) return GA_DIT_ERR_NULL_ARG;
+    if (!a->x || !a->timesteps || !a->img_vector || !a->ca_k || !a->ca_vt || !a->out || !a->workspace) return GA_DIT_ERR_NULL_ARG;
     if (m->stage2 && !a->fps_xyz) return GA_DIT_ERR_NULL_ARG;
     const int B = a->batch, L = a->tokens, D = m->hidden, Mrows = B * L;
     if (B <= 0 || B > 16 || L <= 0 || a->ctx_tokens <= 0) return GA_DIT_ERR_BAD_SHAPE;
@@ -350,6 +356,8 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         GA_TRY(ga_gemm_bf16(&g, stream));
     }
     const size_t kv_rows = (size_t)B * a->ctx_tokens;
+    const int64_t Mp = ((int64_t)a->ctx_tokens + 63) / 64 * 64, Lp = ((int64_t)L + 63) / 64 * 64;
+    if (Lp != L && hipMemsetAsync(w.vt, 0, w.vt_bytes, s) != hipSuccess) return GA_DIT_ERR_LAUNCH;  // zero key padding
     for (int i = 0; i < m->depth; ++i) {
         const GaDitBlockWeights &bw = m->blocks[i];
         const float *mod = w.mod + (size_t)i * B * 6 * D;  // [B][6][D]: shift_msa scale_msa gate_msa shift_mlp scale_mlp gate_mlp
@@ -360,9 +368,8 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         gq.M = Mrows; gq.N = D; gq.K = D; gq.epilogue = GA_GEMM_EPI_STORE_BF16; gq.A = w.xn; gq.lda = D; gq.W = bw.ca_q_w;
         gq.out = w.qkv; gq.ldo = D;
         GA_TRY(ga_gemm_bf16(&gq, stream));
-        const ga_bf16 *kv = a->ca_kv + (size_t)i * kv_rows * 2 * D;
-        GaAttentionArgs ca{B, m->heads, L, a->ctx_tokens, w.qkv, kv, kv + D, D, 2 * D, 2 * D, bw.ca_q_norm_w,
-                           bw.ca_k_norm_w, w.att, D};
+        GaAttentionArgs ca{B, m->heads, L, a->ctx_tokens, w.qkv, a->ca_k + (size_t)i * kv_rows * D,
+                           a->ca_vt + (size_t)i * B * D * Mp, D, D, Mp, bw.ca_q_norm_w, bw.ca_k_norm_w, w.att, D};
         GA_TRY(ga_attention_bf16(&ca, stream));
         GaGemmArgs go{};
         go.M = Mrows; go.N = D; go.K = D; go.epilogue = GA_GEMM_EPI_RESIDUAL; go.A = w.att; go.lda = D; go.W = bw.ca_out_w;
@@ -373,10 +380,10 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         GA_TRY(ga_rmsnorm_modulate(&n1, stream));
         GaGemmArgs gqkv{};
         gqkv.M = Mrows; gqkv.N = 3 * D; gqkv.K = D; gqkv.epilogue = GA_GEMM_EPI_STORE_BF16; gqkv.A = w.xn; gqkv.lda = D;
-        gqkv.W = bw.qkv_w; gqkv.bias = bw.qkv_b; gqkv.out = w.qkv; gqkv.ldo = 3 * D;
+        gqkv.W = bw.qkv_w; gqkv.bias = bw.qkv_b; gqkv.out = w.qkv; gqkv.ldo = 2 * D;   // q | k row-major ...
+        gqkv.vt = w.vt; gqkv.vt_col0 = 2 * D; gqkv.vt_ld = Lp; gqkv.rows_per_batch = L;  // ... v transposed
         GA_TRY(ga_gemm_bf16(&gqkv, stream));
-        GaAttentionArgs sa{B, m->heads, L, L, w.qkv, w.qkv + D, w.qkv + 2 * D, 3 * D, 3 * D, 3 * D, bw.q_norm_w,
-                           bw.k_norm_w, w.att, D};
+        GaAttentionArgs sa{B, m->heads, L, L, w.qkv, w.qkv + D, w.vt, 2 * D, 2 * D, Lp, bw.q_norm_w, bw.k_norm_w, w.att, D};
         GA_TRY(ga_attention_bf16(&sa, stream));
         GaGemmArgs gp{};
         gp.M = Mrows; gp.N = D; gp.K = D; gp.epilogue = GA_GEMM_EPI_RESIDUAL; gp.A = w.att; gp.lda = D; gp.W = bw.proj_w;

@@ -218,12 +218,14 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
             return self._ctx_cache[1]
         B, M, C = ctx_tokens.shape
         ctx = ctx_tokens.detach().to(torch.bfloat16).contiguous()
-        kv = torch.empty((self.depth, B * M, 2 * self.embed_dim), dtype=torch.bfloat16, device=ctx.device)
+        Mp = (M + 63) // 64 * 64
+        ck = torch.empty((self.depth, B * M, self.embed_dim), dtype=torch.bfloat16, device=ctx.device)
+        cvt = torch.zeros((self.depth, B * self.embed_dim, Mp), dtype=torch.bfloat16, device=ctx.device)
         stream = ctypes.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream)
-        ops.check(ops.lib().ga_dit_cache_context(ctypes.byref(pack["model"]), B, M, ctx.data_ptr(), kv.data_ptr(), stream),
-                  "ga_dit_cache_context")
-        self._ctx_cache = (key, kv, ctx_tokens)  # keep the key tensor alive so that its address cannot be reused
-        return kv
+        ops.check(ops.lib().ga_dit_cache_context(ctypes.byref(pack["model"]), B, M, ctx.data_ptr(), ck.data_ptr(),
+                                                 cvt.data_ptr(), stream), "ga_dit_cache_context")
+        self._ctx_cache = (key, (ck, cvt), ctx_tokens)  # keep the key tensor alive so that its address cannot be reused
+        return ck, cvt
 
     # -- the reference surface ------------------------------------------------------------------------------------------
     def forward(self, x, timesteps=None, context=None, y=None, get_attr="", **kwargs):
@@ -234,7 +236,7 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         pack = self._prepare(dev)
         B, L, C = x.shape
         assert C == self.in_channels
-        kv = self._context_kv(pack, context["img_crossattn"])
+        ck, cvt = self._context_kv(pack, context["img_crossattn"])
         Mctx = context["img_crossattn"].shape[1]
         xin = x.detach().float().contiguous()
         t = timesteps.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
@@ -254,7 +256,7 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         buf = pack["ws"]
         base = buf.data_ptr() + ((-buf.data_ptr()) % 256)
         args = ops.GaDitForwardArgs(B, L, Mctx, xin.data_ptr(), t.data_ptr(), vec.data_ptr(),
-                                    xyz.data_ptr() if xyz is not None else None, kv.data_ptr(), out.data_ptr(), base,
+                                    xyz.data_ptr() if xyz is not None else None, ck.data_ptr(), cvt.data_ptr(), out.data_ptr(), base,
                                     pack["ws_bytes"])
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         ops.check(Lib.ga_dit_forward(ctypes.byref(pack["model"]), ctypes.byref(args), stream), "ga_dit_forward")

@@ -16,12 +16,13 @@ EPI_STORE_BF16, EPI_GELU_BF16, EPI_RESIDUAL, EPI_STORE_F32 = 0, 1, 2, 3
 
 class GaGemmArgs(ctypes.Structure):
     _fields_ = [("M", i32), ("N", i32), ("K", i32), ("epilogue", i32), ("A", c_p), ("lda", i64), ("W", c_p),
-                ("bias", c_p), ("out", c_p), ("ldo", i64), ("gate", c_p), ("gate_stride", i64), ("rows_per_batch", i32)]
+                ("bias", c_p), ("out", c_p), ("ldo", i64), ("gate", c_p), ("gate_stride", i64), ("rows_per_batch", i32),
+                ("vt", c_p), ("vt_col0", i32), ("vt_ld", i64)]
 
 
 class GaAttentionArgs(ctypes.Structure):
-    _fields_ = [("batch", i32), ("heads", i32), ("Lq", i32), ("Lk", i32), ("q", c_p), ("k", c_p), ("v", c_p),
-                ("q_stride", i64), ("k_stride", i64), ("v_stride", i64), ("q_norm_weight", c_p), ("k_norm_weight", c_p),
+    _fields_ = [("batch", i32), ("heads", i32), ("Lq", i32), ("Lk", i32), ("q", c_p), ("k", c_p), ("vt", c_p),
+                ("q_stride", i64), ("k_stride", i64), ("vt_ld", i64), ("q_norm_weight", c_p), ("k_norm_weight", c_p),
                 ("out", c_p), ("out_stride", i64)]
 
 
@@ -52,7 +53,7 @@ class GaDitModel(ctypes.Structure):
 
 class GaDitForwardArgs(ctypes.Structure):
     _fields_ = [("batch", i32), ("tokens", i32), ("ctx_tokens", i32), ("x", c_p), ("timesteps", c_p),
-                ("img_vector", c_p), ("fps_xyz", c_p), ("ca_kv", c_p), ("out", c_p), ("workspace", c_p),
+                ("img_vector", c_p), ("fps_xyz", c_p), ("ca_k", c_p), ("ca_vt", c_p), ("out", c_p), ("workspace", c_p),
                 ("workspace_bytes", ctypes.c_size_t)]
 
 
@@ -75,7 +76,7 @@ def lib():
         for name in ("ga_gemm_bf16", "ga_attention_bf16", "ga_rmsnorm_modulate", "ga_small_linear"):
             getattr(L, name).restype = ctypes.c_int
         L.ga_dit_cache_context.restype = ctypes.c_int
-        L.ga_dit_cache_context.argtypes = [ctypes.POINTER(GaDitModel), i32, i32, c_p, c_p, c_p]
+        L.ga_dit_cache_context.argtypes = [ctypes.POINTER(GaDitModel), i32, i32, c_p, c_p, c_p, c_p]
         L.ga_dit_forward.restype = ctypes.c_int
         L.ga_dit_forward.argtypes = [ctypes.POINTER(GaDitModel), ctypes.POINTER(GaDitForwardArgs), c_p]
         _bound = True
@@ -101,30 +102,42 @@ def _need_cuda(*ts):
             raise RuntimeError("gaussiananything_amd DiT ops only run on an MI355X (HIP) device; there is no CPU path")
 
 
-def gemm(A, W, bias=None, epilogue=EPI_STORE_BF16, out=None, gate=None, rows_per_batch=1):
-    """A [M,K] bf16, W [N,K] bf16 -> see ga_dit.h.  EPI_RESIDUAL accumulates into ``out`` (fp32 [M,N])."""
-    _need_cuda(A, W, bias, out, gate)
+def gemm(A, W, bias=None, epilogue=EPI_STORE_BF16, out=None, gate=None, rows_per_batch=1, vt=None, vt_col0=0):
+    """A [M,K] bf16, W [N,K] bf16 -> see ga_dit.h.  EPI_RESIDUAL accumulates into ``out`` (fp32 [M,N]).
+    ``vt`` [B*heads*64, Lpad] bf16 (zero-initialised): columns >= vt_col0 are stored transposed there (V projection)."""
+    _need_cuda(A, W, bias, out, gate, vt)
     assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and A.stride(-1) == 1 and W.is_contiguous()
     M, K = A.shape
     N = W.shape[0]
     if out is None:
-        out = torch.empty((M, N), device=A.device,
+        out = torch.empty((M, N if vt is None else vt_col0), device=A.device,
                           dtype=torch.bfloat16 if epilogue in (EPI_STORE_BF16, EPI_GELU_BF16) else torch.float32)
     a = GaGemmArgs(M, N, K, epilogue, A.data_ptr(), A.stride(0), W.data_ptr(), _ptr(bias), out.data_ptr(), out.stride(0),
-                   _ptr(gate), gate.stride(0) if gate is not None else 0, rows_per_batch)
+                   _ptr(gate), gate.stride(0) if gate is not None else 0, rows_per_batch, _ptr(vt), vt_col0,
+                   vt.stride(0) if vt is not None else 0)
     check(lib().ga_gemm_bf16(ctypes.byref(a), _stream(A)), "ga_gemm_bf16")
     return out
 
 
-def attention(q, k, v, q_norm_weight=None, k_norm_weight=None):
-    """q [B,Lq,H,64], k/v [B,Lk,H,64] bf16 views (token stride arbitrary, head stride 64) -> [B,Lq,H*64] bf16."""
-    _need_cuda(q, k, v)
+def transpose_v(v):
+    """v [B,Lk,H,64] bf16 view -> V^T [B*H*64, Lk rounded up to 64] (zero pad), the layout ``attention`` reads."""
+    B, Lk, H, d = v.shape
+    Lp = (Lk + 63) // 64 * 64
+    vt = torch.zeros((B, H, 64, Lp), device=v.device, dtype=torch.bfloat16)
+    vt[..., :Lk] = v.permute(0, 2, 3, 1)
+    return vt.reshape(B * H * 64, Lp)
+
+
+def attention(q, k, vt, q_norm_weight=None, k_norm_weight=None):
+    """q [B,Lq,H,64], k [B,Lk,H,64] bf16 views (token stride arbitrary, head stride 64), vt = V^T [B*H*64, Lpad]
+    -> [B,Lq,H*64] bf16."""
+    _need_cuda(q, k, vt)
     B, Lq, H, d = q.shape
     Lk = k.shape[1]
-    assert d == 64 and q.stride(3) == 1 and q.stride(2) == 64 and k.stride(2) == 64 and v.stride(2) == 64
-    assert q.stride(0) == Lq * q.stride(1) and k.stride(0) == Lk * k.stride(1) and v.stride(0) == Lk * v.stride(1)
+    assert d == 64 and q.stride(3) == 1 and q.stride(2) == 64 and k.stride(2) == 64 and vt.stride(1) == 1
+    assert q.stride(0) == Lq * q.stride(1) and k.stride(0) == Lk * k.stride(1) and vt.shape[0] == B * H * 64
     out = torch.empty((B, Lq, H * 64), device=q.device, dtype=torch.bfloat16)
-    a = GaAttentionArgs(B, H, Lq, Lk, q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(1), k.stride(1), v.stride(1),
+    a = GaAttentionArgs(B, H, Lq, Lk, q.data_ptr(), k.data_ptr(), vt.data_ptr(), q.stride(1), k.stride(1), vt.stride(0),
                         _ptr(q_norm_weight), _ptr(k_norm_weight), out.data_ptr(), H * 64)
     check(lib().ga_attention_bf16(ctypes.byref(a), _stream(q)), "ga_attention_bf16")
     return out

@@ -52,18 +52,26 @@ typedef struct GaGemmArgs {
     int64_t ldo;              /* elements, multiple of 4                                             */
     const float *gate;        /* EPI 2: [M / rows_per_batch, gate_stride] or NULL (= 1)              */
     int64_t gate_stride;      /* elements between the gate rows of consecutive batch items           */
-    int32_t rows_per_batch;   /* EPI 2: tokens per batch item                                        */
+    int32_t rows_per_batch;   /* EPI 2 / V^T store: tokens per batch item                            */
+    /* EPI 0 only, optional: output columns n >= vt_col0 (the V projection) are NOT written to `out` but TRANSPOSED into
+     * vt[(b*heads + h)*64 + d][token], b = m / rows_per_batch, token = m % rows_per_batch, h*64 + d = n - vt_col0, row
+     * length vt_ld (>= rows_per_batch, multiple of 64; the pad must stay zero) -- the layout ga_attention_bf16 reads. */
+    ga_bf16 *vt;
+    int32_t vt_col0;
+    int64_t vt_ld;
 } GaGemmArgs;
 
 int ga_gemm_bf16(const GaGemmArgs *args, void *stream);
 
 /* softmax(q k^T / sqrt(64)) v with per-head RMSNorm of q and k fused on load (weights qn/kn, eps 1e-5; NULL = none):
  * what MemEffAttention / MemoryEfficientCrossAttention compute between their projections.  head_dim must be 64.
- * q row of (batch b, token i, head h) starts at q + (b*Lq + i)*q_stride + h*64 (same for k, v, out). */
+ * q row of (batch b, token i, head h) starts at q + (b*Lq + i)*q_stride + h*64 (same for k, out).
+ * V is read TRANSPOSED: vt[(b*heads + h)*64 + d][key], row length vt_ld >= Lk rounded up to 64, zero beyond Lk
+ * (written in that layout by ga_gemm_bf16's V^T store). */
 typedef struct GaAttentionArgs {
     int32_t batch, heads, Lq, Lk;
-    const ga_bf16 *q, *k, *v;
-    int64_t q_stride, k_stride, v_stride; /* elements between consecutive tokens                     */
+    const ga_bf16 *q, *k, *vt;
+    int64_t q_stride, k_stride, vt_ld;    /* elements                                               */
     const float *q_norm_weight, *k_norm_weight; /* [64] each                                        */
     ga_bf16 *out;
     int64_t out_stride;
@@ -146,7 +154,8 @@ typedef struct GaDitForwardArgs {
     const float *timesteps;   /* [B']                                                                  */
     const float *img_vector;  /* [B', ctx]                                                             */
     const float *fps_xyz;     /* [B', L, 3] (stage 2) or NULL                                          */
-    const ga_bf16 *ca_kv;     /* [depth][B'*M, 2D] cached K|V projections of the image tokens: ga_dit_cache_context */
+    const ga_bf16 *ca_k;      /* [depth][B'*M, D]        cached K projections of the image tokens (ga_dit_cache_context) */
+    const ga_bf16 *ca_vt;     /* [depth][B'*heads*64, Mp] cached V projections, transposed, Mp = M rounded up to 64, zero pad */
     float *out;               /* [B', L, Cout] fp32 (the reference returns x.float())                  */
     void *workspace;          /* ga_dit_workspace_bytes()                                              */
     size_t workspace_bytes;
@@ -155,9 +164,10 @@ typedef struct GaDitForwardArgs {
 size_t ga_dit_workspace_bytes(const GaDitModel *model, int32_t batch, int32_t tokens, int32_t ctx_tokens);
 
 /* K/V of every block's cross-attention depend only on the (step-invariant) image tokens: project them once per
- * sample.  img_crossattn: bf16 [B'*M, ctx]; ca_kv out: [depth][B'*M, 2D]. */
+ * sample.  img_crossattn: bf16 [B'*M, ctx]; outputs as described in GaDitForwardArgs (ca_vt must be zero-filled by the
+ * caller beforehand: only the first M keys of every row are written). */
 int ga_dit_cache_context(const GaDitModel *model, int32_t batch, int32_t ctx_tokens, const ga_bf16 *img_crossattn,
-                         ga_bf16 *ca_kv, void *stream);
+                         ga_bf16 *ca_k, ga_bf16 *ca_vt, void *stream);
 
 int ga_dit_forward(const GaDitModel *model, const GaDitForwardArgs *args, void *stream);
 

@@ -43,6 +43,25 @@ def test_gemm_epilogues(gpu_device, M, N, K):
     assert rel_l2(x, x0 + ref) < 1e-3
 
 
+def test_gemm_transposed_v_store(gpu_device):
+    """The QKV projection writes q|k row-major and V transposed per (batch, head): [B*H*64, Lpad]."""
+    from gaussiananything_amd import dit_ops as ops
+    B, L, H, K = 2, 96, 2, 128
+    D = H * 64
+    g = torch.Generator(device="cpu").manual_seed(9)
+    A = torch.randn(B * L, K, generator=g).to(gpu_device).bfloat16()
+    W = (torch.randn(3 * D, K, generator=g) / 11).to(gpu_device).bfloat16()
+    bias = torch.randn(3 * D, generator=g).to(gpu_device)
+    Lp = 128
+    vt = torch.zeros(B * D, Lp, device=gpu_device, dtype=torch.bfloat16)
+    out = ops.gemm(A, W, bias, ops.EPI_STORE_BF16, rows_per_batch=L, vt=vt, vt_col0=2 * D)
+    ref = (A.float() @ W.float().T + bias)
+    assert out.shape == (B * L, 2 * D) and rel_l2(out.float(), ref[:, :2 * D]) < 1e-2
+    vref = ref[:, 2 * D:].reshape(B, L, H, 64).permute(0, 2, 3, 1).reshape(B * D, L)
+    assert rel_l2(vt[:, :L].float(), vref) < 1e-2
+    assert float(vt[:, L:].abs().max()) == 0.0
+
+
 def test_gemm_is_transpose_sensitive(gpu_device):
     """A = I with an asymmetric W: a swapped row/column mapping in the epilogue cannot pass."""
     from gaussiananything_amd import dit_ops as ops
@@ -66,7 +85,7 @@ def test_attention(gpu_device, B, H, Lq, Lk, norm):
     q = qkv_q[..., :D].unflatten(-1, (H, 64))
     k = kvbuf[..., :D].unflatten(-1, (H, 64))
     v = kvbuf[..., D:].unflatten(-1, (H, 64))
-    out = ops.attention(q, k, v, qn if norm else None, kn if norm else None)
+    out = ops.attention(q, k, ops.transpose_v(v), qn if norm else None, kn if norm else None)
     qf, kf, vf = q.float().permute(0, 2, 1, 3), k.float().permute(0, 2, 1, 3), v.float().permute(0, 2, 1, 3)
     if norm:
         qf = qf * torch.rsqrt(qf.pow(2).mean(-1, keepdim=True) + 1e-5) * qn
@@ -86,7 +105,7 @@ def test_attention_online_softmax_rescale_is_exercised(gpu_device):
     v = torch.randn(B, Lk, H, 64, generator=g)
     k[0, 250, 0] = q[0, 7, 0] * 6.0          # score ~ 6*|q|^2/8 >> the rest
     q, k, v = (t.to(gpu_device).bfloat16() for t in (q, k, v))
-    out = ops.attention(q, k, v)
+    out = ops.attention(q, k, ops.transpose_v(v))
     qf, kf, vf = (t.float().permute(0, 2, 1, 3) for t in (q, k, v))
     ref = (torch.softmax(qf @ kf.transpose(-1, -2) * 0.125, -1) @ vf).permute(0, 2, 1, 3).reshape(B, Lq, 64)
     assert rel_l2(out.float(), ref) < 1e-2
