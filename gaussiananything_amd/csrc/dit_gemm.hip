@@ -12,7 +12,7 @@
 // lane is then 4 consecutive n for one m, i.e. 8-byte (bf16) / 16-byte (fp32) contiguous stores in the row-major
 // output.  Workgroup tile 128(n) x 128(m) x 64(k), 4 waves as 2x2, each wave 4x4 fragments (64 accumulator VGPRs).
 // Staging is LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction straight into LDS, no VGPR round trip) through
-// a 4-deep ring (128 KiB of the CU's 160 KiB): K-tiles t+1..t+3 are in flight while tile t is multiplied, with COUNTED
+// a ring of 4 slots (128 KiB of the CU's 160 KiB; 2 slots for the larger grids): K-tiles t+1..t+3 are in flight while tile t is multiplied, with COUNTED
 // waits (s_waitcnt vmcnt(24/16/8/0): 8 DMA instructions per wave per tile) and a raw s_barrier -- one barrier per
 // K-tile.  At M = 1536 the grid is only 96-384 workgroups, so every workgroup must run at MFMA speed on its own: with a
 // 2-deep ring each K-tile cost a full DMA latency (measured 1.1 us vs 0.22 us of MFMA work).  The DMA writes LDS in
@@ -25,8 +25,7 @@ namespace gadit {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_ELEMS = 128 * BK;  // one operand tile: 128 rows x 64 bf16 = 16 KiB
-constexpr int NSTAGE = 4;
-constexpr int GEMM_LDS_BYTES = NSTAGE * 2 * TILE_ELEMS * 2;  // 128 KiB
+constexpr int STAGE_BYTES = 2 * TILE_ELEMS * 2;  // one ring slot: W tile + A tile = 32 KiB
 
 struct GemmP {  // by-value kernel parameters (kept flat: no pointer into the argument struct is taken)
     int M, N, K, rows_per_batch;
@@ -45,7 +44,7 @@ __device__ __forceinline__ void glds16(const uint16_t *gsrc, uint16_t *lds_wave_
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <int EPI>
+template <int EPI, int NST>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];  // [NSTAGE][W | A][row][slot] = 4 x 32 KiB
@@ -101,28 +100,30 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
         }                                                                                             \
     } while (0)
 
-    // wait until my DMA of the tile that is `ahead` tiles behind the newest issued one has landed
+    // ring of NST slots: tiles kt+1 .. kt+NST-1 are in flight while tile kt is multiplied (NST-1 tiles of look-ahead).
+    // NST = 4 (128 KiB, one workgroup per CU) for the small grids, NST = 2 (64 KiB, two workgroups per CU, which hide each
+    // other's latency) when the grid has more than one workgroup per CU -- chosen by the host from the grid size.
 #define GA_WAIT_TILES_IN_FLIGHT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((N) * 8) : "memory")
 #define GA_PHASE(BUF, KT)                                                                              \
     do {                                                                                               \
-        const int rem_ = nk - 1 - (KT); /* tiles issued after KT so far: min(rem_, NSTAGE-2) */          \
-        if (rem_ >= 2) GA_WAIT_TILES_IN_FLIGHT(2);                                                      \
-        else if (rem_ == 1) GA_WAIT_TILES_IN_FLIGHT(1);                                                 \
+        const int rem_ = nk - 1 - (KT); /* tiles after KT; at most NST-2 of them are issued so far */    \
+        if (NST >= 4 && rem_ >= 2) GA_WAIT_TILES_IN_FLIGHT(2);                                          \
+        else if (NST >= 3 && rem_ >= 1) GA_WAIT_TILES_IN_FLIGHT(1);                                     \
         else GA_WAIT_TILES_IN_FLIGHT(0);                                                                \
         __builtin_amdgcn_s_barrier(); /* everyone's part of tile KT landed; everyone left tile KT-1 */  \
-        if ((KT) + 3 < nk) GA_STAGE(((BUF) + 3) & 3, (KT) + 3);                                         \
+        if ((KT) + NST - 1 < nk) GA_STAGE(((BUF) + NST - 1) % NST, (KT) + NST - 1);                     \
         GA_COMPUTE(BUF);                                                                                \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* my fragment reads of this buffer are done */ \
     } while (0)
 
     GA_STAGE(0, 0);
-    if (nk > 1) GA_STAGE(1, 1);
-    if (nk > 2) GA_STAGE(2, 2);
-    for (int kt = 0; kt < nk; kt += 4) {
+    if (NST > 2 && nk > 1) GA_STAGE(1 % NST, 1);
+    if (NST > 3 && nk > 2) GA_STAGE(2 % NST, 2);
+    for (int kt = 0; kt < nk; kt += NST) {
         GA_PHASE(0, kt);
-        if (kt + 1 < nk) GA_PHASE(1, kt + 1);
-        if (kt + 2 < nk) GA_PHASE(2, kt + 2);
-        if (kt + 3 < nk) GA_PHASE(3, kt + 3);
+        if (kt + 1 < nk) GA_PHASE(1 % NST, kt + 1);
+        if (NST > 2 && kt + 2 < nk) GA_PHASE(2 % NST, kt + 2);
+        if (NST > 3 && kt + 3 < nk) GA_PHASE(3 % NST, kt + 3);
     }
 #undef GA_PHASE
 #undef GA_WAIT_TILES_IN_FLIGHT
@@ -192,17 +193,22 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
                   a->vt, a->vt_col0, a->vt ? (a->N - a->vt_col0) / 64 : 0, a->vt_ld};
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KiB of dynamic LDS has to be opted into once per kernel
-        (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES);
         attr_set = true;
     }
+    // more than one workgroup per CU available -> shallow ring, two co-resident workgroups; else deep ring
+    const bool deep = (long long)grid.x * grid.y <= 256;
+#define GA_LAUNCH(E)                                                                                            \
+    if (deep) hipLaunchKernelGGL((gemm_bf16_kernel<E, 4>), grid, dim3(256), 4 * STAGE_BYTES, s, p);              \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<E, 2>), grid, dim3(256), 2 * STAGE_BYTES, s, p);
     switch (a->epilogue) {
-    case GA_GEMM_EPI_STORE_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<0>, grid, dim3(256), GEMM_LDS_BYTES, s, p); break;
-    case GA_GEMM_EPI_GELU_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<1>, grid, dim3(256), GEMM_LDS_BYTES, s, p); break;
-    case GA_GEMM_EPI_RESIDUAL: hipLaunchKernelGGL(gemm_bf16_kernel<2>, grid, dim3(256), GEMM_LDS_BYTES, s, p); break;
-    case GA_GEMM_EPI_STORE_F32: hipLaunchKernelGGL(gemm_bf16_kernel<3>, grid, dim3(256), GEMM_LDS_BYTES, s, p); break;
+    case GA_GEMM_EPI_STORE_BF16: GA_LAUNCH(0) break;
+    case GA_GEMM_EPI_GELU_BF16: GA_LAUNCH(1) break;
+    case GA_GEMM_EPI_RESIDUAL: GA_LAUNCH(2) break;
+    case GA_GEMM_EPI_STORE_F32: GA_LAUNCH(3) break;
     default: return GA_DIT_ERR_BAD_SHAPE;
     }
     return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;

@@ -30,3 +30,13 @@ for (B, H, Lq, Lk) in [(2, 16, 768, 768), (2, 16, 768, 1369), (2, 12, 768, 768)]
     vt = ops.transpose_v(v)
     us = timeit(lambda: ops.attention(qq, k, vt, w, w))
     print(f"attn B={B} H={H} Lq={Lq} Lk={Lk}: {us:7.1f} us  {4*B*H*Lq*Lk*64/us/1e6:7.1f} TF/s")
+# ablations
+B, H, Lq, Lk = 2, 16, 768, 768
+D = H * 64
+q = torch.randn(B, Lq, 3 * D, device=dev).bfloat16(); kv = torch.randn(B, Lk, 2 * D, device=dev).bfloat16()
+qq = q[..., :D].unflatten(-1, (H, 64)); k = kv[..., :D].unflatten(-1, (H, 64)); v = kv[..., D:].unflatten(-1, (H, 64))
+vt = ops.transpose_v(v)
+print("attn no norms:", timeit(lambda: ops.attention(qq, k, vt, None, None)))
+for LK in (64, 128, 256, 512, 768):
+    kk = k[:, :LK].contiguous(); vtt = ops.transpose_v(v[:, :LK])
+    print("attn Lk", LK, timeit(lambda: ops.attention(qq, kk, vtt, w, w)))
