@@ -239,9 +239,13 @@ def main():
             P = H * W
             blend_bytes = 76.0 * int(st[0]) + 40.0 * P * v      # per launch (all V views), SURVEY.md 8d
             achieved = blend_bytes / (stage["blend"] * 1e-3) / 1e9
+            traffic = None  # PMC counters cannot be collected live: taken from the committed rocprofv3 passes
+            pmc_file = os.path.join(ROOT, "profiles", "r1_blend_pmc.json")
+            if a.scene == "surface" and n == 100_000 and v == 8 and H == 512 and os.path.exists(pmc_file):
+                traffic = json.load(open(pmc_file))["traffic_bytes_per_launch"]
             out["roofline"] = {"bound": "hbm", "kernel": "surfel_blend_kernel", "achieved": round(achieved, 2),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                               "traffic": None, "algorithmic_bytes_per_launch": int(blend_bytes),
+                               "traffic": traffic, "algorithmic_bytes_per_launch": int(blend_bytes),
                                "avg_launch_ms": round(stage["blend"], 5),
                                "note": "blend is VALU/latency-bound, not HBM-bound (SURVEY.md 8d): see blend_valu"}
             # upper bound on evaluated (pixel, splat) pairs and the ~60 flop/pair estimate of SURVEY.md 8d
