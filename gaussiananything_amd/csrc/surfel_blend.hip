@@ -16,9 +16,11 @@
 //     coefficients to the quadrant origin and parks it in a wave-private LDS slot.  A 64-bit ballot of the box test
 //     is the list of entries that can contribute (about half are culled for the sub-pixel splats of real scenes,
 //     which also halves the serial chain);
-//   * survivors are walked with s_ff1 on the ballot with LANES = PIXELS; a survivor's record is read back from LDS with
-//     broadcast ds_read_b128 (uniform address, conflict-free), double-buffered in registers one survivor ahead so the
-//     LDS latency is off the chain;
+//   * LANES = PIXELS with per-lane survivor lists: from 16 ballots per chunk (does my entry's box cover pixel column c /
+//     row r of the quadrant?) every lane ANDs the masks of its own column and row and walks only those entries --
+//     the trip count of a wave drops from "survivors of the quadrant" to "survivors of its busiest pixel"; records are
+//     gathered from LDS four at a time, their alphas evaluated back to back (no cross-entry dependence), then
+//     composited in order;
 //   * the ray/splat intersection uses the plane form p = C' + dx*A + dy*B (6 FMAs) instead of two 3-vector affine
 //     maps and a cross product (18 ops); A, B, C come from the preprocess kernel;
 //   * upstream's chain of `continue` filters is evaluated branch-free into one predicate, so a pair costs ~25 VALU
@@ -46,44 +48,57 @@ __device__ __forceinline__ Rec lds_read_rec(const float4 (*planes)[64], int j)
     return Rec{planes[0][j], planes[1][j], planes[2][j], planes[3][j], planes[4][j], planes[5][j].x};
 }
 
-// One (pixel, splat) evaluation -- SURVEY.md A.1 "Blend".  dx, dy: this lane's pixel relative to the quadrant origin.
-// Upstream's chain of `continue` filters is evaluated branch-free into one predicate (the filters commute: each one
-// only decides whether the pair is skipped), leaving a single divergent region for the pairs that contribute.
-__device__ __forceinline__ void blend_one(const Rec &r, float dx, float dy, PixelAcc &a, bool &done)
+// One (pixel, splat) evaluation -- SURVEY.md A.1 "Blend" -- in two parts.  dx, dy: this lane's pixel relative to the
+// quadrant origin.  eval_alpha is free of cross-entry dependences (several entries are evaluated back to back in one
+// basic block, which lets a lone wave issue at ~2.4 instead of ~4.4 cycles per instruction); composite is the short
+// sequential part.  Upstream's chain of `continue` filters is evaluated branch-free into one predicate (the filters
+// commute: each one only decides whether the pair is skipped).
+struct Alpha {
+    float alpha, sx, sy;
+    bool pass, use3d;
+};
+
+__device__ __forceinline__ Alpha eval_alpha(const Rec &r, float dx, float dy)
 {
-    const float kM = kFar / (kFar - kNear);
     // p = C' + dx*A + dy*B
     const float p0 = fmaf(dy, r.q0.w, fmaf(dx, r.q0.x, r.q1.z));
     const float p1 = fmaf(dy, r.q1.x, fmaf(dx, r.q0.y, r.q1.w));
     const float p2 = fmaf(dy, r.q1.y, fmaf(dx, r.q0.z, r.q2.x));
     const float rz = __builtin_amdgcn_rcpf(p2);
-    const float sx = p0 * rz, sy = p1 * rz;
-    const float rho3d = sx * sx + sy * sy;
+    Alpha o;
+    o.sx = p0 * rz;
+    o.sy = p1 * rz;
+    const float rho3d = o.sx * o.sx + o.sy * o.sy;
     const float ex = r.q2.y - dx, ey = r.q2.z - dy;  // centre - pixel
     const float rho2d = kFilterInvSquare * (ex * ex + ey * ey);
     const float rho = fminf(rho3d, rho2d);
-    const float alpha = fminf(0.99f, r.q2.w * __builtin_amdgcn_exp2f(rho * -0.72134752044f));
+    o.use3d = rho3d <= rho2d;
+    o.alpha = fminf(0.99f, r.q2.w * __builtin_amdgcn_exp2f(rho * -0.72134752044f));
     // upstream: p.z == 0 -> skip ; power = -0.5*rho > 0 -> skip (a NaN rho passes) ; alpha < 1/255 -> skip
-    const bool pass = !done && p2 != 0.0f && !(rho < 0.0f) && !(alpha < 1.0f / 255.0f);
-    if (pass) {
-        const float depth = (rho3d <= rho2d) ? fmaf(sx, r.q3.x, sy * r.q3.y) + r.q3.z : r.q3.z;
-        const float test_T = a.T * (1.0f - alpha);
-        const bool near_ok = !(depth < kNear);            // upstream: depth < near -> skip (before the alpha test)
-        const bool stop = near_ok && test_T < 0.0001f;    // upstream: done = true
-        done = done || stop;
-        if (near_ok && !stop) {
-            const float w = alpha * a.T;
-            const float A = 1.0f - a.T;
-            const float m = kM * (1.0f - kNear * __builtin_amdgcn_rcpf(depth));
-            a.dist += (m * m * A + a.M2 - 2.0f * m * a.M1) * w;
-            a.Dp += depth * w;
-            a.M1 += m * w;
-            a.M2 += m * m * w;
-            if (a.T > 0.5f) a.median = depth;
-            a.N0 += r.q3.w * w; a.N1 += r.q4.x * w; a.N2 += r.q4.y * w;
-            a.C0 += r.q4.z * w; a.C1 += r.q4.w * w; a.C2 += r.cb * w;
-            a.T = test_T;
-        }
+    o.pass = p2 != 0.0f && !(rho < 0.0f) && !(o.alpha < 1.0f / 255.0f);
+    return o;
+}
+
+__device__ __forceinline__ void composite(const Rec &r, const Alpha &e, PixelAcc &a, bool &done)
+{
+    const float kM = kFar / (kFar - kNear);
+    const float depth = e.use3d ? fmaf(e.sx, r.q3.x, e.sy * r.q3.y) + r.q3.z : r.q3.z;
+    const float test_T = a.T * (1.0f - e.alpha);
+    const bool near_ok = !(depth < kNear);            // upstream: depth < near -> skip (before the alpha test)
+    const bool stop = near_ok && test_T < 0.0001f;    // upstream: done = true
+    done = done || stop;
+    if (near_ok && !stop) {
+        const float w = e.alpha * a.T;
+        const float A = 1.0f - a.T;
+        const float m = kM * (1.0f - kNear * __builtin_amdgcn_rcpf(depth));
+        a.dist += (m * m * A + a.M2 - 2.0f * m * a.M1) * w;
+        a.Dp += depth * w;
+        a.M1 += m * w;
+        a.M2 += m * m * w;
+        if (a.T > 0.5f) a.median = depth;
+        a.N0 += r.q3.w * w; a.N1 += r.q4.x * w; a.N2 += r.q4.y * w;
+        a.C0 += r.q4.z * w; a.C1 += r.q4.w * w; a.C2 += r.cb * w;
+        a.T = test_T;
     }
 }
 
@@ -95,7 +110,7 @@ __global__ __launch_bounds__(256) void surfel_blend_kernel(const uint32_t *__res
                                                            const float *__restrict__ bg, Dims dm,
                                                            float *__restrict__ out_color,
                                                            float *__restrict__ out_others,
-                                                           const int64_t *__restrict__ status)
+                                                           int64_t *__restrict__ status, int flags)
 {
     __shared__ __attribute__((aligned(16))) float4 stage[4][6][64];  // wave-private record planes, 24 KiB
     if (status[GA_STATUS_OVERFLOW]) return;
@@ -118,6 +133,7 @@ __global__ __launch_bounds__(256) void surfel_blend_kernel(const uint32_t *__res
     float4(*planes)[64] = stage[wave];
 
     PixelAcc a = {1.0f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned stat_iters = 0, stat_chunks = 0;
     bool done = !inside;
 
     // ---- software pipeline over 64-entry chunks (lanes = entries) ------------------------------------------------
@@ -185,7 +201,8 @@ __global__ __launch_bounds__(256) void surfel_blend_kernel(const uint32_t *__res
             const float4 *r = rec4 + (size_t)idn * 6;
             g0 = r[0]; g1 = r[1]; g2 = r[2]; g3 = r[3]; g4 = r[4]; g5 = r[5];
         }
-        if (hitmask == 0) continue;
+        ++stat_chunks;
+        if (hitmask == 0 || (flags & 2)) continue;  // flag 2: staging only (measurement aid, not in the public header)
         // ---- lanes = pixels: my own survivor list = entries whose box covers MY column and MY row ---------------
         unsigned long long mx = xm[0], my = ym[0];
 #pragma unroll
@@ -194,30 +211,42 @@ __global__ __launch_bounds__(256) void surfel_blend_kernel(const uint32_t *__res
             my = ((rowsel[c] >> lane) & 1ull) ? ym[c] : my;
         }
         unsigned long long m = done ? 0ull : (mx & my);
-        // Records ping-pong between two register sets, one entry ahead; lanes walk their own lists independently
-        // (compositing order only matters per pixel).  A lane whose list is exhausted re-reads its last slot.
-        int ja = m ? __builtin_ctzll(m) : lane;
-        bool live_a = m != 0;
-        m &= m - 1;
-        Rec ra = lds_read_rec(planes, ja);
+        // Lanes walk their own lists independently (compositing order only matters per pixel), kU entries per trip:
+        // the kU gathers and alpha evaluations are mutually independent (one basic block, high issue rate, LDS latency
+        // paid once per trip), then the contributing ones are composited in order.  An exhausted lane re-reads its
+        // last slot with the pass flag forced off.
+        constexpr int kU = 4;
         while (true) {
-            const bool live_b = m != 0;
-            const int jb = live_b ? __builtin_ctzll(m) : ja;
-            m &= m - 1;
-            const Rec rb = lds_read_rec(planes, jb);
-            if (live_a) blend_one(ra, dx, dy, a, done);
+            int j[kU];
+            bool live[kU];
+            int last = lane;
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                live[u] = m != 0;
+                j[u] = live[u] ? __builtin_ctzll(m) : last;
+                last = j[u];
+                m &= m - 1;
+            }
+            stat_iters += kU;
+            Rec r[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) r[u] = lds_read_rec(planes, j[u]);
+            Alpha e[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) e[u] = eval_alpha(r[u], dx, dy);
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+                if (live[u] && e[u].pass && !done) composite(r[u], e[u], a, done);
             if (done) m = 0;
-            if (__builtin_amdgcn_ballot_w64(live_b && !done) == 0) break;
-            live_a = m != 0;
-            ja = live_a ? __builtin_ctzll(m) : jb;
-            m &= m - 1;
-            ra = lds_read_rec(planes, ja);
-            if (live_b) blend_one(rb, dx, dy, a, done);
-            if (done) m = 0;
-            if (__builtin_amdgcn_ballot_w64(live_a && !done) == 0) break;
+            if (__builtin_amdgcn_ballot_w64(m != 0) == 0) break;
         }
     }
 
+    if ((flags & GA_SURFEL_FLAG_STATS) && lane == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_ITERS), (unsigned long long)stat_iters);
+        atomicMax(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_MAX_ITERS), (unsigned long long)stat_iters);
+        atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_CHUNKS), (unsigned long long)stat_chunks);
+    }
     if (inside) {
         const size_t HW = (size_t)dm.H * dm.W, pid = (size_t)pyi * dm.W + pxi;
         float *oc = out_color + (size_t)v * 3 * HW + pid;
@@ -239,7 +268,7 @@ void launch_blend(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &
 {
     const int nt = d.V * d.tiles;
     hipLaunchKernelGGL(surfel_blend_kernel, dim3(nt), dim3(256), 0, s, ws.tile_start, ws.tile_order, ws.point_list,
-                       ws.bbox, ws.record, a.bg, d, a.out_color, a.out_others, ws.status);
+                       ws.bbox, ws.record, a.bg, d, a.out_color, a.out_others, ws.status, a.flags);
 }
 
 }  // namespace ga

@@ -192,7 +192,7 @@ class SurfelForwardPlan:
     """
 
     def __init__(self, means3D, opacities, colors_precomp, scales, rotations, viewmatrix, projmatrix, bg,
-                 image_height, image_width, scale_modifier=1.0, capacity=None):
+                 image_height, image_width, scale_modifier=1.0, capacity=None, flags=0):
         device = means3D.device
         self.device = device
         self.means3D = _f32c(means3D, "means3D", device)
@@ -207,6 +207,7 @@ class SurfelForwardPlan:
         self.bg = _f32c(bg, "bg", device).reshape(3)
         self.h, self.w = int(image_height), int(image_width)
         self.scale_modifier = float(scale_modifier)
+        self.flags = int(flags)
         self.color = torch.empty((v, 3, self.h, self.w), dtype=torch.float32, device=device)
         self.allmap = torch.empty((v, 7, self.h, self.w), dtype=torch.float32, device=device)
         self.radii = torch.empty((v, n), dtype=torch.int32, device=device)
@@ -217,7 +218,7 @@ class SurfelForwardPlan:
     def _bind(self, stage_events):
         ws = self.ws
         self._args = _lib.GaSurfelForwardArgs(
-            self.n, self.v, self.h, self.w, self.scale_modifier, 0, self.means3D.data_ptr(),
+            self.n, self.v, self.h, self.w, self.scale_modifier, self.flags, self.means3D.data_ptr(),
             self.opacities.data_ptr(), self.colors.data_ptr(), self.scales.data_ptr(), self.rotations.data_ptr(),
             self.vm.data_ptr(), self.pm.data_ptr(), self.bg.data_ptr(), self.color.data_ptr(),
             self.allmap.data_ptr(), self.radii.data_ptr(), ws.ptr, ws.layout.total_bytes, ws.capacity, stage_events)

@@ -39,7 +39,10 @@ extern "C" {
 #define GA_STATUS_OVERFLOW 1       /* 1 if D > capacity: outputs are then NOT written; retry with more capacity */
 #define GA_STATUS_MAX_TILE 2       /* longest per-tile list (diagnostic)                           */
 #define GA_STATUS_EXTRA_RUNS 3     /* number of entries of run_table (internal)                    */
-#define GA_STATUS_WORDS 4
+#define GA_STATUS_BLEND_ITERS 4   /* with GA_SURFEL_FLAG_STATS: total inner-loop iterations of the blend (all waves) */
+#define GA_STATUS_BLEND_MAX_ITERS 5 /* with GA_SURFEL_FLAG_STATS: most iterations executed by one wave              */
+#define GA_STATUS_BLEND_CHUNKS 6  /* with GA_SURFEL_FLAG_STATS: total 64-entry chunks consumed                          */
+#define GA_STATUS_WORDS 8
 
 typedef struct GaSurfelForwardArgs {
     int32_t num_points;      /* N Gaussians                                                       */
@@ -70,6 +73,7 @@ typedef struct GaSurfelForwardArgs {
 #define GA_SURFEL_STAGE_EVENTS 5
 
 #define GA_SURFEL_FLAG_NONE 0
+#define GA_SURFEL_FLAG_STATS 1      /* collect the GA_STATUS_BLEND_* diagnostics (costs three atomics per wave) */
 
 /* Byte offsets of the workspace sections (all 256-byte aligned).  Tests read the integer artefacts
  * (rect, tile ranges, sorted point list) straight out of the workspace through these offsets. */
