@@ -308,6 +308,7 @@ extern "C" int ga_dit_cache_context(const GaDitModel *m, int32_t batch, int32_t 
         g.A = ctx; g.lda = m->context_dim; g.W = m->blocks[i].ca_kv_w; g.bias = nullptr;
         g.out = ca_k + (size_t)i * rows * D; g.ldo = D;                    // K columns [0, D)
         g.vt = ca_vt + (size_t)i * batch * D * Mp; g.vt_col0 = D; g.vt_ld = Mp; g.rows_per_batch = ctx_tokens;
+        g.qk_w0 = m->blocks[i].ca_k_norm_w; g.qk_cols0 = D; g.qk_cols1 = D;  // k_norm applied once, here
         GA_TRY(ga_gemm_bf16(&g, stream));
     }
     return GA_DIT_OK;
@@ -367,9 +368,10 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         GaGemmArgs gq{};
         gq.M = Mrows; gq.N = D; gq.K = D; gq.epilogue = GA_GEMM_EPI_STORE_BF16; gq.A = w.xn; gq.lda = D; gq.W = bw.ca_q_w;
         gq.out = w.qkv; gq.ldo = D;
+        gq.qk_w0 = bw.ca_q_norm_w; gq.qk_cols0 = D; gq.qk_cols1 = D;           // q_norm fused into the projection
         GA_TRY(ga_gemm_bf16(&gq, stream));
         GaAttentionArgs ca{B, m->heads, L, a->ctx_tokens, w.qkv, a->ca_k + (size_t)i * kv_rows * D,
-                           a->ca_vt + (size_t)i * B * D * Mp, D, D, Mp, bw.ca_q_norm_w, bw.ca_k_norm_w, w.att, D};
+                           a->ca_vt + (size_t)i * B * D * Mp, D, D, Mp, nullptr, nullptr, w.att, D};
         GA_TRY(ga_attention_bf16(&ca, stream));
         GaGemmArgs go{};
         go.M = Mrows; go.N = D; go.K = D; go.epilogue = GA_GEMM_EPI_RESIDUAL; go.A = w.att; go.lda = D; go.W = bw.ca_out_w;
@@ -382,8 +384,9 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         gqkv.M = Mrows; gqkv.N = 3 * D; gqkv.K = D; gqkv.epilogue = GA_GEMM_EPI_STORE_BF16; gqkv.A = w.xn; gqkv.lda = D;
         gqkv.W = bw.qkv_w; gqkv.bias = bw.qkv_b; gqkv.out = w.qkv; gqkv.ldo = 2 * D;   // q | k row-major ...
         gqkv.vt = w.vt; gqkv.vt_col0 = 2 * D; gqkv.vt_ld = Lp; gqkv.rows_per_batch = L;  // ... v transposed
+        gqkv.qk_w0 = bw.q_norm_w; gqkv.qk_cols0 = D; gqkv.qk_w1 = bw.k_norm_w; gqkv.qk_cols1 = 2 * D;  // per-head q/k RMSNorm
         GA_TRY(ga_gemm_bf16(&gqkv, stream));
-        GaAttentionArgs sa{B, m->heads, L, L, w.qkv, w.qkv + D, w.vt, 2 * D, 2 * D, Lp, bw.q_norm_w, bw.k_norm_w, w.att, D};
+        GaAttentionArgs sa{B, m->heads, L, L, w.qkv, w.qkv + D, w.vt, 2 * D, 2 * D, Lp, nullptr, nullptr, w.att, D};
         GA_TRY(ga_attention_bf16(&sa, stream));
         GaGemmArgs gp{};
         gp.M = Mrows; gp.N = D; gp.K = D; gp.epilogue = GA_GEMM_EPI_RESIDUAL; gp.A = w.att; gp.lda = D; gp.W = bw.proj_w;

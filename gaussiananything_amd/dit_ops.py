@@ -17,7 +17,8 @@ EPI_STORE_BF16, EPI_GELU_BF16, EPI_RESIDUAL, EPI_STORE_F32 = 0, 1, 2, 3
 class GaGemmArgs(ctypes.Structure):
     _fields_ = [("M", i32), ("N", i32), ("K", i32), ("epilogue", i32), ("A", c_p), ("lda", i64), ("W", c_p),
                 ("bias", c_p), ("out", c_p), ("ldo", i64), ("gate", c_p), ("gate_stride", i64), ("rows_per_batch", i32),
-                ("vt", c_p), ("vt_col0", i32), ("vt_ld", i64)]
+                ("vt", c_p), ("vt_col0", i32), ("vt_ld", i64), ("qk_w0", c_p), ("qk_w1", c_p), ("qk_cols0", i32),
+                ("qk_cols1", i32)]
 
 
 class GaAttentionArgs(ctypes.Structure):
@@ -102,9 +103,11 @@ def _need_cuda(*ts):
             raise RuntimeError("gaussiananything_amd DiT ops only run on an MI355X (HIP) device; there is no CPU path")
 
 
-def gemm(A, W, bias=None, epilogue=EPI_STORE_BF16, out=None, gate=None, rows_per_batch=1, vt=None, vt_col0=0):
+def gemm(A, W, bias=None, epilogue=EPI_STORE_BF16, out=None, gate=None, rows_per_batch=1, vt=None, vt_col0=0,
+         qk_w0=None, qk_cols0=0, qk_w1=None, qk_cols1=0):
     """A [M,K] bf16, W [N,K] bf16 -> see ga_dit.h.  EPI_RESIDUAL accumulates into ``out`` (fp32 [M,N]).
-    ``vt`` [B*heads*64, Lpad] bf16 (zero-initialised): columns >= vt_col0 are stored transposed there (V projection)."""
+    ``vt`` [B*heads*64, Lpad] bf16 (zero-initialised): columns >= vt_col0 are stored transposed there (V projection).
+    ``qk_w0/qk_w1``: per-head RMSNorm weights for the column groups [0, qk_cols0) / [qk_cols0, qk_cols1)."""
     _need_cuda(A, W, bias, out, gate, vt)
     assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and A.stride(-1) == 1 and W.is_contiguous()
     M, K = A.shape
@@ -114,7 +117,7 @@ def gemm(A, W, bias=None, epilogue=EPI_STORE_BF16, out=None, gate=None, rows_per
                           dtype=torch.bfloat16 if epilogue in (EPI_STORE_BF16, EPI_GELU_BF16) else torch.float32)
     a = GaGemmArgs(M, N, K, epilogue, A.data_ptr(), A.stride(0), W.data_ptr(), _ptr(bias), out.data_ptr(), out.stride(0),
                    _ptr(gate), gate.stride(0) if gate is not None else 0, rows_per_batch, _ptr(vt), vt_col0,
-                   vt.stride(0) if vt is not None else 0)
+                   vt.stride(0) if vt is not None else 0, _ptr(qk_w0), _ptr(qk_w1), qk_cols0, max(qk_cols1, qk_cols0))
     check(lib().ga_gemm_bf16(ctypes.byref(a), _stream(A)), "ga_gemm_bf16")
     return out
 

@@ -59,6 +59,12 @@ typedef struct GaGemmArgs {
     ga_bf16 *vt;
     int32_t vt_col0;
     int64_t vt_ld;
+    /* EPI 0 only, optional: per-head RMSNorm (eps 1e-5, dit/norm.py:29-43) of the 64-wide column groups ("heads") of the
+     * result before the bf16 store -- columns [0, qk_cols0) with weight qk_w0[64], [qk_cols0, qk_cols1) with qk_w1[64]
+     * (multiples of 64; 0 = none).  This is the q_norm / k_norm of MemEffAttention / MemoryEfficientCrossAttention
+     * applied where the projection is produced instead of where it is consumed. */
+    const float *qk_w0, *qk_w1;
+    int32_t qk_cols0, qk_cols1;
 } GaGemmArgs;
 
 int ga_gemm_bf16(const GaGemmArgs *args, void *stream);

@@ -62,6 +62,24 @@ def test_gemm_transposed_v_store(gpu_device):
     assert float(vt[:, L:].abs().max()) == 0.0
 
 
+def test_gemm_fused_qk_rmsnorm(gpu_device):
+    """Per-head RMSNorm of the q and k column groups in the projection epilogue (dit/norm.py:29-43 semantics)."""
+    from gaussiananything_amd import dit_ops as ops
+    M, K, H = 200, 128, 3
+    D = H * 64
+    g = torch.Generator(device="cpu").manual_seed(21)
+    A = torch.randn(M, K, generator=g).to(gpu_device).bfloat16()
+    W = (torch.randn(3 * D, K, generator=g) / 11).to(gpu_device).bfloat16()
+    bias = torch.randn(3 * D, generator=g).to(gpu_device)
+    wq = (1 + 0.3 * torch.randn(64, generator=g)).to(gpu_device)
+    wk = (1 + 0.3 * torch.randn(64, generator=g)).to(gpu_device)
+    out = ops.gemm(A, W, bias, ops.EPI_STORE_BF16, qk_w0=wq, qk_cols0=D, qk_w1=wk, qk_cols1=2 * D)
+    ref = (A.float() @ W.float().T + bias).reshape(M, 3, H, 64)
+    nrm = lambda t, w: t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-5) * w  # noqa: E731
+    ref = torch.stack([nrm(ref[:, 0], wq), nrm(ref[:, 1], wk), ref[:, 2]], 1).reshape(M, 3 * D)
+    assert rel_l2(out.float(), ref) < 1e-2
+
+
 def test_gemm_is_transpose_sensitive(gpu_device):
     """A = I with an asymmetric W: a swapped row/column mapping in the epilogue cannot pass."""
     from gaussiananything_amd import dit_ops as ops
