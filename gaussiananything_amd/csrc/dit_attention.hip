@@ -7,8 +7,8 @@
 // is applied while the tiles are staged, and the softmax scale 64^-1/2.
 //
 // MI355X mapping (flash-style, one pass over the keys, online softmax in fp32):
-//   * grid (ceil(Lq/128), heads, batch); 4 waves per workgroup, each wave owns 32 query rows (two 16-row MFMA
-//     fragments, so every K / V fragment read from LDS feeds two MFMAs), the workgroup shares the staged K / V^T tiles
+//   * grid (ceil(Lq/128), heads, batch); 8 waves per workgroup, each wave owns 16 query rows; two waves share a SIMD
+//     so that one wave's softmax (VALU) overlaps the other's MFMAs; the workgroup shares the staged K / V^T tiles
 //     (64 keys) in LDS;
 //   * "swapped" products so that every reduction is lane-local or a 2-step lane shuffle: S^T = K Q^T puts one query
 //     in a lane (column lane&15) with 4 keys per accumulator fragment, and O^T = V^T P^T keeps that query in the same
@@ -26,24 +26,30 @@
 
 namespace gadit {
 
-constexpr int QB = 128, KB = 64, HD = 64;
+constexpr int KB = 64, HD = 64;
 constexpr int TILE = KB * HD;  // elements of one staged tile (8 KiB)
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ (row & 7)) * 8); }
 
-__global__ __launch_bounds__(256) void attention_fwd_kernel(GaAttentionArgs a)
+// NW waves per workgroup, QI 16-row query fragments per wave: query rows per workgroup = NW * QI * 16.
+// <8,1>: 8 waves x 16 rows -- two waves per SIMD, so one wave's softmax VALU work overlaps the other's MFMAs (PMC of the
+// <4,2> shape: one wave per SIMD, 58 % of its cycles spent issuing ~9 k instructions at the lone-wave rate of one per
+// ~4.5 cycles, MFMA pipe 7 % busy).
+template <int NW, int QI>
+__global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(GaAttentionArgs a)
 {
+    constexpr int QB = NW * QI * 16, NT = NW * 64, CPT = 512 / NT;  // chunks (16 B) per thread per staged tile
     __shared__ __attribute__((aligned(16))) uint16_t sK[2 * TILE];   // [buf][key][d]      (swizzled)
     __shared__ __attribute__((aligned(16))) uint16_t sV[2 * TILE];   // [buf][d][perm key] (swizzled)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB + wave * 32;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB + wave * (QI * 16);
     const int Lq = a.Lq, Lk = a.Lk;
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + qi*16 + c16][kk*32 + g*8 .. +7], normalised, scaled
-    bf16x8 qf[2][2];
+    bf16x8 qf[QI][2];
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
+    for (int qi = 0; qi < QI; ++qi) {
         const int row = min(q0 + qi * 16 + c16, Lq - 1);
         const uint16_t *qp = a.q + ((size_t)b * Lq + row) * a.q_stride + h * HD;
         float qv[16];
@@ -74,21 +80,23 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(GaAttentionArgs a)
             }
     }
 
-    f32x4 o[2][4];
+    f32x4 o[QI][4];
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi)
+    for (int qi = 0; qi < QI; ++qi)
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[qi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+    float m_run[QI], l_run[QI];
+#pragma unroll
+    for (int qi = 0; qi < QI; ++qi) { m_run[qi] = -1e30f; l_run[qi] = 0.f; }
 
     // ---- staging: K and V^T tiles are 512 16-byte chunks each, 2 per thread; chunk c -> row c>>3, part c&7
     const int ntiles = (Lk + KB - 1) / KB;
     const uint16_t *vt_base = a.vt + ((size_t)b * a.heads + h) * HD * a.vt_ld;
-    uint4 rk[2], rv[2];
+    uint4 rk[CPT], rv[CPT];
     auto issue = [&](int tile) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, part = c & 7;
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + NT * i, row = c >> 3, part = c & 7;
             const int key = min(tile * KB + row, Lk - 1);
             rk[i] = *reinterpret_cast<const uint4 *>(a.k + ((size_t)b * Lk + key) * a.k_stride + h * HD + part * 8);
             rv[i] = *reinterpret_cast<const uint4 *>(vt_base + (size_t)row * a.vt_ld + tile * KB + part * 8);
@@ -97,8 +105,8 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(GaAttentionArgs a)
     auto write_lds = [&](int buf) {
         uint16_t *dk = sK + buf * TILE, *dv = sV + buf * TILE;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, part = c & 7;
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + NT * i, row = c >> 3, part = c & 7;
             // K: RMS-normalise the row (8 consecutive lanes hold it)
             const uint32_t kw[4] = {rk[i].x, rk[i].y, rk[i].z, rk[i].w};
             uint4 pk = rk[i];
@@ -142,23 +150,24 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(GaAttentionArgs a)
         const uint16_t *bk = sK + cur * TILE, *bv = sV + cur * TILE;
 
         // ---- S^T = K Q^T : s[qi][kf][r] = S[key = kf*16 + g*4 + r][q = qi*16 + c16]
-        f32x4 s[2][4];
+        f32x4 s[QI][4];
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) {
-            s[0][kf] = f32x4{0.f, 0.f, 0.f, 0.f};
-            s[1][kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qi = 0; qi < QI; ++qi) s[qi][kf] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const bf16x8 kfrag = *reinterpret_cast<const bf16x8 *>(bk + swz(kf * 16 + c16, kk * 4 + g));
-                s[0][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[0][kk], s[0][kf], 0, 0, 0);
-                s[1][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[1][kk], s[1][kf], 0, 0, 0);
+#pragma unroll
+                for (int qi = 0; qi < QI; ++qi)
+                    s[qi][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[qi][kk], s[qi][kf], 0, 0, 0);
             }
         }
         const int kbase = tile * KB + g * 4;
         const bool tail = tile * KB + KB > Lk;
-        bf16x8 pf[2][2];
+        bf16x8 pf[QI][2];
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
+        for (int qi = 0; qi < QI; ++qi) {
             float tmax = -1e30f;
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
@@ -193,14 +202,15 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(GaAttentionArgs a)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 const bf16x8 vfrag = *reinterpret_cast<const bf16x8 *>(bv + swz(df * 16 + c16, kb * 4 + g));
-                o[0][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pf[0][kb], o[0][df], 0, 0, 0);
-                o[1][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pf[1][kb], o[1][df], 0, 0, 0);
+#pragma unroll
+                for (int qi = 0; qi < QI; ++qi)
+                    o[qi][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pf[qi][kb], o[qi][df], 0, 0, 0);
             }
         __syncthreads();
     }
 
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
+    for (int qi = 0; qi < QI; ++qi) {
         float l = l_run[qi];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
@@ -228,7 +238,8 @@ extern "C" int ga_attention_bf16(const GaAttentionArgs *a, void *stream)
         a->vt_ld < ((a->Lk + KB - 1) / KB) * KB || a->out_stride % 4)
         return GA_DIT_ERR_BAD_SHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    constexpr int QB = 128;  // 8 waves x 16 rows
     const dim3 grid((a->Lq + QB - 1) / QB, a->heads, a->batch);
-    hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(256), 0, s, *a);
+    hipLaunchKernelGGL((attention_fwd_kernel<8, 1>), grid, dim3(512), 0, s, *a);
     return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
 }
