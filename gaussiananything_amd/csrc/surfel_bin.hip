@@ -257,7 +257,10 @@ __global__ __launch_bounds__(256) void surfel_run_sort_kernel(const uint32_t *__
     }
 }
 
-// Rank merge of the sorted runs of a long list (keys unique inside a tile => ranks are a permutation).
+// Rank merge of the sorted runs of a long list (keys unique inside a tile => ranks are a permutation).  Every other run
+// is first copied into LDS (coalesced), then each thread binary-searches its 8 keys in it with the 8 searches
+// interleaved: the first version chased 8 x 22 dependent L2 loads per thread, one after the other (34 us for a
+// handful of lists, profiles/r1b_*).
 __global__ __launch_bounds__(256) void surfel_run_merge_kernel(const uint32_t *__restrict__ tile_start,
                                                                const uint32_t *__restrict__ tile_order,
                                                                const uint32_t *__restrict__ run_table,
@@ -265,6 +268,7 @@ __global__ __launch_bounds__(256) void surfel_run_merge_kernel(const uint32_t *_
                                                                uint32_t *__restrict__ point_list,
                                                                const int64_t *__restrict__ status)
 {
+    __shared__ __attribute__((aligned(16))) uint64_t other[kSortCap];
     if (status[GA_STATUS_OVERFLOW]) return;
     uint32_t tile, run;
     if (!sort_block_assignment(tile_order, run_table, status, max_extra, tile, run)) return;
@@ -274,20 +278,40 @@ __global__ __launch_bounds__(256) void surfel_run_merge_kernel(const uint32_t *_
     const int nruns = (n + kSortCap - 1) / kSortCap;
     const int rb = (int)run * kSortCap, rn = min(kSortCap, n - rb);
     const uint64_t *k = keys + beg;
-    for (int e = threadIdx.x; e < rn; e += 256) {
-        const uint64_t key = k[rb + e];
-        int rank = e;
-        for (int r = 0; r < nruns; ++r) {
-            if (r == (int)run) continue;
-            const int ob = r * kSortCap, on = min(kSortCap, n - ob);
-            int lo = 0, hi = on;  // lower_bound
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (k[ob + mid] < key) lo = mid + 1; else hi = mid;
+    constexpr int kPer = kSortCap / 256;  // keys of my run per thread
+    uint64_t mine[kPer];
+    int rank[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        mine[i] = e < rn ? k[rb + e] : ~0ull;
+        rank[i] = e;
+    }
+    for (int r = 0; r < nruns; ++r) {
+        if (r == (int)run) continue;
+        const int ob = r * kSortCap, on = min(kSortCap, n - ob);
+        __syncthreads();
+        for (int t = threadIdx.x; t < on; t += 256) other[t] = k[ob + t];
+        __syncthreads();
+        int lo[kPer], hi[kPer];
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) { lo[i] = 0; hi[i] = on; }
+        for (int step = 0; step < 12; ++step) {  // 2^11 = kSortCap: 12 halvings reach lo == hi
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                if (lo[i] < hi[i]) {
+                    const int mid = (lo[i] + hi[i]) >> 1;
+                    if (other[mid] < mine[i]) lo[i] = mid + 1; else hi[i] = mid;
+                }
             }
-            rank += lo;
         }
-        point_list[beg + rank] = (uint32_t)key;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) rank[i] += lo[i];
+    }
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        if (e < rn) point_list[beg + rank[i]] = (uint32_t)mine[i];
     }
 }
 
