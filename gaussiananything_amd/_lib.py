@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libga_mi355.so")
 
 GA_OK = 0
-GA_STATUS_NUM_RENDERED, GA_STATUS_OVERFLOW, GA_STATUS_MAX_TILE, GA_STATUS_WORDS = 0, 1, 2, 8
+GA_STATUS_NUM_RENDERED, GA_STATUS_OVERFLOW, GA_STATUS_MAX_TILE, GA_STATUS_WORDS = 0, 1, 2, 16
 GA_SURFEL_RECORD_FLOATS = 24
 GA_SURFEL_STAGE_EVENTS = 5
 _ERR = {-1: "GA_ERR_NULL_ARG", -2: "GA_ERR_BAD_SHAPE", -3: "GA_ERR_WORKSPACE", -4: "GA_ERR_LAUNCH"}

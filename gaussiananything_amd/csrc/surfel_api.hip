@@ -1,5 +1,7 @@
 // surfel_api.hip -- C-ABI entry points of the surfel rasterizer (declared in include/ga_surfel.h).
 // Host-side only: argument validation, workspace carving, and the launch sequence on the caller's stream.
+#include <stdlib.h>
+
 #include "surfel_common.h"
 
 namespace {
@@ -21,6 +23,18 @@ bool make_dims(int32_t N, int32_t V, int32_t H, int32_t W, ga::Dims *d)
 }
 
 }  // namespace
+
+namespace ga {
+int long_list()
+{
+    static const int v = [] {
+        const char *e = getenv("GA_LONG_LOG2");
+        const int l = e ? atoi(e) : 0;
+        return (l >= 6 && l <= 30) ? (1 << l) : kLongList;
+    }();
+    return v;
+}
+}  // namespace ga
 
 extern "C" {
 

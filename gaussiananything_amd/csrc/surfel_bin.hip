@@ -30,7 +30,7 @@ __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(const uint32_t *
                                                                 uint32_t *__restrict__ tile_cursor,
                                                                 uint32_t *__restrict__ tile_order,
                                                                 uint32_t *__restrict__ run_table, int n,
-                                                                int64_t capacity, int64_t *__restrict__ status)
+                                                                int64_t capacity, int long_bucket, int64_t *__restrict__ status)
 {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry_s;
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(const uint32_t *
             bucket[b] = run;
             run += c;
             if (b == kBigBucket) nbig_s = run;
+            if (b == long_bucket) status[GA_STATUS_LONG_TILES] = (int64_t)run;
         }
     }
     __syncthreads();
@@ -319,7 +320,8 @@ void launch_binning(const GaSurfelForwardArgs &a, const Dims &d, const Workspace
 {
     const int nt = d.V * d.tiles;
     hipLaunchKernelGGL(surfel_tile_scan_kernel, dim3(1), dim3(1024), 0, s, ws.tile_count, ws.tile_start,
-                       ws.tile_cursor, ws.tile_order, ws.run_table, nt, a.capacity, ws.status);
+                       ws.tile_cursor, ws.tile_order, ws.run_table, nt, a.capacity,
+                       32 - __builtin_clz((unsigned)long_list()), ws.status);  // classes >= this hold the long lists
     const dim3 grid((unsigned)((d.N + 256 * kBinSplats - 1) / (256 * kBinSplats)), (unsigned)d.V);
     if (d.tiles <= kLdsTiles)
         hipLaunchKernelGGL(surfel_fill_kernel<true>, grid, dim3(256), 2 * d.tiles * sizeof(uint32_t), s, ws.rect,

@@ -23,6 +23,8 @@ constexpr float kFilterInvSquare = 2.0f;
 
 constexpr int kBinSplats = 8;           // splats per thread in the preprocess / fill kernels (2048 per workgroup)
 constexpr int kLdsTiles = 8192;         // per-view tile counters aggregated in LDS up to this many tiles (32 KiB)
+constexpr int kLongList = 1024;          // lists of >= this many pairs (a power of two) are blended four segments at a time
+int long_list();                         // kLongList, or 2^GA_LONG_LOG2 from the environment (tuning aid)
 constexpr int kSortCap = GA_SURFEL_SORT_RUN;         // per-tile entries sorted in one LDS pass (16 KiB of u64 keys: 8+ workgroups per CU)
 
 struct Dims {

@@ -42,7 +42,9 @@ extern "C" {
 #define GA_STATUS_BLEND_ITERS 4   /* with GA_SURFEL_FLAG_STATS: total inner-loop iterations of the blend (all waves) */
 #define GA_STATUS_BLEND_MAX_ITERS 5 /* with GA_SURFEL_FLAG_STATS: most iterations executed by one wave              */
 #define GA_STATUS_BLEND_CHUNKS 6  /* with GA_SURFEL_FLAG_STATS: total 64-entry chunks consumed                          */
-#define GA_STATUS_WORDS 8
+#define GA_STATUS_LONG_TILES 7    /* tiles whose list is blended in segments (internal)                                */
+#define GA_STATUS_BLEND_LANE_SLOTS 8 /* with GA_SURFEL_FLAG_STATS: (pixel, pair) evaluations that had work (of 64 x BLEND_ITERS) */
+#define GA_STATUS_WORDS 16
 
 typedef struct GaSurfelForwardArgs {
     int32_t num_points;      /* N Gaussians                                                       */

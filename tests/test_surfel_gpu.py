@@ -98,6 +98,23 @@ def test_long_tile_lists_take_the_run_merge_path(gpu_device):
     assert art["max_tile"] > 8192
 
 
+def test_segmented_blend_of_transparent_long_lists(gpu_device):
+    """Lists >= 1024 pairs are blended four segments at a time (transmittance pre-pass, ordered merge with the
+    distortion cross terms).  Nearly transparent splats keep every segment alive down to the last pair, so colour,
+    depth, median depth and distortion all cross the segment seams; an opaque variant stops inside the first segment."""
+    cams = synthetic.eval_cameras(8)
+    for lo, hi in ((0.005, 0.02), (0.3, 1.0)):
+        g = synthetic.random_surfels(6000, seed=13)[0].clone()
+        g[:, 0:3] *= 0.05
+        g[:, 3] = lo + (hi - lo) * torch.rand(6000, generator=torch.Generator().manual_seed(3))
+        art = _run_case(g, cams, [0, 5], 64, 64, gpu_device)
+        assert art["max_tile"] >= 1024
+        if lo < 0.1:
+            _, _, allmap, _ = _util.hip_views(g, cams, [0], 64, 64, gpu_device)
+            alpha = allmap[0, 1].cpu().numpy()
+            assert 0.2 < float(alpha.max()) < 0.9999, "scene should stay short of the stop rule"
+
+
 def test_degenerate_inputs(gpu_device):
     """behind-camera, zero-scale, zero / tiny opacity, duplicate depths (tie-break by index), edge-on splats."""
     cams = synthetic.eval_cameras(8)
