@@ -24,7 +24,18 @@
 namespace ga {
 
 // ---------------------------------------------------------------------------------------------------------------
-// 2. exclusive scan of the per-(view, tile) counters; single workgroup of 1024 threads, wave-shuffle scans.
+// 2. exclusive scan of the per-(view, tile) counters + the workgroup schedule of the per-tile kernels.
+// A single workgroup of 1024 threads: everything here is latency, not throughput, so the kernel is organised to keep
+// the dependent steps few -- counters are loaded 8 per thread at once into registers (chunks of 8192 = 8 views of
+// 512 x 512), the eight wave scans of a chunk run back to back, the 128 wave totals are scanned by one wave, length
+// classes are counted in wave-private LDS histograms (no contended atomics, no returned values) and ranks inside a
+// class come from one returning LDS atomic per element on the wave's own histogram.
+__device__ __forceinline__ int length_class(uint32_t c) { return c ? 32 - __builtin_clz(c) : 0; }  // 2^(b-1) <= c < 2^b
+
+constexpr int kScanPer = 8;         // counters per thread and chunk
+constexpr int kClasses = 33;
+constexpr int kBigStash = 1024;     // (tile, count) of the lists longer than one sort run kept in LDS for the run table
+
 __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(const uint32_t *__restrict__ tile_count,
                                                                 uint32_t *__restrict__ tile_start,
                                                                 uint32_t *__restrict__ tile_cursor,
@@ -32,89 +43,164 @@ __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(const uint32_t *
                                                                 uint32_t *__restrict__ run_table, int n,
                                                                 int64_t capacity, int long_bucket, int64_t *__restrict__ status)
 {
+    __shared__ uint32_t wt[kScanPer * 16], wt_ex[kScanPer * 16];
+    __shared__ uint32_t hist[16][kClasses];       // wave-private class counts, later wave-private rank counters
+    __shared__ uint32_t wave_off[16][kClasses];   // class start + population of the lower waves
+    __shared__ uint32_t class_start[kClasses + 1];
     __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t carry_s;
-    __shared__ uint32_t maxc_s;
     __shared__ uint64_t wide_tot[16];
-    __shared__ uint32_t bucket[33];
-    __shared__ uint32_t nbig_s;
+    __shared__ uint32_t wave_max[16];
+    __shared__ uint32_t carry_s, nbig_s;
+    __shared__ uint32_t big_tile[kBigStash], big_cnt[kBigStash];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) { carry_s = 0; maxc_s = 0; }
-    if (tid < 33) bucket[tid] = 0;
+    for (int i = tid; i < 16 * kClasses; i += 1024) (&hist[0][0])[i] = 0;
+    if (tid == 0) carry_s = 0;
     __syncthreads();
+
+    const int nchunk = (n + kScanPer * 1024 - 1) / (kScanPer * 1024);
+    uint32_t cnt[kScanPer];      // the (last) chunk stays in registers for the second phase
     uint32_t local_max = 0;
     uint64_t local_sum = 0;
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + tid;
-        const uint32_t c = i < n ? tile_count[i] : 0u;
-        local_max = max(local_max, c);
-        local_sum += c;
-        if (i < n) atomicAdd(&bucket[c ? 32 - __builtin_clz(c) : 0], 1u);  // bucket b: 2^(b-1) <= c < 2^b
-        uint32_t x = c;  // inclusive scan inside the wave
+    // ---- phase A: tile_start / tile_cursor and the class histogram ------------------------------------------------
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int cbase = ch * kScanPer * 1024;
+#pragma unroll
+        for (int k = 0; k < kScanPer; ++k) {
+            const int i = cbase + k * 1024 + tid;
+            cnt[k] = i < n ? tile_count[i] : 0u;
+        }
+        uint32_t x[kScanPer];
+#pragma unroll
+        for (int k = 0; k < kScanPer; ++k) {
+            local_max = max(local_max, cnt[k]);
+            local_sum += cnt[k];
+            if (cbase + k * 1024 + tid < n) atomicAdd(&hist[wid][length_class(cnt[k])], 1u);
+            x[k] = cnt[k];  // inclusive scan inside the wave
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_up(x[k], o, 64);
+                if (lane >= o) x[k] += y;
+            }
+            if (lane == 63) wt[k * 16 + wid] = x[k];
+        }
+        __syncthreads();
+        if (wid == 0) {  // exclusive scan of the 128 wave totals, two per lane, on top of the carry of earlier chunks
+            const uint32_t v0 = wt[2 * lane], v1 = wt[2 * lane + 1];
+            uint32_t sx = v0 + v1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_up(sx, o, 64);
+                if (lane >= o) sx += y;
+            }
+            const uint32_t carry = carry_s;
+            wt_ex[2 * lane] = carry + sx - v0 - v1;
+            wt_ex[2 * lane + 1] = carry + sx - v1;
+            if (lane == 63) carry_s = carry + sx;  // read by everyone only after the next barrier
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kScanPer; ++k) {
+            const int i = cbase + k * 1024 + tid;
+            const uint32_t excl = wt_ex[k * 16 + wid] + x[k] - cnt[k];
+            if (i < n) { tile_start[i] = excl; tile_cursor[i] = excl; }
+        }
+    }
+    // ---- totals (64-bit: the uint32 running offsets above wrap past 2^32; that case is reported as overflow) -------
+    {
+        uint64_t wsum = local_sum;
+        uint32_t wmax = local_max;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            wsum += __shfl_down(wsum, o, 64);
+            wmax = max(wmax, (uint32_t)__shfl_down(wmax, o, 64));
+        }
+        if (lane == 0) { wide_tot[wid] = wsum; wave_max[wid] = wmax; }
+    }
+    __syncthreads();
+    // class populations -> class starts, longest lists first (wave 0: lane b owns class 32 - b)
+    if (wid == 0) {
+        const int b = 32 - lane;
+        uint32_t pop = 0;
+        if (lane < kClasses)
+            for (int w = 0; w < 16; ++w) pop += hist[w][b];
+        uint32_t sx = pop;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t y = __shfl_up(x, o, 64);
-            if (lane >= o) x += y;
+            const uint32_t y = __shfl_up(sx, o, 64);
+            if (lane >= o) sx += y;
         }
-        if (lane == 63) wave_tot[wid] = x;
-        __syncthreads();
-        uint32_t wbase = 0;
-        for (int w = 0; w < wid; ++w) wbase += wave_tot[w];
-        const uint32_t carry = carry_s;
-        const uint32_t excl = carry + wbase + x - c;
-        if (i < n) { tile_start[i] = excl; tile_cursor[i] = excl; }
-        __syncthreads();
-        if (tid == 1023) carry_s = carry + wbase + x;
-        __syncthreads();
-    }
-    // 64-bit total (the uint32 running offsets above wrap past 2^32; that case is reported as overflow).
-    atomicMax(&maxc_s, local_max);
-    uint64_t wsum = local_sum;
+        if (lane < kClasses) {
+            class_start[b] = sx - pop;
+            // every list longer than one sort run lives in a class >= kBigBucket; lists >= the long-list bound (a power
+            // of two) in a class >= long_bucket: remember where those classes end
+            constexpr int kBigBucket = 32 - __builtin_clz((unsigned)kSortCap + 1u);
+            if (b == kBigBucket) nbig_s = sx;
+            if (b == long_bucket) status[GA_STATUS_LONG_TILES] = (int64_t)sx;
+        }
+        uint64_t total = lane < 16 ? wide_tot[lane] : 0ull;
+        uint32_t mx = lane < 16 ? wave_max[lane] : 0u;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wsum += __shfl_down(wsum, o, 64);
-    if (lane == 0) wide_tot[wid] = wsum;
-    __syncthreads();
-    if (tid == 0) {
-        uint64_t total = 0;
-        for (int w = 0; w < 16; ++w) total += wide_tot[w];
-        tile_start[n] = (uint32_t)total;
-        status[GA_STATUS_NUM_RENDERED] = (int64_t)total;
-        status[GA_STATUS_OVERFLOW] = (total > (uint64_t)capacity || total > 0xFFFFFFFFull) ? 1 : 0;
-        status[GA_STATUS_MAX_TILE] = (int64_t)maxc_s;
-        // bucket start offsets, longest lists first
-        uint32_t run = 0;
-        // every list longer than one sort run lives in a length class >= kBigBucket: remember where those end
-        constexpr int kBigBucket = 32 - __builtin_clz((unsigned)kSortCap + 1u);
-        for (int b = 32; b >= 0; --b) {
-            const uint32_t c = bucket[b];
-            bucket[b] = run;
-            run += c;
-            if (b == kBigBucket) nbig_s = run;
-            if (b == long_bucket) status[GA_STATUS_LONG_TILES] = (int64_t)run;
+        for (int o = 8; o > 0; o >>= 1) {
+            total += __shfl_down(total, o, 64);
+            mx = max(mx, (uint32_t)__shfl_down(mx, o, 64));
+        }
+        if (lane == 0) {
+            tile_start[n] = (uint32_t)total;
+            status[GA_STATUS_NUM_RENDERED] = (int64_t)total;
+            status[GA_STATUS_OVERFLOW] = (total > (uint64_t)capacity || total > 0xFFFFFFFFull) ? 1 : 0;
+            status[GA_STATUS_MAX_TILE] = (int64_t)mx;
         }
     }
     __syncthreads();
-    // Workgroup schedule for the per-tile kernels: tiles ordered by list length class, longest first, so the long
-    // serial chains start at once and the short ones fill in behind them (order inside a class is irrelevant).
-    for (int i = tid; i < n; i += 1024) {
-        const uint32_t c = tile_count[i];
-        const uint32_t pos = atomicAdd(&bucket[c ? 32 - __builtin_clz(c) : 0], 1u);
-        tile_order[pos] = (uint32_t)i;
+    for (int i = tid; i < 16 * kClasses; i += 1024) {  // (wave, class): start of the class + population of lower waves
+        const int w = i / kClasses, b = i - w * kClasses;
+        uint32_t off = class_start[b];
+        for (int w2 = 0; w2 < w; ++w2) off += hist[w2][b];
+        wave_off[w][b] = off;
     }
-    // Run table of the per-tile sort: run 0 of every tile is implicit; list the runs 1.. of the long lists (they sit
-    // at the front of tile_order) as (tile, run) pairs so that each gets its own workgroup.
-    __threadfence();
+    __syncthreads();
+    for (int i = tid; i < 16 * kClasses; i += 1024) (&hist[0][0])[i] = 0;  // now the per-wave rank counters
+    __syncthreads();
+    // ---- phase B: workgroup schedule of the per-tile kernels: tiles ordered by length class, longest first, so the
+    // long serial chains start at once and the short ones fill in behind them (order inside a class is irrelevant) ---
+    const uint32_t nbig = nbig_s;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int cbase = ch * kScanPer * 1024;
+        if (nchunk > 1) {
+#pragma unroll
+            for (int k = 0; k < kScanPer; ++k) {
+                const int i = cbase + k * 1024 + tid;
+                cnt[k] = i < n ? tile_count[i] : 0u;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kScanPer; ++k) {
+            const int i = cbase + k * 1024 + tid;
+            if (i < n) {
+                const int b = length_class(cnt[k]);
+                const uint32_t pos = wave_off[wid][b] + atomicAdd(&hist[wid][b], 1u);
+                tile_order[pos] = (uint32_t)i;
+                if (pos < nbig && pos < (uint32_t)kBigStash) { big_tile[pos] = (uint32_t)i; big_cnt[pos] = cnt[k]; }
+            }
+        }
+    }
+    // ---- run table of the per-tile sort: run 0 of every tile is implicit; list the runs 1.. of the lists longer than
+    // one sort run (they sit at the front of tile_order) as (tile, run) pairs so that each gets its own workgroup -------
+    if (nbig > (uint32_t)kBigStash) __threadfence();  // the overflow of the stash is re-read from tile_order
     __syncthreads();
     if (tid == 0) carry_s = 0;
     __syncthreads();
     const uint32_t table_cap = (uint32_t)(capacity / kSortCap + 1);
-    const int nbig = (int)nbig_s;
-    for (int base = 0; base < nbig; base += 1024) {
-        const int p = base + tid;
+    for (uint32_t base = 0; base < nbig; base += 1024) {
+        const uint32_t p = base + tid;
         uint32_t t = 0, extra = 0;
         if (p < nbig) {
-            t = __hip_atomic_load(tile_order + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t c = tile_count[t];
+            uint32_t c;
+            if (p < (uint32_t)kBigStash) { t = big_tile[p]; c = big_cnt[p]; }
+            else {
+                t = __hip_atomic_load(tile_order + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                c = tile_count[t];
+            }
             extra = c > (uint32_t)kSortCap ? (c - 1) / kSortCap : 0;
         }
         uint32_t x = extra;

@@ -76,6 +76,14 @@ def test_ragged_image_sizes(gpu_device, H, W):
     _run_case(g, cams, [1, 5], H, W, gpu_device)
 
 
+def test_more_than_8192_tiles_take_the_chunked_scan(gpu_device):
+    """3 views of 1024 x 1024 = 12 288 (view, tile) counters: beyond the single-pass register scan of the tile-scan
+    kernel (and beyond the per-view LDS histograms of preprocess / fill at 4096 tiles? no: those hold 8192)."""
+    cams = synthetic.eval_cameras(8)
+    g = synthetic.random_surfels(1500, seed=21)[0]
+    _run_case(g, cams, [1, 4, 6], 1024, 1024, gpu_device)
+
+
 def test_multi_view_batch_equals_oracle_per_view(gpu_device):
     cams = synthetic.eval_cameras(8)
     g = synthetic.random_surfels(20000, seed=5)[0]
