@@ -54,8 +54,8 @@ int ga_surfel_workspace_layout(int32_t num_points, int32_t num_views, int32_t im
     out->tile_count = off;  off += align256(nt * 4);
     out->tile_start = off;  off += align256((nt + 1) * 4);
     out->tile_cursor = off; off += align256(nt * 4);
-    out->tile_order = off;  off += align256(nt * 4);
-    out->run_table = off;   off += align256((cap / GA_SURFEL_SORT_RUN + 1) * 8);
+    out->tile_order = off;  off += align256(nt * 16);   /* uint4 (tile, begin, length, 0) per schedule slot */
+    out->run_table = off;   off += align256((cap / GA_SURFEL_SORT_RUN + 1) * 16);  /* uint4 (tile, run, begin, length) */
     out->rect = off;        off += align256(nv * 4 * sizeof(uint16_t));
     out->depth = off;       off += align256(nv * 4);
     out->bbox = off;        off += align256(nv * 16);
@@ -88,8 +88,8 @@ int ga_surfel_forward(const GaSurfelForwardArgs *a, void *stream_v)
     ws.tile_count = reinterpret_cast<uint32_t *>(w + L.tile_count);
     ws.tile_start = reinterpret_cast<uint32_t *>(w + L.tile_start);
     ws.tile_cursor = reinterpret_cast<uint32_t *>(w + L.tile_cursor);
-    ws.tile_order = reinterpret_cast<uint32_t *>(w + L.tile_order);
-    ws.run_table = reinterpret_cast<uint32_t *>(w + L.run_table);
+    ws.tile_order = reinterpret_cast<uint4 *>(w + L.tile_order);
+    ws.run_table = reinterpret_cast<uint4 *>(w + L.run_table);
     ws.rect = reinterpret_cast<uint16_t *>(w + L.rect);
     ws.depth = reinterpret_cast<float *>(w + L.depth);
     ws.bbox = reinterpret_cast<float *>(w + L.bbox);

@@ -39,8 +39,8 @@ constexpr int kBigStash = 1024;     // (tile, count) of the lists longer than on
 __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(const uint32_t *__restrict__ tile_count,
                                                                 uint32_t *__restrict__ tile_start,
                                                                 uint32_t *__restrict__ tile_cursor,
-                                                                uint32_t *__restrict__ tile_order,
-                                                                uint32_t *__restrict__ run_table, int n,
+                                                                uint4 *__restrict__ tile_order,
+                                                                uint4 *__restrict__ run_table, int n,
                                                                 int64_t capacity, int long_bucket, int64_t *__restrict__ status)
 {
     __shared__ uint32_t wt[kScanPer * 16], wt_ex[kScanPer * 16];
@@ -51,14 +51,14 @@ __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(const uint32_t *
     __shared__ uint64_t wide_tot[16];
     __shared__ uint32_t wave_max[16];
     __shared__ uint32_t carry_s, nbig_s;
-    __shared__ uint32_t big_tile[kBigStash], big_cnt[kBigStash];
+    __shared__ uint32_t big_tile[kBigStash], big_cnt[kBigStash], big_beg[kBigStash];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < 16 * kClasses; i += 1024) (&hist[0][0])[i] = 0;
     if (tid == 0) carry_s = 0;
     __syncthreads();
 
     const int nchunk = (n + kScanPer * 1024 - 1) / (kScanPer * 1024);
-    uint32_t cnt[kScanPer];      // the (last) chunk stays in registers for the second phase
+    uint32_t cnt[kScanPer], ex[kScanPer];  // the (last) chunk stays in registers for the second phase
     uint32_t local_max = 0;
     uint64_t local_sum = 0;
     // ---- phase A: tile_start / tile_cursor and the class histogram ------------------------------------------------
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(const uint32_t *
 #pragma unroll
         for (int k = 0; k < kScanPer; ++k) {
             const int i = cbase + k * 1024 + tid;
-            const uint32_t excl = wt_ex[k * 16 + wid] + x[k] - cnt[k];
-            if (i < n) { tile_start[i] = excl; tile_cursor[i] = excl; }
+            ex[k] = wt_ex[k * 16 + wid] + x[k] - cnt[k];
+            if (i < n) { tile_start[i] = ex[k]; tile_cursor[i] = ex[k]; }
         }
     }
     // ---- totals (64-bit: the uint32 running offsets above wrap past 2^32; that case is reported as overflow) -------
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(const uint32_t *
             for (int k = 0; k < kScanPer; ++k) {
                 const int i = cbase + k * 1024 + tid;
                 cnt[k] = i < n ? tile_count[i] : 0u;
+                ex[k] = i < n ? tile_start[i] : 0u;  // written by this thread in phase A
             }
         }
 #pragma unroll
@@ -179,8 +180,8 @@ __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(const uint32_t *
             if (i < n) {
                 const int b = length_class(cnt[k]);
                 const uint32_t pos = wave_off[wid][b] + atomicAdd(&hist[wid][b], 1u);
-                tile_order[pos] = (uint32_t)i;
-                if (pos < nbig && pos < (uint32_t)kBigStash) { big_tile[pos] = (uint32_t)i; big_cnt[pos] = cnt[k]; }
+                tile_order[pos] = make_uint4((uint32_t)i, ex[k], cnt[k], 0u);
+                if (pos < nbig && pos < (uint32_t)kBigStash) { big_tile[pos] = (uint32_t)i; big_cnt[pos] = cnt[k]; big_beg[pos] = ex[k]; }
             }
         }
     }
@@ -193,13 +194,14 @@ __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(const uint32_t *
     const uint32_t table_cap = (uint32_t)(capacity / kSortCap + 1);
     for (uint32_t base = 0; base < nbig; base += 1024) {
         const uint32_t p = base + tid;
-        uint32_t t = 0, extra = 0;
+        uint32_t t = 0, extra = 0, c = 0, tb = 0;
         if (p < nbig) {
-            uint32_t c;
-            if (p < (uint32_t)kBigStash) { t = big_tile[p]; c = big_cnt[p]; }
+            if (p < (uint32_t)kBigStash) { t = big_tile[p]; c = big_cnt[p]; tb = big_beg[p]; }
             else {
-                t = __hip_atomic_load(tile_order + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                c = tile_count[t];
+                const uint32_t *rec = reinterpret_cast<const uint32_t *>(tile_order + p);
+                t = __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tb = __hip_atomic_load(rec + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                c = __hip_atomic_load(rec + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             extra = c > (uint32_t)kSortCap ? (c - 1) / kSortCap : 0;
         }
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(const uint32_t *
         const uint32_t carry = carry_s;
         uint32_t dst = carry + wbase + x - extra;
         for (uint32_t r = 1; r <= extra; ++r, ++dst)
-            if (dst < table_cap) { run_table[2 * dst] = t; run_table[2 * dst + 1] = r; }
+            if (dst < table_cap) run_table[dst] = make_uint4(t, r, tb, c);
         __syncthreads();
         if (tid == 1023) carry_s = carry + wbase + x;
         __syncthreads();
@@ -281,54 +283,68 @@ __global__ __launch_bounds__(256) void surfel_fill_kernel(const uint16_t *__rest
 
 // ---------------------------------------------------------------------------------------------------------------
 // 4. per-tile sort.  LDS bitonic network on u64 keys, padded with ~0 to the next power of two.
-__device__ __forceinline__ void bitonic_sort_lds(uint64_t *s, int np, int tid, int nthreads)
+// Thread t of a stage with stride j handles the pair (i, i|j), i = ((t & ~(j-1)) << 1) | (t & (j-1)).  For j <= 64 the 64
+// threads of a wave touch exactly the 128 elements [128*(t/64), +128): those stages need no workgroup barrier (LDS
+// operations of one wave execute in order), only the stages with j >= 128 do -- 10 of the 66 stages of a 2048-key run,
+// 1 of the 36 stages of a 256-key list.
+__device__ __forceinline__ void bitonic_exchange(uint64_t *s, int t, int j, int k)
 {
-    for (int k = 2; k <= np; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (np >> 1); t += nthreads) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int p = i | j;
-                const uint64_t a = s[i], b = s[p];
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) { s[i] = b; s[p] = a; }
-            }
-            __syncthreads();
-        }
-    }
+    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+    const int p = i | j;
+    const uint64_t a = s[i], b = s[p];
+    const bool up = (i & k) == 0;
+    if ((a > b) == up) { s[i] = b; s[p] = a; }
 }
 
-// Workgroup -> (tile, run).  The first `max_extra` workgroups take the runs 1.. of the long lists from the run table
-// (so the long lists start first), the rest take run 0 of tile_order[...].
-__device__ __forceinline__ bool sort_block_assignment(const uint32_t *__restrict__ tile_order,
-                                                      const uint32_t *__restrict__ run_table,
-                                                      const int64_t *__restrict__ status, uint32_t max_extra,
-                                                      uint32_t &tile, uint32_t &run)
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t *s, int np, int tid, int nthreads)
 {
-    const uint32_t b = blockIdx.x;
-    if (b < max_extra) {
-        if ((int64_t)b >= status[GA_STATUS_EXTRA_RUNS]) return false;
-        tile = run_table[2 * b];
-        run = run_table[2 * b + 1];
-    } else {
-        tile = tile_order[b - max_extra];
-        run = 0;
+    const int half = np >> 1;
+    for (int k = 2; k <= np; k <<= 1) {
+        int j = k >> 1;
+        for (; j >= 128; j >>= 1) {
+            for (int t = tid; t < half; t += nthreads) bitonic_exchange(s, t, j, k);
+            __syncthreads();
+        }
+        for (int t = tid; t < half; t += nthreads) {  // one 128-element block per wave and pass: all its low stages
+            for (int jj = j; jj > 0; jj >>= 1) {
+                bitonic_exchange(s, t, jj, k);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (k >= 128) __syncthreads();  // the next k starts with j = k >= 128 (or the caller reads the result)
     }
+    if (np < 128) __syncthreads();
+}
+
+// Workgroup -> (run, list begin, list length): one 16-byte load.  The first `max_extra` workgroups take the runs 1.. of
+// the long lists from the run table (so the long lists start first), the rest take run 0 of schedule slot b - max_extra.
+// The status words are read together with it (independent loads, one latency).
+__device__ __forceinline__ bool sort_block_assignment(const uint4 *__restrict__ tile_order,
+                                                      const uint4 *__restrict__ run_table,
+                                                      const int64_t *__restrict__ status, uint32_t max_extra,
+                                                      uint32_t b, uint32_t &run, uint32_t &beg, int &n)
+{
+    const bool extra = b < max_extra;
+    const uint4 rec = extra ? run_table[b] : tile_order[b - max_extra];
+    const int64_t overflow = status[GA_STATUS_OVERFLOW], extra_runs = status[GA_STATUS_EXTRA_RUNS];
+    if (overflow || (extra && (int64_t)b >= extra_runs)) return false;
+    run = extra ? rec.y : 0u;
+    beg = extra ? rec.z : rec.y;
+    n = (int)(extra ? rec.w : rec.z);
     return true;
 }
 
-__global__ __launch_bounds__(256) void surfel_run_sort_kernel(const uint32_t *__restrict__ tile_start,
-                                                              const uint32_t *__restrict__ tile_order,
-                                                              const uint32_t *__restrict__ run_table,
+__global__ __launch_bounds__(256) void surfel_run_sort_kernel(const uint4 *__restrict__ tile_order,
+                                                              const uint4 *__restrict__ run_table,
                                                               uint32_t max_extra, uint64_t *__restrict__ keys,
                                                               uint32_t *__restrict__ point_list,
                                                               const int64_t *__restrict__ status)
 {
     __shared__ __attribute__((aligned(16))) uint64_t s[kSortCap];
-    if (status[GA_STATUS_OVERFLOW]) return;
-    uint32_t tile, run;
-    if (!sort_block_assignment(tile_order, run_table, status, max_extra, tile, run)) return;
-    const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
-    const int n = (int)(end - beg);
+    uint32_t run, beg;
+    int n;
+    if (!sort_block_assignment(tile_order, run_table, status, max_extra, blockIdx.x, run, beg, n)) return;
     if (n <= 0) return;
     const int tid = threadIdx.x;
     if (n == 1) { if (tid == 0) point_list[beg] = (uint32_t)keys[beg]; return; }
@@ -344,60 +360,85 @@ __global__ __launch_bounds__(256) void surfel_run_sort_kernel(const uint32_t *__
     }
 }
 
-// Rank merge of the sorted runs of a long list (keys unique inside a tile => ranks are a permutation).  Every other run
-// is first copied into LDS (coalesced), then each thread binary-searches its 8 keys in it with the 8 searches
-// interleaved: the first version chased 8 x 22 dependent L2 loads per thread, one after the other (34 us for a
-// handful of lists, profiles/r1b_*).
-__global__ __launch_bounds__(256) void surfel_run_merge_kernel(const uint32_t *__restrict__ tile_start,
-                                                               const uint32_t *__restrict__ tile_order,
-                                                               const uint32_t *__restrict__ run_table,
+// Rank merge of the sorted runs of a long list (keys unique inside a tile => ranks are a permutation).  A run is split
+// over kMergeParts workgroups (2 keys per thread); the other runs are copied into LDS three at a time with all global
+// loads in flight together, then every thread binary-searches its keys in them, all searches interleaved and
+// branch-free.  (History: chasing 8 x 22 dependent L2 loads per thread took 34 us for a handful of lists; one other run
+// at a time with 8 keys per thread 25 us, profiles/r1b_*, r1c_*.)
+constexpr int kMergeParts = 4;
+constexpr int kMergeGroup = 3;
+
+__global__ __launch_bounds__(256) void surfel_run_merge_kernel(const uint4 *__restrict__ tile_order,
+                                                               const uint4 *__restrict__ run_table,
                                                                uint32_t max_extra, const uint64_t *__restrict__ keys,
                                                                uint32_t *__restrict__ point_list,
                                                                const int64_t *__restrict__ status)
 {
-    __shared__ __attribute__((aligned(16))) uint64_t other[kSortCap];
-    if (status[GA_STATUS_OVERFLOW]) return;
-    uint32_t tile, run;
-    if (!sort_block_assignment(tile_order, run_table, status, max_extra, tile, run)) return;
-    const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
-    const int n = (int)(end - beg);
+    __shared__ __attribute__((aligned(16))) uint64_t other[kMergeGroup][kSortCap];
+    uint32_t run, beg;
+    int n;
+    if (!sort_block_assignment(tile_order, run_table, status, max_extra, blockIdx.x / kMergeParts, run, beg, n)) return;
     if (n <= kSortCap) return;
+    const int part = (int)(blockIdx.x % kMergeParts);
     const int nruns = (n + kSortCap - 1) / kSortCap;
     const int rb = (int)run * kSortCap, rn = min(kSortCap, n - rb);
     const uint64_t *k = keys + beg;
-    constexpr int kPer = kSortCap / 256;  // keys of my run per thread
+    constexpr int kPer = kSortCap / kMergeParts / 256;  // keys of my part of the run per thread
     uint64_t mine[kPer];
     int rank[kPer];
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
-        const int e = threadIdx.x + 256 * i;
+        const int e = part * (kSortCap / kMergeParts) + (int)threadIdx.x + 256 * i;
         mine[i] = e < rn ? k[rb + e] : ~0ull;
         rank[i] = e;
     }
-    for (int r = 0; r < nruns; ++r) {
-        if (r == (int)run) continue;
-        const int ob = r * kSortCap, on = min(kSortCap, n - ob);
-        __syncthreads();
-        for (int t = threadIdx.x; t < on; t += 256) other[t] = k[ob + t];
-        __syncthreads();
-        int lo[kPer], hi[kPer];
+    for (int g0 = 0; g0 < nruns - 1; g0 += kMergeGroup) {  // other runs g0 .. g0+2 (skipping my own)
+        int ob[kMergeGroup], on[kMergeGroup];
 #pragma unroll
-        for (int i = 0; i < kPer; ++i) { lo[i] = 0; hi[i] = on; }
+        for (int q = 0; q < kMergeGroup; ++q) {
+            const int j = g0 + q, r = j < (int)run ? j : j + 1;
+            ob[q] = r * kSortCap;
+            on[q] = j < nruns - 1 ? min(kSortCap, n - ob[q]) : 0;
+        }
+        if (g0) __syncthreads();
+        uint64_t tmp[kMergeGroup][kSortCap / 256];
+#pragma unroll
+        for (int q = 0; q < kMergeGroup; ++q)
+#pragma unroll
+            for (int i = 0; i < kSortCap / 256; ++i) {
+                const int t = (int)threadIdx.x + 256 * i;
+                tmp[q][i] = t < on[q] ? k[ob[q] + t] : ~0ull;
+            }
+#pragma unroll
+        for (int q = 0; q < kMergeGroup; ++q)
+#pragma unroll
+            for (int i = 0; i < kSortCap / 256; ++i) other[q][threadIdx.x + 256 * i] = tmp[q][i];
+        __syncthreads();
+        int lo[kMergeGroup][kPer], hi[kMergeGroup][kPer];
+#pragma unroll
+        for (int q = 0; q < kMergeGroup; ++q)
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) { lo[q][i] = 0; hi[q][i] = on[q]; }
         for (int step = 0; step < 12; ++step) {  // 2^11 = kSortCap: 12 halvings reach lo == hi
 #pragma unroll
-            for (int i = 0; i < kPer; ++i) {
-                if (lo[i] < hi[i]) {
-                    const int mid = (lo[i] + hi[i]) >> 1;
-                    if (other[mid] < mine[i]) lo[i] = mid + 1; else hi[i] = mid;
+            for (int q = 0; q < kMergeGroup; ++q)
+#pragma unroll
+                for (int i = 0; i < kPer; ++i) {
+                    const bool open = lo[q][i] < hi[q][i];
+                    const int mid = (lo[q][i] + hi[q][i]) >> 1;       // < kSortCap whenever the interval is open
+                    const bool less = other[q][mid & (kSortCap - 1)] < mine[i];
+                    lo[q][i] = (open && less) ? mid + 1 : lo[q][i];
+                    hi[q][i] = (open && !less) ? mid : hi[q][i];
                 }
-            }
         }
 #pragma unroll
-        for (int i = 0; i < kPer; ++i) rank[i] += lo[i];
+        for (int q = 0; q < kMergeGroup; ++q)
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) rank[i] += lo[q][i];
     }
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
-        const int e = threadIdx.x + 256 * i;
+        const int e = part * (kSortCap / kMergeParts) + (int)threadIdx.x + 256 * i;
         if (e < rn) point_list[beg + rank[i]] = (uint32_t)mine[i];
     }
 }
@@ -421,9 +462,11 @@ void launch_tile_sort(const GaSurfelForwardArgs &a, const Dims &d, const Workspa
 {
     const uint32_t nt = (uint32_t)(d.V * d.tiles);
     const uint32_t max_extra = (uint32_t)(a.capacity / kSortCap + 1);
-    hipLaunchKernelGGL(surfel_run_sort_kernel, dim3(nt + max_extra), dim3(256), 0, s, ws.tile_start, ws.tile_order,
+    hipLaunchKernelGGL(surfel_run_sort_kernel, dim3(nt + max_extra), dim3(256), 0, s, ws.tile_order,
                        ws.run_table, max_extra, ws.keys, ws.point_list, ws.status);
-    hipLaunchKernelGGL(surfel_run_merge_kernel, dim3(nt + max_extra), dim3(256), 0, s, ws.tile_start, ws.tile_order,
+    // lists longer than one run sit at the front of tile_order and there are fewer than capacity / kSortCap of them
+    const uint32_t max_big = (uint32_t)std::min<int64_t>(nt, a.capacity / kSortCap);
+    hipLaunchKernelGGL(surfel_run_merge_kernel, dim3((max_big + max_extra) * kMergeParts), dim3(256), 0, s, ws.tile_order,
                        ws.run_table, max_extra, ws.keys, ws.point_list, ws.status);
 }
 

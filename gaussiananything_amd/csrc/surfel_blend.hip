@@ -299,8 +299,7 @@ __device__ __forceinline__ void write_pixel(const PixelAcc &a, const float *__re
 //     The only numerical difference to the sequential order is the rounding of P_w (a product of segment products).
 // The tile scan leaves the long tiles at the front of tile_order and their number in status[GA_STATUS_LONG_TILES]; the
 // grid is [4 x long tiles rounded up to 8 | remaining tiles], sized on the host from the capacity bound.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void surfel_blend_kernel(const uint32_t *__restrict__ tile_start,
-                                                               const uint32_t *__restrict__ tile_order,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void surfel_blend_kernel(const uint4 *__restrict__ tile_order,
                                                                const uint32_t *__restrict__ point_list,
                                                                const float *__restrict__ bbox,
                                                                const float *__restrict__ record,
@@ -312,8 +311,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __shared__ __attribute__((aligned(16))) float4 stage[4][6][128];  // wave-private record planes, 24 KiB; after pass 2
                                                                       // the same 6 KiB hold the wave's segment results
     __shared__ float seg_T[4][64];                                    // pass-1 transmittance of each segment
-    if (status[GA_STATUS_OVERFLOW]) return;
-    const uint32_t nlong = (uint32_t)status[GA_STATUS_LONG_TILES], nlong8 = (nlong + 7u) & ~7u;
+    const int64_t overflow = status[GA_STATUS_OVERFLOW], nlong64 = status[GA_STATUS_LONG_TILES];  // one latency
+    if (overflow) return;
+    const uint32_t nlong = (uint32_t)nlong64, nlong8 = (nlong + 7u) & ~7u;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t pos, quad;
@@ -331,7 +331,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         quad = (uint32_t)wave;
         split = false;
     }
-    const uint32_t vt = tile_order[pos];  // longest lists first
+    const uint4 sched = tile_order[pos];  // longest lists first: (tile, list begin, list length)
+    const uint32_t vt = sched.x;
     const int v = (int)(vt / (uint32_t)dm.tiles), tile = (int)(vt - (uint32_t)v * dm.tiles);
     const int tx = tile % dm.gx, ty = tile / dm.gx;
     const int qx0 = tx * kTile + (int)(quad & 1) * 8, qy0 = ty * kTile + (int)(quad >> 1) * 8;
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
     const bool inside = pxi < dm.W && pyi < dm.H;
 
-    const uint32_t beg = tile_start[vt], end = tile_start[vt + 1];
+    const uint32_t beg = sched.y, end = sched.y + sched.z;
     const size_t vbase = (size_t)v * dm.N;
     WaveCtx c;
     c.lane = lane; c.dx = (float)(lane & 7); c.dy = (float)(lane >> 3); c.qxlo = (float)qx0; c.qylo = (float)qy0;
@@ -413,7 +414,7 @@ void launch_blend(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &
     // long tiles hold >= long_list() pairs each, so there are at most capacity / long_list() of them
     const int64_t max_long = std::min<int64_t>(nt, a.capacity / long_list());
     const unsigned grid = (unsigned)(4 * ((max_long + 7) / 8 * 8) + nt);
-    hipLaunchKernelGGL(surfel_blend_kernel, dim3(grid), dim3(256), 0, s, ws.tile_start,
+    hipLaunchKernelGGL(surfel_blend_kernel, dim3(grid), dim3(256), 0, s,
                        ws.tile_order, ws.point_list, ws.bbox, ws.record, a.bg, d, nt, a.out_color, a.out_others, ws.status,
                        a.flags);
 }

@@ -33,7 +33,9 @@ struct Dims {
 
 struct Workspace {
     int64_t *status;
-    uint32_t *tile_count, *tile_start, *tile_cursor, *tile_order, *run_table;
+    uint32_t *tile_count, *tile_start, *tile_cursor;
+    uint4 *tile_order;   // schedule of the per-tile kernels, longest lists first: (tile, list begin, list length, 0)
+    uint4 *run_table;    // runs 1.. of the lists longer than one sort run: (tile, run, list begin, list length)
     uint16_t *rect;
     float *depth, *bbox, *record;
     uint64_t *keys;
