@@ -283,38 +283,127 @@ __global__ __launch_bounds__(256) void surfel_fill_kernel(const uint16_t *__rest
 
 // ---------------------------------------------------------------------------------------------------------------
 // 4. per-tile sort.  LDS bitonic network on u64 keys, padded with ~0 to the next power of two.
-// Thread t of a stage with stride j handles the pair (i, i|j), i = ((t & ~(j-1)) << 1) | (t & (j-1)).  For j <= 64 the 64
-// threads of a wave touch exactly the 128 elements [128*(t/64), +128): those stages need no workgroup barrier (LDS
-// operations of one wave execute in order), only the stages with j >= 128 do -- 10 of the 66 stages of a 2048-key run,
-// 1 of the 36 stages of a 256-key list.
-__device__ __forceinline__ void bitonic_exchange(uint64_t *s, int t, int j, int k)
+// Register-blocked: a thread holds E = 2^e keys whose indices differ in e consecutive bits [p, p+e) and performs up to
+// e consecutive stages of the network on them in registers -- one LDS round trip per group of stages instead of one per
+// stage (26 instead of 66 for a 2048-key run).
+//
+// The network is the direction-free form of the bitonic sorter: the block that merges sorted 2^(L-1)-subsequences into
+// sorted 2^L-subsequences starts with a "flip" stage pairing i with i ^ (2^L - 1), followed by the ordinary stages
+// i <-> i ^ 2^b (b = L-2 .. 0); every comparator is ascending.  A thread realises the flip by loading its upper-half
+// keys from the mirrored positions i ^ (2^(L-1) - 1); for the rest of that group its upper-half register slots are in
+// mirrored order, so their comparators are written the other way round -- all of it fixed at compile time.
+//
+// A compare-exchange is v_min_f64 + v_max_f64 on the raw key bits: keys are (depth bits << 32) | index with depth finite
+// and > 0.2 (near cull in the preprocess), so they are the bit patterns of positive normal doubles, whose order is the
+// unsigned order of the bits; padding is +infinity.  (A 64-bit integer compare and four selects cost about three times as
+// many issue cycles; PMC showed the sort to be instruction-issue bound: 14 M VALU + 10 M SALU wave instructions.)
+constexpr uint64_t kSortPad = 0x7FF0000000000000ull;
+
+// LDS slot of key i: an XOR swizzle of the low five index bits (32 eight-byte keys span the 64 banks) that makes the
+// gathers of the frequent groups (held bits at 0, 3, 6 for eight keys per thread) conflict-free -- unswizzled, a thread
+// reading its eight consecutive keys is an 8-way bank conflict.
+__device__ __forceinline__ int sort_slot(int i) { return i ^ ((i >> 5) & 7) ^ (((i >> 6) & 3) << 3); }
+
+// Top group of block L: flip at slot bit FB (index bit L-1), then G-1 ordinary stages below it.
+template <int E, int FB, int G>
+__device__ __forceinline__ void sort_group_top(double *s, int base, int p, int L)
 {
-    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-    const int p = i | j;
-    const uint64_t a = s[i], b = s[p];
-    const bool up = (i & k) == 0;
-    if ((a > b) == up) { s[i] = b; s[p] = a; }
+    const int mirror = (1 << (L - 1)) - 1;
+    double v[E];
+    int slot[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+        int i = base | (m << p);
+        if (m & (1 << FB)) i ^= mirror;
+        slot[m] = sort_slot(i);
+        v[m] = s[slot[m]];
+    }
+#pragma unroll
+    for (int q = FB; q > FB - G; --q) {
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            if (m & (1 << q)) continue;
+            const double x = v[m], y = v[m | (1 << q)];
+            const double mn = __builtin_fmin(x, y), mx = __builtin_fmax(x, y);
+            const bool mirrored = q < FB && (m & (1 << FB));
+            v[m] = mirrored ? mx : mn;
+            v[m | (1 << q)] = mirrored ? mn : mx;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < E; ++m) s[slot[m]] = v[m];
 }
 
-__device__ __forceinline__ void bitonic_sort_lds(uint64_t *s, int np, int tid, int nthreads)
+// Lower group: e ordinary stages on the held bits [p, p+e).
+template <int E>
+__device__ __forceinline__ void sort_group_low(double *s, int base, int p)
 {
-    const int half = np >> 1;
-    for (int k = 2; k <= np; k <<= 1) {
-        int j = k >> 1;
-        for (; j >= 128; j >>= 1) {
-            for (int t = tid; t < half; t += nthreads) bitonic_exchange(s, t, j, k);
-            __syncthreads();
-        }
-        for (int t = tid; t < half; t += nthreads) {  // one 128-element block per wave and pass: all its low stages
-            for (int jj = j; jj > 0; jj >>= 1) {
-                bitonic_exchange(s, t, jj, k);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        if (k >= 128) __syncthreads();  // the next k starts with j = k >= 128 (or the caller reads the result)
+    constexpr int e = E == 8 ? 3 : (E == 4 ? 2 : 1);
+    double v[E];
+    int slot[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+        slot[m] = sort_slot(base | (m << p));
+        v[m] = s[slot[m]];
     }
-    if (np < 128) __syncthreads();
+#pragma unroll
+    for (int q = e - 1; q >= 0; --q) {
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            if (m & (1 << q)) continue;
+            const double x = v[m], y = v[m | (1 << q)];
+            v[m] = __builtin_fmin(x, y);
+            v[m | (1 << q)] = __builtin_fmax(x, y);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < E; ++m) s[slot[m]] = v[m];
+}
+
+template <int E>
+__device__ __forceinline__ void bitonic_sort_blocked(double *s, int np, int tid)
+{
+    constexpr int e = E == 8 ? 3 : (E == 4 ? 2 : 1);
+    const int T = np / E;
+    const bool act = tid < T;
+    const int Ltot = 31 - __builtin_clz((unsigned)np);
+    int prev_p = 0;  // the caller has a barrier after filling the array
+    // With the held bits at or below bit 6 the 64 threads of a wave own the contiguous keys [64 E w, +64 E) in this group
+    // and in the previous one (mirroring stays inside it): no workgroup barrier between two such groups, LDS operations
+    // of one wave execute in order.
+    auto sync = [&](int p) {
+        if (p > 6 || prev_p > 6) __syncthreads();
+        else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        prev_p = p;
+    };
+    for (int L = 1; L <= Ltot; ++L) {
+        const int g = (L % e) ? (L % e) : e;  // stages of the top group; the groups below it are full
+        const int p = max(0, L - e);
+        sync(p);
+        if (act) {
+            const int base = ((tid >> p) << (p + e)) | (tid & ((1 << p) - 1));
+            if (L >= e) {
+                if (e == 1 || g == e) sort_group_top<E, e - 1, e>(s, base, p, L);
+                else if (g == 1) sort_group_top<E, e - 1, 1>(s, base, p, L);
+                else sort_group_top<E, e - 1, (e > 2 ? 2 : 1)>(s, base, p, L);
+            } else if (L == 1) sort_group_top<E, 0, 1>(s, base, p, L);
+            else sort_group_top<E, (e > 1 ? 1 : 0), (e > 1 ? 2 : 1)>(s, base, p, L);
+        }
+        for (int hi = L - 1 - g; hi >= 0; hi -= e) {
+            const int pl = hi - e + 1;
+            sync(pl);
+            if (act) sort_group_low<E>(s, ((tid >> pl) << (pl + e)) | (tid & ((1 << pl) - 1)), pl);
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void bitonic_sort_lds(double *s, int np, int tid)
+{
+    // eight keys per thread as soon as that fills half a wave: fewer, fatter groups beat more active threads
+    if (np >= 256) bitonic_sort_blocked<8>(s, np, tid);
+    else if (np >= 64) bitonic_sort_blocked<4>(s, np, tid);
+    else bitonic_sort_blocked<2>(s, np, tid);
 }
 
 // Workgroup -> (run, list begin, list length): one 16-byte load.  The first `max_extra` workgroups take the runs 1.. of
@@ -341,7 +430,7 @@ __global__ __launch_bounds__(256) void surfel_run_sort_kernel(const uint4 *__res
                                                               uint32_t *__restrict__ point_list,
                                                               const int64_t *__restrict__ status)
 {
-    __shared__ __attribute__((aligned(16))) uint64_t s[kSortCap];
+    __shared__ __attribute__((aligned(16))) double s[kSortCap];  // raw key bits (see bitonic_sort_blocked)
     uint32_t run, beg;
     int n;
     if (!sort_block_assignment(tile_order, run_table, status, max_extra, blockIdx.x, run, beg, n)) return;
@@ -350,13 +439,13 @@ __global__ __launch_bounds__(256) void surfel_run_sort_kernel(const uint4 *__res
     if (n == 1) { if (tid == 0) point_list[beg] = (uint32_t)keys[beg]; return; }
     const int rb = (int)run * kSortCap, rn = min(kSortCap, n - rb);
     int np = 2; while (np < rn) np <<= 1;
-    for (int t = tid; t < np; t += 256) s[t] = t < rn ? keys[beg + rb + t] : ~0ull;
+    for (int t = tid; t < np; t += 256) s[sort_slot(t)] = __longlong_as_double((long long)(t < rn ? keys[beg + rb + t] : kSortPad));
     __syncthreads();
-    bitonic_sort_lds(s, np, tid, 256);
+    bitonic_sort_lds(s, np, tid);
     if (n <= kSortCap) {
-        for (int t = tid; t < rn; t += 256) point_list[beg + t] = (uint32_t)s[t];   // single run: final order
+        for (int t = tid; t < rn; t += 256) point_list[beg + t] = (uint32_t)__double_as_longlong(s[sort_slot(t)]);   // single run: final order
     } else {
-        for (int t = tid; t < rn; t += 256) keys[beg + rb + t] = s[t];              // sorted run, merged by the next kernel
+        for (int t = tid; t < rn; t += 256) keys[beg + rb + t] = (uint64_t)__double_as_longlong(s[sort_slot(t)]);              // sorted run, merged by the next kernel
     }
 }
 

@@ -10,5 +10,5 @@ for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_W
            "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_ACTIVE_INST_MISC"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/$tag/p$i -o x -- python $R/bench.py --no-cpu-baseline --no-dit --no-stage-events --steps 5 --warmup 2 > /dev/null 2>$R/gpurun_out/$tag/p$i.err
-  python $R/tools/rocpd_pmc.py $(ls $R/gpurun_out/$tag/p$i/*/*.db $R/gpurun_out/$tag/p$i/*.db 2>/dev/null | head -1) 2>&1 | grep -A12 "surfel_blend"
+  python $R/tools/rocpd_pmc.py $(ls $R/gpurun_out/$tag/p$i/*/*.db $R/gpurun_out/$tag/p$i/*.db 2>/dev/null | head -1) 2>&1 | grep -A12 "${KPAT:-surfel_blend}"
 done
