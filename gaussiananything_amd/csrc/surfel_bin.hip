@@ -304,19 +304,36 @@ constexpr uint64_t kSortPad = 0x7FF0000000000000ull;
 // reading its eight consecutive keys is an 8-way bank conflict.
 __device__ __forceinline__ int sort_slot(int i) { return i ^ ((i >> 5) & 7) ^ (((i >> 6) & 3) << 3); }
 
+// v_min_f64 / v_max_f64 as such: through __builtin_fmin the compiler first canonicalises every loaded value (a
+// v_max_f64 x, x per key and group) for the sake of signalling NaNs, which these keys never are.
+__device__ __forceinline__ double key_min(double x, double y)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ double key_max(double x, double y)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
 // Top group of block L: flip at slot bit FB (index bit L-1), then G-1 ordinary stages below it.
 template <int E, int FB, int G>
 __device__ __forceinline__ void sort_group_top(double *s, int base, int p, int L)
 {
-    const int mirror = (1 << (L - 1)) - 1;
+    // the swizzle is linear over XOR and base, m << p are bit-disjoint: slot(base | m << p) = slot(base) ^ slot(m << p),
+    // where the second factor (and the mirror's) is wave-uniform -- one vector XOR per key
+    // (byte offsets, so that the vector side is the XOR alone)
+    const int sb = sort_slot(base) << 3, smirror = sort_slot((1 << (L - 1)) - 1) << 3;
+    char *sc = reinterpret_cast<char *>(s);
     double v[E];
     int slot[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) {
-        int i = base | (m << p);
-        if (m & (1 << FB)) i ^= mirror;
-        slot[m] = sort_slot(i);
-        v[m] = s[slot[m]];
+        slot[m] = sb ^ ((sort_slot(m << p) << 3) ^ ((m & (1 << FB)) ? smirror : 0));
+        v[m] = *reinterpret_cast<double *>(sc + slot[m]);
     }
 #pragma unroll
     for (int q = FB; q > FB - G; --q) {
@@ -324,14 +341,14 @@ __device__ __forceinline__ void sort_group_top(double *s, int base, int p, int L
         for (int m = 0; m < E; ++m) {
             if (m & (1 << q)) continue;
             const double x = v[m], y = v[m | (1 << q)];
-            const double mn = __builtin_fmin(x, y), mx = __builtin_fmax(x, y);
+            const double mn = key_min(x, y), mx = key_max(x, y);
             const bool mirrored = q < FB && (m & (1 << FB));
             v[m] = mirrored ? mx : mn;
             v[m | (1 << q)] = mirrored ? mn : mx;
         }
     }
 #pragma unroll
-    for (int m = 0; m < E; ++m) s[slot[m]] = v[m];
+    for (int m = 0; m < E; ++m) *reinterpret_cast<double *>(sc + slot[m]) = v[m];
 }
 
 // Lower group: e ordinary stages on the held bits [p, p+e).
@@ -341,10 +358,12 @@ __device__ __forceinline__ void sort_group_low(double *s, int base, int p)
     constexpr int e = E == 8 ? 3 : (E == 4 ? 2 : 1);
     double v[E];
     int slot[E];
+    const int sb = sort_slot(base) << 3;
+    char *sc = reinterpret_cast<char *>(s);
 #pragma unroll
     for (int m = 0; m < E; ++m) {
-        slot[m] = sort_slot(base | (m << p));
-        v[m] = s[slot[m]];
+        slot[m] = sb ^ (sort_slot(m << p) << 3);
+        v[m] = *reinterpret_cast<double *>(sc + slot[m]);
     }
 #pragma unroll
     for (int q = e - 1; q >= 0; --q) {
@@ -352,12 +371,12 @@ __device__ __forceinline__ void sort_group_low(double *s, int base, int p)
         for (int m = 0; m < E; ++m) {
             if (m & (1 << q)) continue;
             const double x = v[m], y = v[m | (1 << q)];
-            v[m] = __builtin_fmin(x, y);
-            v[m | (1 << q)] = __builtin_fmax(x, y);
+            v[m] = key_min(x, y);
+            v[m | (1 << q)] = key_max(x, y);
         }
     }
 #pragma unroll
-    for (int m = 0; m < E; ++m) s[slot[m]] = v[m];
+    for (int m = 0; m < E; ++m) *reinterpret_cast<double *>(sc + slot[m]) = v[m];
 }
 
 template <int E>
