@@ -36,7 +36,7 @@ class GaSurfelForwardArgs(ctypes.Structure):
 
 class GaSurfelWorkspaceLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_size_t) for n in (
-        "status", "tile_count", "tile_start", "tile_cursor", "tile_order", "run_table", "rect", "depth", "bbox", "record", "keys",
+        "status", "tile_count", "tile_start", "tile_cursor", "tile_order", "run_table", "rect", "depth", "record", "keys",
         "point_list", "total_bytes")]
 
 

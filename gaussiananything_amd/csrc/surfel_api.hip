@@ -58,7 +58,6 @@ int ga_surfel_workspace_layout(int32_t num_points, int32_t num_views, int32_t im
     out->run_table = off;   off += align256((cap / GA_SURFEL_SORT_RUN + 1) * 16);  /* uint4 (tile, run, begin, length) */
     out->rect = off;        off += align256(nv * 4 * sizeof(uint16_t));
     out->depth = off;       off += align256(nv * 4);
-    out->bbox = off;        off += align256(nv * 16);
     out->record = off;      off += align256(nv * ga::kRec * 4);
     out->keys = off;        off += align256(cap * 8);
     out->point_list = off;  off += align256(cap * 4);
@@ -92,7 +91,6 @@ int ga_surfel_forward(const GaSurfelForwardArgs *a, void *stream_v)
     ws.run_table = reinterpret_cast<uint4 *>(w + L.run_table);
     ws.rect = reinterpret_cast<uint16_t *>(w + L.rect);
     ws.depth = reinterpret_cast<float *>(w + L.depth);
-    ws.bbox = reinterpret_cast<float *>(w + L.bbox);
     ws.record = reinterpret_cast<float *>(w + L.record);
     ws.keys = reinterpret_cast<uint64_t *>(w + L.keys);
     ws.point_list = reinterpret_cast<uint32_t *>(w + L.point_list);

@@ -28,49 +28,66 @@
 //     64 pixels are saturated.
 // Pixel results are compared with the oracle by MSE (<= 1e-5, tests/), so this TU may contract to FMA and uses
 // v_rcp_f32 / v_exp_f32 instead of IEEE division and libm expf.
+#include <hip/hip_fp16.h>
+
 #include "surfel_common.h"
 
 namespace ga {
 
-struct PixelAcc {
-    float T, C0, C1, C2, N0, N1, N2, Dp, M1, M2, dist, median;
+typedef float f2 __attribute__((ext_vector_type(2)));  // one packed-fp32 operand (even-aligned register pair)
+
+__device__ __forceinline__ f2 lo2(const float4 &q) { return f2{q.x, q.y}; }
+__device__ __forceinline__ f2 hi2(const float4 &q) { return f2{q.z, q.w}; }
+
+struct PixelAcc {  // pairs are updated by one v_pk_fma_f32
+    float T, Dp, dist, median;
+    f2 M;     // M1, M2
+    f2 N01;   // normal x, y
+    f2 N2C0;  // normal z, red
+    f2 C12;   // green, blue
 };
 
-struct Rec {  // one staged record (quadrant-relative, see the staging step) in registers
+__device__ __forceinline__ PixelAcc fresh_pixel(float T)
+{
+    return PixelAcc{T, 0.0f, 0.0f, 0.0f, f2{0.0f, 0.0f}, f2{0.0f, 0.0f}, f2{0.0f, 0.0f}, f2{0.0f, 0.0f}};
+}
+
+struct Rec {  // one staged record (quadrant-relative, see the staging step) in registers; layout: surfel_common.h
     float4 q0, q1, q2, q3, q4;
-    float cb;
+    f2 q5;
 };
 
-// LDS image of a wave's staged chunk: six planes of 64 float4 (plane q holds quad q of every slot), so that the
+// LDS image of a wave's staged chunks: six planes of 128 float4 (plane q holds quad q of every slot), so that the
 // staging writes are contiguous and a gather of 16 different slots spreads over all 64 banks.
 __device__ __forceinline__ Rec lds_read_rec(const float4 (*planes)[128], int j)
 {
-    return Rec{planes[0][j], planes[1][j], planes[2][j], planes[3][j], planes[4][j], planes[5][j].x};
+    return Rec{planes[0][j], planes[1][j], planes[2][j], planes[3][j], planes[4][j],
+               *reinterpret_cast<const f2 *>(&planes[5][j])};
 }
 
-// One (pixel, splat) evaluation -- SURVEY.md A.1 "Blend" -- in two parts.  dx, dy: this lane's pixel relative to the
-// quadrant origin.  eval_alpha is free of cross-entry dependences (several entries are evaluated back to back in one
-// basic block, which lets a lone wave issue at ~2.4 instead of ~4.4 cycles per instruction); composite is the short
-// sequential part.  Upstream's chain of `continue` filters is evaluated branch-free into one predicate (the filters
-// commute: each one only decides whether the pair is skipped).
+// One (pixel, splat) evaluation -- SURVEY.md A.1 "Blend" -- in two parts.  dxy: this lane's pixel relative to the
+// quadrant origin.  eval_alpha is free of cross-entry dependences (several entries are evaluated back to back);
+// composite is the short sequential part.  Upstream's chain of `continue` filters is evaluated branch-free into one
+// predicate (the filters commute: each one only decides whether the pair is skipped).
 struct Alpha {
-    float alpha, sx, sy;
+    float alpha;
+    f2 s;
     bool pass, use3d;
 };
 
-__device__ __forceinline__ Alpha eval_alpha(const Rec &r, float dx, float dy)
+__device__ __forceinline__ Alpha eval_alpha(const Rec &r, f2 dxy)
 {
     // p = C' + dx*A + dy*B
-    const float p0 = fmaf(dy, r.q0.w, fmaf(dx, r.q0.x, r.q1.z));
-    const float p1 = fmaf(dy, r.q1.x, fmaf(dx, r.q0.y, r.q1.w));
-    const float p2 = fmaf(dy, r.q1.y, fmaf(dx, r.q0.z, r.q2.x));
+    const f2 pxy = dxy.y * hi2(r.q0) + (dxy.x * lo2(r.q0) + lo2(r.q1));
+    const float p2 = fmaf(dxy.y, r.q1.w, fmaf(dxy.x, r.q1.z, r.q2.z));
     const float rz = __builtin_amdgcn_rcpf(p2);
     Alpha o;
-    o.sx = p0 * rz;
-    o.sy = p1 * rz;
-    const float rho3d = o.sx * o.sx + o.sy * o.sy;
-    const float ex = r.q2.y - dx, ey = r.q2.z - dy;  // centre - pixel
-    const float rho2d = kFilterInvSquare * (ex * ex + ey * ey);
+    o.s = pxy * rz;
+    const f2 ss = o.s * o.s;
+    const float rho3d = ss.x + ss.y;
+    const f2 e = lo2(r.q2) - dxy;  // centre - pixel
+    const f2 ee = e * e;
+    const float rho2d = kFilterInvSquare * (ee.x + ee.y);
     const float rho = fminf(rho3d, rho2d);
     o.use3d = rho3d <= rho2d;
     o.alpha = fminf(0.99f, r.q2.w * __builtin_amdgcn_exp2f(rho * -0.72134752044f));
@@ -79,10 +96,16 @@ __device__ __forceinline__ Alpha eval_alpha(const Rec &r, float dx, float dy)
     return o;
 }
 
+__device__ __forceinline__ float pair_depth(const Rec &r, const Alpha &e)
+{
+    const f2 d = e.s * lo2(r.q3);
+    return e.use3d ? (d.x + d.y) + r.q3.z : r.q3.z;
+}
+
 __device__ __forceinline__ void composite(const Rec &r, const Alpha &e, PixelAcc &a, bool &done)
 {
     const float kM = kFar / (kFar - kNear);
-    const float depth = e.use3d ? fmaf(e.sx, r.q3.x, e.sy * r.q3.y) + r.q3.z : r.q3.z;
+    const float depth = pair_depth(r, e);
     const float test_T = a.T * (1.0f - e.alpha);
     const bool near_ok = !(depth < kNear);            // upstream: depth < near -> skip (before the alpha test)
     const bool stop = near_ok && test_T < 0.0001f;    // upstream: done = true
@@ -91,13 +114,14 @@ __device__ __forceinline__ void composite(const Rec &r, const Alpha &e, PixelAcc
         const float w = e.alpha * a.T;
         const float A = 1.0f - a.T;
         const float m = kM * (1.0f - kNear * __builtin_amdgcn_rcpf(depth));
-        a.dist += (m * m * A + a.M2 - 2.0f * m * a.M1) * w;
+        const f2 mm = f2{m, m * m};
+        a.dist += (mm.y * A + a.M.y - 2.0f * m * a.M.x) * w;
         a.Dp += depth * w;
-        a.M1 += m * w;
-        a.M2 += m * m * w;
+        a.M += mm * w;
         if (a.T > 0.5f) a.median = depth;
-        a.N0 += r.q3.w * w; a.N1 += r.q4.x * w; a.N2 += r.q4.y * w;
-        a.C0 += r.q4.z * w; a.C1 += r.q4.w * w; a.C2 += r.cb * w;
+        a.N01 += lo2(r.q4) * w;
+        a.N2C0 += hi2(r.q4) * w;
+        a.C12 += r.q5 * w;
         a.T = test_T;
     }
 }
@@ -108,10 +132,10 @@ __device__ __forceinline__ void composite(const Rec &r, const Alpha &e, PixelAcc
 // rule), which the segment-parallel kernel needs to give each segment its true starting transmittance.
 struct WaveCtx {
     int lane;
-    float dx, dy, qxlo, qylo;
+    f2 dxy;
+    float qxlo, qylo;
     uint32_t safe;  // a valid list position: out-of-range lanes re-read it
     const uint32_t *__restrict__ point_list;
-    const float4 *__restrict__ bbox4;
     const float4 *__restrict__ rec4;
     float4 (*planes)[128];
 };
@@ -127,16 +151,16 @@ __device__ __forceinline__ void walk_list(const WaveCtx &c, uint32_t sbeg, uint3
     //   iteration k consumes {bb, g0..g5} of chunk k (issued during k-1), issues them for chunk k+1 (whose ids were
     //   issued during k-1) and issues the ids of chunk k+2.  Loads are unconditional (out-of-range lanes re-read a
     //   valid entry) so the loop body is straight-line code and the loaded registers stay untouched until consumed.
-    float4 bb, g0, g1, g2, g3, g4, g5;
+    float4 g0, g1, g2, g3, g4;
+    f2 g5;
     uint32_t id_next;
     {
         const uint32_t e0 = sbeg + lane < send ? sbeg + lane : c.safe;
         const uint32_t e1 = sbeg + 64 + lane < send ? sbeg + 64 + lane : c.safe;
         const uint32_t id0 = c.point_list[e0];
         id_next = c.point_list[e1];
-        bb = c.bbox4[id0];
         const float4 *r = c.rec4 + (size_t)id0 * 6;
-        g0 = r[0]; g1 = r[1]; g2 = r[2]; g3 = r[3]; g4 = r[4]; g5 = r[5];
+        g0 = r[0]; g1 = r[1]; g2 = r[2]; g3 = r[3]; g4 = r[4]; g5 = *reinterpret_cast<const f2 *>(r + 5);
     }
     // loop-invariant lane predicates "my column / row is c" as wave masks (SGPR pairs)
     unsigned long long colsel[8], rowsel[8];
@@ -182,13 +206,13 @@ __device__ __forceinline__ void walk_list(const WaveCtx &c, uint32_t sbeg, uint3
             }
             Alpha e[kU];
 #pragma unroll
-            for (int u = 0; u < kU; ++u) e[u] = eval_alpha(r[u], c.dx, c.dy);
+            for (int u = 0; u < kU; ++u) e[u] = eval_alpha(r[u], c.dxy);
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 if (FULL) {
                     if (live[u] && e[u].pass && !done) composite(r[u], e[u], a, done);
                 } else {
-                    const float depth = e[u].use3d ? fmaf(e[u].sx, r[u].q3.x, e[u].sy * r[u].q3.y) + r[u].q3.z : r[u].q3.z;
+                    const float depth = pair_depth(r[u], e[u]);
                     if (live[u] && e[u].pass && !done && !(depth < kNear)) {
                         // T_global <= T_segment: once the segment product alone trips the stop rule the sequential
                         // loop has stopped at or before this pair, and every later segment is dead (P = 0)
@@ -207,41 +231,43 @@ __device__ __forceinline__ void walk_list(const WaveCtx &c, uint32_t sbeg, uint3
         const int newb = (step & 1) * 64, oldb = 64 - newb;
         // ---- lanes = entries: which pixel columns / rows of the quadrant does my entry's cull box cover? ----------
         const bool valid = base + lane < send;
+        // centre relative to the quadrant origin and the cull half-extents (fp16 pair, +inf = unbounded, < 0 = never)
+        const float ex0 = g2.x - c.qxlo, ey0 = g2.y - c.qylo;
+        const uint32_t cull = __float_as_uint(g3.w);
+        const float rx = __half2float(__ushort_as_half((unsigned short)(cull & 0xffffu)));
+        const float ry = __half2float(__ushort_as_half((unsigned short)(cull >> 16)));
         unsigned long long xm[8], ym[8], xany = 0, yany = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float fx = c.qxlo + (float)k, fy = c.qylo + (float)k;
-            xm[k] = __builtin_amdgcn_ballot_w64(valid && bb.x <= fx && bb.z >= fx);
-            ym[k] = __builtin_amdgcn_ballot_w64(valid && bb.y <= fy && bb.w >= fy);
+            xm[k] = __builtin_amdgcn_ballot_w64(valid && fabsf((float)k - ex0) <= rx);
+            ym[k] = __builtin_amdgcn_ballot_w64(valid && fabsf((float)k - ey0) <= ry);
             xany |= xm[k];
             yany |= ym[k];
         }
         const unsigned long long hitmask = xany & yany;
         if ((hitmask >> lane) & 1ull) {
             // rebase to the quadrant origin: C' = C + (q0.x - ox)*A + (q0.y - oy)*B with o = rint(centre); centre -= q0
-            const float ox = rintf(g2.y), oy = rintf(g2.z);
-            const float ux = c.qxlo - ox, uy = c.qylo - oy;
-            const float Cx = fmaf(uy, g0.w, fmaf(ux, g0.x, g1.z));
-            const float Cy = fmaf(uy, g1.x, fmaf(ux, g0.y, g1.w));
-            const float Cz = fmaf(uy, g1.y, fmaf(ux, g0.z, g2.x));
+            const float ux = c.qxlo - rintf(g2.x), uy = c.qylo - rintf(g2.y);
+            const float Cx = fmaf(uy, g0.z, fmaf(ux, g0.x, g1.x));
+            const float Cy = fmaf(uy, g0.w, fmaf(ux, g0.y, g1.y));
+            const float Cz = fmaf(uy, g1.w, fmaf(ux, g1.z, g2.z));
             const int slot = newb + lane;
             planes[0][slot] = g0;
-            planes[1][slot] = make_float4(g1.x, g1.y, Cx, Cy);
-            planes[2][slot] = make_float4(Cz, g2.y - c.qxlo, g2.z - c.qylo, g2.w);
-            planes[3][slot] = g3;
+            planes[1][slot] = make_float4(Cx, Cy, g1.z, g1.w);
+            planes[2][slot] = make_float4(ex0, ey0, Cz, g2.w);
+            planes[3][slot] = make_float4(g3.x, g3.y, g3.z, g3.w);
             if (FULL) {
                 planes[4][slot] = g4;
-                planes[5][slot] = g5;
+                *reinterpret_cast<f2 *>(&planes[5][slot]) = g5;
             }
         }
         {   // issue the next chunk's loads (ids arrived during the previous iteration) and the ids after that
             const uint32_t idn = id_next;
             const uint32_t e2 = base + 128 + lane < send ? base + 128 + lane : c.safe;
             id_next = c.point_list[e2];
-            bb = c.bbox4[idn];
             const float4 *r = c.rec4 + (size_t)idn * 6;
             g0 = r[0]; g1 = r[1]; g2 = r[2]; g3 = r[3];
-            if (FULL) { g4 = r[4]; g5 = r[5]; }
+            if (FULL) { g4 = r[4]; g5 = *reinterpret_cast<const f2 *>(r + 5); }
         }
         ++stat_chunks;
         if (flags & 2) continue;  // flag 2: staging only (measurement aid, not in the public header)
@@ -271,14 +297,14 @@ __device__ __forceinline__ void write_pixel(const PixelAcc &a, const float *__re
     const size_t HW = (size_t)dm.H * dm.W, pid = (size_t)pyi * dm.W + pxi;
     float *oc = out_color + (size_t)v * 3 * HW + pid;
     float *oo = out_others + (size_t)v * 7 * HW + pid;
-    oc[0] = a.C0 + a.T * bg[0];
-    oc[HW] = a.C1 + a.T * bg[1];
-    oc[2 * HW] = a.C2 + a.T * bg[2];
+    oc[0] = a.N2C0.y + a.T * bg[0];
+    oc[HW] = a.C12.x + a.T * bg[1];
+    oc[2 * HW] = a.C12.y + a.T * bg[2];
     oo[0] = a.Dp;
     oo[HW] = 1.0f - a.T;
-    oo[2 * HW] = a.N0;
-    oo[3 * HW] = a.N1;
-    oo[4 * HW] = a.N2;
+    oo[2 * HW] = a.N01.x;
+    oo[3 * HW] = a.N01.y;
+    oo[4 * HW] = a.N2C0.x;
     oo[5 * HW] = a.median;
     oo[6 * HW] = a.dist;
 }
@@ -301,7 +327,6 @@ __device__ __forceinline__ void write_pixel(const PixelAcc &a, const float *__re
 // grid is [4 x long tiles rounded up to 8 | remaining tiles], sized on the host from the capacity bound.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void surfel_blend_kernel(const uint4 *__restrict__ tile_order,
                                                                const uint32_t *__restrict__ point_list,
-                                                               const float *__restrict__ bbox,
                                                                const float *__restrict__ record,
                                                                const float *__restrict__ bg, Dims dm, int ntiles,
                                                                float *__restrict__ out_color,
@@ -343,13 +368,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const uint32_t beg = sched.y, end = sched.y + sched.z;
     const size_t vbase = (size_t)v * dm.N;
     WaveCtx c;
-    c.lane = lane; c.dx = (float)(lane & 7); c.dy = (float)(lane >> 3); c.qxlo = (float)qx0; c.qylo = (float)qy0;
+    c.lane = lane; c.dxy = f2{(float)(lane & 7), (float)(lane >> 3)}; c.qxlo = (float)qx0; c.qylo = (float)qy0;
     c.safe = beg; c.point_list = point_list;
-    c.bbox4 = reinterpret_cast<const float4 *>(bbox) + vbase;
     c.rec4 = reinterpret_cast<const float4 *>(record) + vbase * (kRec / 4);
     c.planes = stage[wave];
     unsigned stat_iters = 0, stat_chunks = 0, stat_useful = 0;
-    PixelAcc a = {1.0f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    PixelAcc a = fresh_pixel(1.0f);
     bool done = !inside;
 
     if (!split) {
@@ -368,29 +392,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         float P = 1.0f;
         for (int k = 0; k < wave; ++k) P *= seg_T[k][lane];
         // pass 2: the sequential blend of my segment, entered with the global transmittance
-        a = PixelAcc{P, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        a = fresh_pixel(P);
         done = done || P < 0.0001f;  // T never falls below 1e-4 in the sequential loop: it stopped before this segment
         a.median = -1.0f;  // depths are >= near > 0: a negative median means "not set inside this segment"
         walk_list<true>(c, sbeg, send, a, done, stat_iters, stat_chunks, flags, stat_useful);
         float *o = reinterpret_cast<float *>(stage[wave]) + lane;
-        o[0 * 64] = a.C0; o[1 * 64] = a.C1; o[2 * 64] = a.C2; o[3 * 64] = a.N0; o[4 * 64] = a.N1; o[5 * 64] = a.N2;
-        o[6 * 64] = a.Dp; o[7 * 64] = a.M1; o[8 * 64] = a.M2; o[9 * 64] = a.dist; o[10 * 64] = a.median;
+        o[0 * 64] = a.N2C0.y; o[1 * 64] = a.C12.x; o[2 * 64] = a.C12.y; o[3 * 64] = a.N01.x; o[4 * 64] = a.N01.y;
+        o[5 * 64] = a.N2C0.x; o[6 * 64] = a.Dp; o[7 * 64] = a.M.x; o[8 * 64] = a.M.y; o[9 * 64] = a.dist;
+        o[10 * 64] = a.median;
         o[11 * 64] = a.T; o[12 * 64] = done ? 1.0f : 0.0f; o[13 * 64] = P;
         __syncthreads();
         if (wave == 0 && inside) {
-            PixelAcc r = {1.0f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            PixelAcc r = fresh_pixel(1.0f);
             bool dead = false;
 #pragma unroll
             for (int k = 0; k < kSeg; ++k) {
                 const float *q = reinterpret_cast<const float *>(stage[k]) + lane;
                 if (!dead) {
                     const float Wk = q[13 * 64] - q[11 * 64];
-                    r.C0 += q[0 * 64]; r.C1 += q[1 * 64]; r.C2 += q[2 * 64];
-                    r.N0 += q[3 * 64]; r.N1 += q[4 * 64]; r.N2 += q[5 * 64];
+                    r.N2C0.y += q[0 * 64]; r.C12.x += q[1 * 64]; r.C12.y += q[2 * 64];
+                    r.N01.x += q[3 * 64]; r.N01.y += q[4 * 64]; r.N2C0.x += q[5 * 64];
                     r.Dp += q[6 * 64];
-                    r.dist += q[9 * 64] + r.M2 * Wk - 2.0f * r.M1 * q[7 * 64];
-                    r.M1 += q[7 * 64];
-                    r.M2 += q[8 * 64];
+                    r.dist += q[9 * 64] + r.M.y * Wk - 2.0f * r.M.x * q[7 * 64];
+                    r.M.x += q[7 * 64];
+                    r.M.y += q[8 * 64];
                     if (q[10 * 64] >= 0.0f) r.median = q[10 * 64];
                     r.T = q[11 * 64];
                     dead = q[12 * 64] != 0.0f;
@@ -415,7 +440,7 @@ void launch_blend(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &
     const int64_t max_long = std::min<int64_t>(nt, a.capacity / long_list());
     const unsigned grid = (unsigned)(4 * ((max_long + 7) / 8 * 8) + nt);
     hipLaunchKernelGGL(surfel_blend_kernel, dim3(grid), dim3(256), 0, s,
-                       ws.tile_order, ws.point_list, ws.bbox, ws.record, a.bg, d, nt, a.out_color, a.out_others, ws.status,
+                       ws.tile_order, ws.point_list, ws.record, a.bg, d, nt, a.out_color, a.out_others, ws.status,
                        a.flags);
 }
 

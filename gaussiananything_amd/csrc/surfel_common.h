@@ -13,15 +13,24 @@ constexpr int kRec = GA_SURFEL_RECORD_FLOATS;
 //   k = px*Tw - Tu ; l = py*Tw - Tv ; p = cross(k, l),   is bilinear in the pixel:  p = (px-ox)*A + (py-oy)*B + C
 //   with (ox,oy) = rint(centre), U = Tu - ox*Tw, V = Tv - oy*Tw, A = V x Tw, B = Tw x U, C = U x V  (pixel-independent,
 //   so computed once per splat by the preprocess kernel):
-//   q0 = A.x A.y A.z B.x | q1 = B.y B.z C.x C.y | q2 = C.z cx cy opacity      <- needed for every evaluated pair
-//   q3 = Tw.x Tw.y Tw.z n.x | q4 = n.y n.z r g | q5 = b - - -                 <- only for pairs that contribute
+//   q0 = A.x A.y B.x B.y | q1 = C.x C.y A.z B.z | q2 = cx cy C.z opacity      <- needed for every evaluated pair
+//   q3 = Tw.x Tw.y Tw.z cull | q4 = n.x n.y n.z r | q5 = g b - -                 <- Tw, cull: every pair; rest: contributing pairs
+// Values that are combined by one packed-fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32 take even-aligned register
+// pairs) sit in the same half of a quad: (A.x,A.y) (B.x,B.y) (C.x,C.y) (cx,cy) (Tw.x,Tw.y) (n.x,n.y) (n.z,r) (g,b).
+// `cull` = two fp16 half-extents (rx, ry), rounded up, of the conservative {alpha >= 1/255} pixel box about (cx, cy):
+// the blend loop rejects pixel columns / rows with |x - cx| > rx or |y - cy| > ry without evaluating the pair
+// (+inf = no bound, negative = the splat can never pass the threshold).
 constexpr float kNear = 0.2f;          // upstream near_n
 constexpr float kFar = 100.0f;         // upstream far_n
 constexpr float kCutoff = 3.0f;
 constexpr float kFilterSize = 0.707106f;
 constexpr float kFilterInvSquare = 2.0f;
 
-constexpr int kBinSplats = 8;           // splats per thread in the preprocess / fill kernels (2048 per workgroup)
+constexpr int kBinSplats = 8;           // splats per thread in the fill kernel (2048 per workgroup)
+#ifndef GA_PRE_SPLATS
+#define GA_PRE_SPLATS 2
+#endif
+constexpr int kPreSplats = GA_PRE_SPLATS;  // splats per thread in the preprocess kernel
 constexpr int kLdsTiles = 8192;         // per-view tile counters aggregated in LDS up to this many tiles (32 KiB)
 constexpr int kLongList = 1024;          // lists of >= this many pairs (a power of two) are blended four segments at a time
 int long_list();                         // kLongList, or 2^GA_LONG_LOG2 from the environment (tuning aid)
@@ -37,7 +46,7 @@ struct Workspace {
     uint4 *tile_order;   // schedule of the per-tile kernels, longest lists first: (tile, list begin, list length, 0)
     uint4 *run_table;    // runs 1.. of the lists longer than one sort run: (tile, run, list begin, list length)
     uint16_t *rect;
-    float *depth, *bbox, *record;
+    float *depth, *record;
     uint64_t *keys;
     uint32_t *point_list;
 };

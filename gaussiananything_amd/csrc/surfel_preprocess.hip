@@ -12,6 +12,8 @@
 // (what the blend kernel stages into LDS) plus the small SoA side arrays the binning passes stream (depth, rect,
 // bbox).  Tile occupancy is counted here (LDS histogram per workgroup, then L2 atomics), which replaces upstream's
 // tiles_touched array + device-wide inclusive scan.
+#include <hip/hip_fp16.h>
+
 #include "surfel_common.h"
 
 #pragma clang fp contract(off)
@@ -27,7 +29,7 @@ __device__ __forceinline__ void preprocess_one(
     const float *__restrict__ means3D, const float *__restrict__ opacities, const float *__restrict__ colors,
     const float *__restrict__ scales, const float *__restrict__ rotations, const float *__restrict__ vm,
     const float *__restrict__ pm, float scale_modifier, const Dims &dm, int v, int i, int32_t *__restrict__ radii,
-    uint16_t *__restrict__ rect_out, float *__restrict__ depth_out, float *__restrict__ bbox_out,
+    uint16_t *__restrict__ rect_out, float *__restrict__ depth_out,
     float *__restrict__ rec_out, uint32_t *tc)
 {
     const int64_t idx = (int64_t)v * dm.N + i;
@@ -112,22 +114,15 @@ __device__ __forceinline__ void preprocess_one(
     const float Ax = Vc[1] * Tw[2] - Vc[2] * Tw[1], Ay = Vc[2] * Tw[0] - Vc[0] * Tw[2], Az = Vc[0] * Tw[1] - Vc[1] * Tw[0];
     const float Bx = Tw[1] * Uc[2] - Tw[2] * Uc[1], By = Tw[2] * Uc[0] - Tw[0] * Uc[2], Bz = Tw[0] * Uc[1] - Tw[1] * Uc[0];
     const float Cx = Uc[1] * Vc[2] - Uc[2] * Vc[1], Cy = Uc[2] * Vc[0] - Uc[0] * Vc[2], Cz = Uc[0] * Vc[1] - Uc[1] * Vc[0];
-    float4 *rec = reinterpret_cast<float4 *>(rec_out + (size_t)idx * kRec);
-    rec[0] = make_float4(Ax, Ay, Az, Bx);
-    rec[1] = make_float4(By, Bz, Cx, Cy);
-    rec[2] = make_float4(Cz, cx, cy, opa);
-    rec[3] = make_float4(Tw[0], Tw[1], Tw[2], nvx);
-    rec[4] = make_float4(nvy, nvz, colors[3 * i], colors[3 * i + 1]);
-    rec[5] = make_float4(colors[3 * i + 2], 0.0f, 0.0f, 0.0f);
-
-    // Conservative pixel bounding box of {alpha >= 1/255}: the blend loop rejects (pixel, splat) pairs outside it
-    // without evaluating them.  alpha = min(.99, opa*exp(-rho/2)) >= 1/255  <=>  rho = min(rho3d, rho2d) <= c2 with
+    // Conservative pixel box of {alpha >= 1/255}: the blend loop rejects (pixel, splat) pairs outside it without
+    // evaluating them.  alpha = min(.99, opa*exp(-rho/2)) >= 1/255  <=>  rho = min(rho3d, rho2d) <= c2 with
     // c2 = 2 ln(255 opa): union of the low-pass disc (rho2d) and the projected c-sigma ellipse (rho3d, same AABB
     // formula as above with cutoff c).  Margins make rounding irrelevant; anything doubtful falls back to "everything".
+    // Stored as half-extents about (cx, cy), rounded up to fp16 (see surfel_common.h).
     const float kInf = __builtin_inff();
-    float4 bb = make_float4(-kInf, -kInf, kInf, kInf);  // xmin ymin xmax ymax
+    float rx = kInf, ry = kInf;
     if (opa < 1.0f / 255.0f) {
-        bb = make_float4(kInf, kInf, -kInf, -kInf);     // can never pass the alpha threshold
+        rx = ry = -1.0f;                                 // can never pass the alpha threshold
     } else {
         const float c2 = (2.0f * __logf(255.0f * opa)) * 1.02f + 0.05f;
         const float dd = (c2 * (Tw[0] * Tw[0]) + c2 * (Tw[1] * Tw[1])) - (Tw[2] * Tw[2]);
@@ -142,17 +137,28 @@ __device__ __forceinline__ void preprocess_one(
             const float r2 = sqrtf(0.5f * c2) + 0.5f;
             const float xmin = fminf(bx - e3x, cx - r2), xmax = fmaxf(bx + e3x, cx + r2);
             const float ymin = fminf(by - e3y, cy - r2), ymax = fmaxf(by + e3y, cy + r2);
-            if (xmin == xmin && xmax == xmax && ymin == ymin && ymax == ymax && hx == hx && hy == hy)
-                bb = make_float4(xmin, ymin, xmax, ymax);
+            if (xmin == xmin && xmax == xmax && ymin == ymin && ymax == ymax && hx == hx && hy == hy) {
+                rx = fmaxf(cx - xmin, xmax - cx);
+                ry = fmaxf(cy - ymin, ymax - cy);
+            }
         }
     }
-    *reinterpret_cast<float4 *>(bbox_out + 4 * idx) = bb;
+    // fp16, rounded towards +inf (a value beyond the fp16 range becomes +inf = no bound)
+    const uint32_t cull = (uint32_t)__half_as_ushort(__float2half_ru(rx)) |
+                          ((uint32_t)__half_as_ushort(__float2half_ru(ry)) << 16);
+    float4 *rec = reinterpret_cast<float4 *>(rec_out + (size_t)idx * kRec);
+    rec[0] = make_float4(Ax, Ay, Bx, By);
+    rec[1] = make_float4(Cx, Cy, Az, Bz);
+    rec[2] = make_float4(cx, cy, Cz, opa);
+    rec[3] = make_float4(Tw[0], Tw[1], Tw[2], __uint_as_float(cull));
+    rec[4] = make_float4(nvx, nvy, nvz, colors[3 * i]);
+    rec[5] = make_float4(colors[3 * i + 1], colors[3 * i + 2], 0.0f, 0.0f);
 
     for (int ty = rminy; ty < rmaxy; ++ty)
         for (int tx = rminx; tx < rmaxx; ++tx) atomicAdd(tc + ty * dm.gx + tx, 1u);
 }
 
-// One workgroup = 256 threads x kBinSplats consecutive Gaussians of ONE view (blockIdx.y).  Tile occupancy is
+// One workgroup = 256 threads x kPreSplats consecutive Gaussians of ONE view (blockIdx.y).  Tile occupancy is
 // accumulated in an LDS histogram of the view's tiles and flushed with one global atomic per touched tile per
 // workgroup: the hottest tile of a real scene receives thousands of increments per view and same-address L2 atomics
 // serialise (measured 0.27 ms for 1.4 M increments, profiles/r1a_*).  Views with more than kLdsTiles tiles use the
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256) void surfel_preprocess_kernel(
     const float *__restrict__ means3D, const float *__restrict__ opacities, const float *__restrict__ colors,
     const float *__restrict__ scales, const float *__restrict__ rotations, const float *__restrict__ viewmatrix,
     const float *__restrict__ projmatrix, float scale_modifier, Dims dm, int32_t *__restrict__ radii,
-    uint16_t *__restrict__ rect_out, float *__restrict__ depth_out, float *__restrict__ bbox_out,
+    uint16_t *__restrict__ rect_out, float *__restrict__ depth_out,
     float *__restrict__ rec_out, uint32_t *__restrict__ tile_count)
 {
     extern __shared__ uint32_t hist[];
@@ -173,11 +179,11 @@ __global__ __launch_bounds__(256) void surfel_preprocess_kernel(
     }
     const float *vm = viewmatrix + 16 * v, *pm = projmatrix + 16 * v;
     uint32_t *tcg = tile_count + (size_t)v * dm.tiles;
-    for (int k = 0; k < kBinSplats; ++k) {
-        const int i = (blockIdx.x * kBinSplats + k) * 256 + threadIdx.x;
+    for (int k = 0; k < kPreSplats; ++k) {
+        const int i = (blockIdx.x * kPreSplats + k) * 256 + threadIdx.x;
         if (i < dm.N)
             preprocess_one<kLds>(means3D, opacities, colors, scales, rotations, vm, pm, scale_modifier, dm, v, i, radii,
-                                 rect_out, depth_out, bbox_out, rec_out, kLds ? hist : tcg);
+                                 rect_out, depth_out, rec_out, kLds ? hist : tcg);
     }
     if (kLds) {
         __syncthreads();
@@ -190,15 +196,15 @@ __global__ __launch_bounds__(256) void surfel_preprocess_kernel(
 
 void launch_preprocess(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &ws, hipStream_t s)
 {
-    const dim3 grid((unsigned)((d.N + 256 * kBinSplats - 1) / (256 * kBinSplats)), (unsigned)d.V);
+    const dim3 grid((unsigned)((d.N + 256 * kPreSplats - 1) / (256 * kPreSplats)), (unsigned)d.V);
     if (d.tiles <= kLdsTiles)
         hipLaunchKernelGGL(surfel_preprocess_kernel<true>, grid, dim3(256), d.tiles * sizeof(uint32_t), s, a.means3D,
                            a.opacities, a.colors, a.scales, a.rotations, a.viewmatrix, a.projmatrix, a.scale_modifier,
-                           d, a.radii, ws.rect, ws.depth, ws.bbox, ws.record, ws.tile_count);
+                           d, a.radii, ws.rect, ws.depth, ws.record, ws.tile_count);
     else
         hipLaunchKernelGGL(surfel_preprocess_kernel<false>, grid, dim3(256), 0, s, a.means3D, a.opacities, a.colors,
                            a.scales, a.rotations, a.viewmatrix, a.projmatrix, a.scale_modifier, d, a.radii, ws.rect,
-                           ws.depth, ws.bbox, ws.record, ws.tile_count);
+                           ws.depth, ws.record, ws.tile_count);
 }
 
 }  // namespace ga

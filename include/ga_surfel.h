@@ -88,7 +88,6 @@ typedef struct GaSurfelWorkspaceLayout {
     size_t run_table;   /* uint32[2*(capacity/GA_SURFEL_SORT_RUN+1)] (tile id, run index) of the 2nd.. sort runs of long lists */
     size_t rect;        /* uint16[V*N*4]     tile rect min.x min.y max.x max.y (0 when culled)    */
     size_t depth;       /* float[V*N]        view-space depth (sort key)                          */
-    size_t bbox;        /* float[V*N*4]      conservative pixel bbox of alpha >= 1/255            */
     size_t record;      /* float[V*N*GA_SURFEL_RECORD_FLOATS] blend-ready splat records           */
     size_t keys;        /* uint64[capacity]  (depth bits << 32 | gaussian index), binned per tile */
     size_t point_list;  /* uint32[capacity]  gaussian indices, per tile in (depth, index) order   */

@@ -32,6 +32,12 @@ def ws_artifacts(ws, N, V, H, W):
     tile_start = ws.section("tile_start", torch.int32, V * tiles + 1).cpu().numpy().astype(np.int64)
     rect = ws.section("rect", torch.int16, V * N * 4).cpu().numpy().view(np.uint16).reshape(V, N, 4)
     point_list = ws.section("point_list", torch.int32, max(D, 1)).cpu().numpy()[:D]
-    bbox = ws.section("bbox", torch.float32, V * N * 4).cpu().numpy().reshape(V, N, 4)
+    # cull box = centre (record floats 8, 9) +- the two fp16 half-extents packed into record float 15 (surfel_common.h)
+    rec = ws.section("record", torch.float32, V * N * 24).cpu().numpy().reshape(V, N, 24)
+    ext = np.ascontiguousarray(rec[..., 15]).view(np.uint32)
+    rx = (ext & 0xFFFF).astype(np.uint16).view(np.float16).astype(np.float32)
+    ry = (ext >> 16).astype(np.uint16).view(np.float16).astype(np.float32)
+    with np.errstate(invalid="ignore"):
+        bbox = np.stack([rec[..., 8] - rx, rec[..., 9] - ry, rec[..., 8] + rx, rec[..., 9] + ry], -1)
     return dict(D=D, overflow=int(st[1]), max_tile=int(st[2]), tile_start=tile_start, rect=rect,
                 point_list=point_list, bbox=bbox, tiles=tiles)
