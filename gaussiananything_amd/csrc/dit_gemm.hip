@@ -19,6 +19,8 @@
 // lane order, so the bank-conflict-free image is obtained by permuting the SOURCE: slot (row, s) of the 128-byte row
 // holds global 16-byte chunk s ^ (row & 7), and fragment reads apply the same XOR (conflict-free for the hardware's
 // ds_read_b128 lane groups).
+#include <stdlib.h>
+
 #include "dit_common.h"
 
 namespace gadit {
@@ -238,7 +240,8 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
     //   <= 256 of them, but > 128             -> 128-row tiles, 4-slot ring (128 KiB): one workgroup per CU, deep look-ahead
     //   <= 128 (the N = 1024 GEMMs at M=1536) -> 64-row tiles, 4-slot ring (96 KiB): twice the workgroups
     const long long wg128 = (long long)((a->N + BN - 1) / BN) * ((a->M + 127) / 128);
-    const int cfg = wg128 > 256 ? 0 : (wg128 > 128 ? 1 : 2);
+    int cfg = wg128 > 256 ? 0 : (wg128 > 128 ? 1 : 2);
+    if (const char *e = getenv("GA_GEMM_CFG")) cfg = atoi(e);  // tuning aid
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KiB of dynamic LDS has to be opted into once per kernel
 #define GA_ATTR(E)                                                                                                  \

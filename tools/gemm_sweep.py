@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""K / N / M sweeps of ga_gemm_bf16: separates the fixed cost of a launch from the per-K-tile cost."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gaussiananything_amd import dit_ops as ops
+dev = torch.device("cuda:0")
+
+def timeit(fn, n=100):
+    for _ in range(10): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3  # us
+
+def run(M, N, K, epi):
+    A = torch.randn(M, K, device=dev).bfloat16(); W = torch.randn(N, K, device=dev).bfloat16() / 32
+    bias = torch.randn(N, device=dev)
+    out = torch.zeros(M, N, device=dev) if epi in (2, 3) else torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    us = timeit(lambda: ops.gemm(A, W, bias, epi, out=out))
+    print(f"gemm M={M:5d} N={N:5d} K={K:5d} epi={epi}: {us:7.1f} us  {2*M*N*K/us/1e6:7.1f} TF/s", flush=True)
+
+for (N, K, epi) in [(3072, 1024, 0), (4096, 1024, 1), (1024, 4096, 2), (1024, 1024, 2), (2048, 1024, 0)]:
+    run(1536, N, K, epi)
+if os.environ.get("GA_FULL_SWEEP"):
+    for K in (64, 256, 1024, 2048, 4096):
+        run(1536, 1024, K, 2)
+    run(8192, 8192, 8192, 0)
