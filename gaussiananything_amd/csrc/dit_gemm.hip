@@ -47,6 +47,80 @@ __device__ __forceinline__ void glds16(const uint16_t *gsrc, uint16_t *lds_wave_
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+template <int EPI, int MT>
+__device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[4][MT], int m0, int n0, int wn, int wm, int lane)
+{
+    const int M = p.M, N = p.N;
+    // epilogue: lane holds acc[i][j][r] = C[m = m0 + wm*MT*16 + j*16 + (lane&15)][n = n0 + wn*64 + i*16 + (lane>>4)*4 + r];
+    // the 64 columns of a wave are one attention head: its 64 values of row m sit in 4 fragments x 4 lane-groups x 4
+    // registers, so the per-head RMSNorm is an in-lane sum plus two xor-shuffles
+    const int nhead = n0 + wn * 64;
+    const float *qkw = nullptr;
+    if (EPI == GA_GEMM_EPI_STORE_BF16) {
+        if (nhead < p.qk_cols0) qkw = p.qk_w0;
+        else if (nhead < p.qk_cols1) qkw = p.qk_w1;
+    }
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int m = m0 + wm * (MT * 16) + j * 16 + (lane & 15);
+        const float *gate_row = nullptr;
+        if (EPI == GA_GEMM_EPI_RESIDUAL && p.gate && m < M) gate_row = p.gate + (size_t)(m / p.rows_per_batch) * p.gate_stride;
+        f32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = nhead + i * 16 + (lane >> 4) * 4;
+            v[i] = acc[i][j];
+            if (p.bias && n < N) {
+                const float4 b = *reinterpret_cast<const float4 *>(p.bias + n);
+                v[i][0] += b.x; v[i][1] += b.y; v[i][2] += b.z; v[i][3] += b.w;
+            }
+        }
+        if (EPI == GA_GEMM_EPI_STORE_BF16 && qkw) {  // wave-uniform
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const float rs = rsqrtf(ss * (1.0f / 64.0f) + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 w = *reinterpret_cast<const float4 *>(qkw + i * 16 + (lane >> 4) * 4);
+                v[i][0] *= rs * w.x; v[i][1] *= rs * w.y; v[i][2] *= rs * w.z; v[i][3] *= rs * w.w;
+            }
+        }
+        if (m >= M) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = nhead + i * 16 + (lane >> 4) * 4;
+            if (n >= N) continue;
+            if (EPI == GA_GEMM_EPI_GELU_BF16) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[i][r] = 0.5f * v[i][r] * (1.0f + erff(v[i][r] * 0.70710678118654752f));
+            }
+            if (EPI == GA_GEMM_EPI_STORE_BF16 && p.vt && n >= p.vt_col0) {
+                // V projection: write V^T[(b*heads + h)*64 + d][token]; 16 consecutive lanes hold 16 consecutive tokens
+                const int b = m / p.rows_per_batch, tok = m - b * p.rows_per_batch, dn = n - p.vt_col0;
+                uint16_t *dst = p.vt + ((size_t)b * p.heads * 64 + dn) * p.vt_ld + tok;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(size_t)r * p.vt_ld] = f32_to_bf16(v[i][r]);
+            } else if (EPI == GA_GEMM_EPI_STORE_BF16 || EPI == GA_GEMM_EPI_GELU_BF16) {
+                uint2 pk = make_uint2(pack_bf16x2(v[i][0], v[i][1]), pack_bf16x2(v[i][2], v[i][3]));
+                *reinterpret_cast<uint2 *>(static_cast<uint16_t *>(p.out) + (size_t)m * p.ldo + n) = pk;
+            } else {
+                float4 *dst = reinterpret_cast<float4 *>(static_cast<float *>(p.out) + (size_t)m * p.ldo + n);
+                if (EPI == GA_GEMM_EPI_RESIDUAL) {
+                    float4 gt = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (gate_row) gt = *reinterpret_cast<const float4 *>(gate_row + n);
+                    const float4 x = *dst;
+                    *dst = make_float4(x.x + gt.x * v[i][0], x.y + gt.y * v[i][1], x.z + gt.z * v[i][2], x.w + gt.w * v[i][3]);
+                } else {
+                    *dst = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+                }
+            }
+        }
+    }
+}
+
 // MT = activation-row fragments per wave: 4 -> 128-row tiles, 2 -> 64-row tiles (twice the workgroups for the N = 1024
 // GEMMs, whose 128x128 grid fills only 96 of the 256 CUs)
 template <int EPI, int NST, int MT>
@@ -144,74 +218,122 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
 #undef GA_STAGE
 #undef GA_COMPUTE
 
-    // epilogue: lane holds acc[i][j][r] = C[m = m0 + wm*MT*16 + j*16 + (lane&15)][n = n0 + wn*64 + i*16 + (lane>>4)*4 + r];
-    // the 64 columns of a wave are one attention head: its 64 values of row m sit in 4 fragments x 4 lane-groups x 4
-    // registers, so the per-head RMSNorm is an in-lane sum plus two xor-shuffles
-    const int nhead = n0 + wn * 64;
-    const float *qkw = nullptr;
-    if (EPI == GA_GEMM_EPI_STORE_BF16) {
-        if (nhead < p.qk_cols0) qkw = p.qk_w0;
-        else if (nhead < p.qk_cols1) qkw = p.qk_w1;
+    gemm_epilogue<EPI, MT>(p, acc, m0, n0, wn, wm, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Register-FIFO variant.  The LDS-DMA ring above holds at most 3 K-tiles in flight per CU (~74 KiB); with ~1.1 us from
+// issue to arrival that caps a workgroup at ~68 GB/s = one K-tile per 0.36 us, three times the tile's MFMA time (sweep
+// in tools/gemm_sweep.py: 8 us fixed + 6 us per 1024 of K at M = 1536).  Bytes in flight are what is missing and the
+// register file is the big buffer of a CU (512 KiB vs 160 KiB of LDS): here every wave keeps D K-tiles of its share of
+// the operands in flight in VGPRs (global_load_dwordx4, (4 + MT) x 4 registers per tile), drops tile t into one of two
+// LDS buffers when it arrives (the XOR swizzle moves from the DMA source to the ds_write address) and re-issues the
+// registers for tile t + D.  One barrier per K-tile: a wave writes buffer (t+1)&1 while others still read buffer t&1.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in registers (HIP's uint4 is a struct)
+
+template <int EPI, int D, int MT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_rf_kernel(GemmP p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];  // [2][W | A][row][slot]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    constexpr int BMT = 2 * MT * 16;
+    constexpr int SLOT = (BN + BMT) * BK;
+    constexpr int LPT = 4 + MT;  // loads per wave per K-tile
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BMT;
+    const int M = p.M, N = p.N, K = p.K;
+
+    // load i of wave w covers rows (w*4+i)*8 .. +7 (W) / (w*MT+i)*8 .. +7 (A): lane -> row + (lane>>3), 16-byte chunk lane&7
+    const u32x4 *src[LPT];
+    int dst[LPT];  // byte offset inside a buffer, swizzled: chunk c of row r sits at slot c ^ (r & 7)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        src[i] = reinterpret_cast<const u32x4 *>(p.W + (size_t)min(n0 + row, N - 1) * K + (lane & 7) * 8);
+        dst[i] = (row * BK + (((lane & 7) ^ (row & 7)) * 8)) * 2;
     }
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        const int m = m0 + wm * (MT * 16) + j * 16 + (lane & 15);
-        const float *gate_row = nullptr;
-        if (EPI == GA_GEMM_EPI_RESIDUAL && p.gate && m < M) gate_row = p.gate + (size_t)(m / p.rows_per_batch) * p.gate_stride;
-        f32x4 v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = nhead + i * 16 + (lane >> 4) * 4;
-            v[i] = acc[i][j];
-            if (p.bias && n < N) {
-                const float4 b = *reinterpret_cast<const float4 *>(p.bias + n);
-                v[i][0] += b.x; v[i][1] += b.y; v[i][2] += b.z; v[i][3] += b.w;
-            }
-        }
-        if (EPI == GA_GEMM_EPI_STORE_BF16 && qkw) {  // wave-uniform
-            float ss = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
-            ss += __shfl_xor(ss, 16, 64);
-            ss += __shfl_xor(ss, 32, 64);
-            const float rs = rsqrtf(ss * (1.0f / 64.0f) + 1e-5f);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 w = *reinterpret_cast<const float4 *>(qkw + i * 16 + (lane >> 4) * 4);
-                v[i][0] *= rs * w.x; v[i][1] *= rs * w.y; v[i][2] *= rs * w.z; v[i][3] *= rs * w.w;
-            }
-        }
-        if (m >= M) continue;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = nhead + i * 16 + (lane >> 4) * 4;
-            if (n >= N) continue;
-            if (EPI == GA_GEMM_EPI_GELU_BF16) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[i][r] = 0.5f * v[i][r] * (1.0f + erff(v[i][r] * 0.70710678118654752f));
-            }
-            if (EPI == GA_GEMM_EPI_STORE_BF16 && p.vt && n >= p.vt_col0) {
-                // V projection: write V^T[(b*heads + h)*64 + d][token]; 16 consecutive lanes hold 16 consecutive tokens
-                const int b = m / p.rows_per_batch, tok = m - b * p.rows_per_batch, dn = n - p.vt_col0;
-                uint16_t *dst = p.vt + ((size_t)b * p.heads * 64 + dn) * p.vt_ld + tok;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dst[(size_t)r * p.vt_ld] = f32_to_bf16(v[i][r]);
-            } else if (EPI == GA_GEMM_EPI_STORE_BF16 || EPI == GA_GEMM_EPI_GELU_BF16) {
-                uint2 pk = make_uint2(pack_bf16x2(v[i][0], v[i][1]), pack_bf16x2(v[i][2], v[i][3]));
-                *reinterpret_cast<uint2 *>(static_cast<uint16_t *>(p.out) + (size_t)m * p.ldo + n) = pk;
-            } else {
-                float4 *dst = reinterpret_cast<float4 *>(static_cast<float *>(p.out) + (size_t)m * p.ldo + n);
-                if (EPI == GA_GEMM_EPI_RESIDUAL) {
-                    float4 gt = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (gate_row) gt = *reinterpret_cast<const float4 *>(gate_row + n);
-                    const float4 x = *dst;
-                    *dst = make_float4(x.x + gt.x * v[i][0], x.y + gt.y * v[i][1], x.z + gt.z * v[i][2], x.w + gt.w * v[i][3]);
-                } else {
-                    *dst = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
-                }
-            }
-        }
+    for (int i = 0; i < MT; ++i) {
+        const int row = (wave * MT + i) * 8 + (lane >> 3);
+        src[4 + i] = reinterpret_cast<const u32x4 *>(p.A + (size_t)min(m0 + row, M - 1) * p.lda + (lane & 7) * 8);
+        dst[4 + i] = (TILE_ELEMS + row * BK + (((lane & 7) ^ (row & 7)) * 8)) * 2;
     }
+    f32x4 acc[4][MT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, g = lane >> 4;
+    const int nk = K / BK;
+
+    u32x4 fifo0[LPT], fifo1[LPT], fifo2[LPT], fifo3[LPT], fifo4[LPT], fifo5[LPT], fifo6[LPT], fifo7[LPT];  // sets >= D stay unused
+#define GA_ISSUE(SET, KT)                                                                             \
+    do {                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < LPT; ++i) fifo##SET[i] = src[i][(size_t)(KT) * (BK / 8)]; \
+    } while (0)
+#define GA_DROP(SET, BUF)                                                                             \
+    do {                                                                                              \
+        char *b_ = reinterpret_cast<char *>(smem) + (BUF) * SLOT * 2;                                  \
+        _Pragma("unroll") for (int i = 0; i < LPT; ++i) *reinterpret_cast<u32x4 *>(b_ + dst[i]) = fifo##SET[i]; \
+    } while (0)
+#define GA_COMPUTE(BUF)                                                                               \
+    do {                                                                                              \
+        const uint16_t *bw_ = smem + (BUF) * SLOT, *ba_ = bw_ + TILE_ELEMS;                            \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                            \
+            bf16x8 fw[4], fa[MT];                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+                const int rw = wn * 64 + i * 16 + frow;                                               \
+                fw[i] = *reinterpret_cast<const bf16x8 *>(bw_ + rw * BK + (((kk * 4 + g) ^ (rw & 7)) * 8)); \
+            }                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                          \
+                const int ra = wm * (MT * 16) + i * 16 + frow;                                        \
+                fa[i] = *reinterpret_cast<const bf16x8 *>(ba_ + ra * BK + (((kk * 4 + g) ^ (ra & 7)) * 8)); \
+            }                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
+                _Pragma("unroll") for (int j = 0; j < MT; ++j)                                        \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0); \
+        }                                                                                             \
+    } while (0)
+#define GA_PHASE(SET, KT)                                                                             \
+    do {                                                                                              \
+        GA_DROP(SET, (KT) & 1);           /* waits for tile KT only: the younger loads stay in flight */ \
+        GA_ISSUE(SET, min((KT) + D, nk - 1)); /* unconditional: see below */                           \
+        __syncthreads();                  /* tile KT is in LDS; everyone has left tile KT-1's buffer */ \
+        GA_COMPUTE((KT) & 1);                                                                          \
+    } while (0)
+
+    // Requires nk % D == 0 (host-checked).  The loop body is branch-free on purpose: hipcc's wait-count insertion only
+    // keeps the younger loads in flight (vmcnt(N > 0) in front of the LDS writes) when the order of the outstanding loads is
+    // the same on every path into the loop; with conditional issues it drains everything (vmcnt(0)) every tile.  The
+    // tail therefore re-loads the last tile into sets that are never consumed.
+    GA_ISSUE(0, 0);
+    GA_ISSUE(1, 1);
+    if (D > 2) GA_ISSUE(2, 2);
+    if (D > 3) GA_ISSUE(3, 3);
+    if (D > 4) GA_ISSUE(4, 4);
+    if (D > 5) GA_ISSUE(5, 5);
+    if (D > 6) GA_ISSUE(6, 6);
+    if (D > 7) GA_ISSUE(7, 7);
+    // 16 K-tiles per trip, straight-line: the wait-count pass drains all loads at a loop back-edge, which costs one
+    // exposed load latency per trip (none at all for K = 1024)
+    for (int kt0 = 0; kt0 < nk; kt0 += 16)
+#pragma unroll
+    for (int kt = kt0; kt < kt0 + 16; kt += D) {
+        GA_PHASE(0, kt);
+        GA_PHASE(1, kt + 1);
+        if (D > 2) GA_PHASE(2, kt + 2);
+        if (D > 3) GA_PHASE(3, kt + 3);
+        if (D > 4) GA_PHASE(4, kt + 4);
+        if (D > 5) GA_PHASE(5, kt + 5);
+        if (D > 6) GA_PHASE(6, kt + 6);
+        if (D > 7) GA_PHASE(7, kt + 7);
+    }
+#undef GA_PHASE
+#undef GA_COMPUTE
+#undef GA_DROP
+#undef GA_ISSUE
+    gemm_epilogue<EPI, MT>(p, acc, m0, n0, wn, wm, lane);
 }
 
 }  // namespace gadit
@@ -263,6 +385,30 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
     else                                                                                                           \
         hipLaunchKernelGGL((gemm_bf16_kernel<E, 4, 2>), dim3((a->N + BN - 1) / BN, (a->M + 63) / 64), dim3(256),    \
                            4 * (BN + 64) * BK * 2, s, p);
+#define GA_LAUNCH_RF(E)                                                                                            \
+    if (cfg == 3)                                                                                                  \
+        hipLaunchKernelGGL((gemm_bf16_rf_kernel<E, 4, 4>), dim3((a->N + BN - 1) / BN, (a->M + 127) / 128), dim3(256), \
+                           2 * (BN + 128) * BK * 2, s, p);                                                          \
+    else if (cfg == 4)                                                                                             \
+        hipLaunchKernelGGL((gemm_bf16_rf_kernel<E, 8, 4>), dim3((a->N + BN - 1) / BN, (a->M + 127) / 128), dim3(256), \
+                           2 * (BN + 128) * BK * 2, s, p);                                                          \
+    else if (cfg == 5)                                                                                             \
+        hipLaunchKernelGGL((gemm_bf16_rf_kernel<E, 4, 2>), dim3((a->N + BN - 1) / BN, (a->M + 63) / 64), dim3(256),  \
+                           2 * (BN + 64) * BK * 2, s, p);                                                           \
+    else                                                                                                           \
+        hipLaunchKernelGGL((gemm_bf16_rf_kernel<E, 8, 2>), dim3((a->N + BN - 1) / BN, (a->M + 63) / 64), dim3(256),  \
+                           2 * (BN + 64) * BK * 2, s, p);
+    if (cfg >= 3 && (a->K / BK) % ((cfg == 4 || cfg == 6) ? 8 : 4) != 0) cfg = wg128 > 256 ? 0 : (wg128 > 128 ? 1 : 2);
+    if (cfg >= 3) {
+        switch (a->epilogue) {
+        case GA_GEMM_EPI_STORE_BF16: GA_LAUNCH_RF(0) break;
+        case GA_GEMM_EPI_GELU_BF16: GA_LAUNCH_RF(1) break;
+        case GA_GEMM_EPI_RESIDUAL: GA_LAUNCH_RF(2) break;
+        case GA_GEMM_EPI_STORE_F32: GA_LAUNCH_RF(3) break;
+        default: return GA_DIT_ERR_BAD_SHAPE;
+        }
+        return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
+    }
     switch (a->epilogue) {
     case GA_GEMM_EPI_STORE_BF16: GA_LAUNCH(0) break;
     case GA_GEMM_EPI_GELU_BF16: GA_LAUNCH(1) break;

@@ -22,6 +22,10 @@ def run(M, N, K, epi):
     us = timeit(lambda: ops.gemm(A, W, bias, epi, out=out))
     print(f"gemm M={M:5d} N={N:5d} K={K:5d} epi={epi}: {us:7.1f} us  {2*M*N*K/us/1e6:7.1f} TF/s", flush=True)
 
+if os.environ.get("GA_ONE_SHAPE"):
+    n_, k_, e_ = [int(x) for x in os.environ["GA_ONE_SHAPE"].split(",")]
+    run(1536, n_, k_, e_)
+    sys.exit(0)
 for (N, K, epi) in [(3072, 1024, 0), (4096, 1024, 1), (1024, 4096, 2), (1024, 1024, 2), (2048, 1024, 0)]:
     run(1536, N, K, epi)
 if os.environ.get("GA_FULL_SWEEP"):
