@@ -85,7 +85,7 @@ def dit_flops_per_nfe(D, depth, L, M, ctx, batch):
     return batch * depth * (sa + ca + mlp), batch * depth * attn_only
 
 
-def bench_dit(dev, arch, nfe, warmup):
+def bench_dit(dev, arch, nfe, warmup, parity_mode=False):
     """ms per function evaluation of forward_with_cfg at the release shapes: CFG batch 2, 768 latent tokens,
     1369 x 1024 image tokens, seeded random weights (zero-initialised tensors re-drawn)."""
     from gaussiananything_amd.dit import DiT_models
@@ -129,12 +129,54 @@ def bench_dit(dev, arch, nfe, warmup):
         fn(x, model.forward_with_cfg, context=ctx, cfg_scale=4.0)
         torch.cuda.synchronize()
         sec250 = time.perf_counter() - t0
+        extra = {}
+        if parity_mode:
+            # SURVEY.md 8d metric 2 (ii): the reference's own sampler settings (dopri5, rtol 1e-3, atol 1e-6, 250 output
+            # times) with the number of function evaluations recorded -- adaptive, so it depends on the (random) weights
+            calls = [0]
+
+            class _TooManyEvaluations(RuntimeError):
+                pass
+
+            def counted(xx, tt, **kw):
+                calls[0] += 1
+                if calls[0] > 4000:   # keeps the default bench run bounded if the random-weight ODE turns out stiff
+                    raise _TooManyEvaluations()
+                return model.forward_with_cfg(xx, tt, **kw)
+            fn5 = sampler.sample_ode(sampling_method="dopri5", num_steps=250, atol=1e-6, rtol=1e-3)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            try:
+                fn5(x, counted, context=ctx, cfg_scale=4.0)
+                finished = True
+            except _TooManyEvaluations:
+                finished = False
+            torch.cuda.synchronize()
+            extra["dopri5_parity_mode"] = {"sec": round(time.perf_counter() - t0, 4), "nfe": calls[0], "finished": finished,
+                                           "rtol": 1e-3, "atol": 1e-6, "num_steps": 250}
+            # CPU figure next to it: the fp32 oracle (PyTorch CPU over the same state dict), one function evaluation
+            from oracle import dit as odit
+            sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+            cctx = {k: v.float().cpu() for k, v in ctx.items()}
+            ncpu = min(64, len(os.sched_getaffinity(0)))   # more intra-op threads than that only add contention
+            torch.set_num_threads(ncpu)
+            best = float("inf")
+            for _ in range(2):                             # the first call pays the oneDNN primitive set-up
+                t0 = time.perf_counter()
+                odit.forward_with_cfg(sd, x.float().cpu(), t.cpu(), cctx, 4.0)
+                best = min(best, time.perf_counter() - t0)
+                if best > 20.0:
+                    break
+            extra["cpu_baseline"] = {"value": round(best * 1e3, 2), "unit": "ms per function evaluation", "kind": "port",
+                                     "cores": ncpu,
+                                     "sample": "best of 2 forward_with_cfg calls of the fp32 PyTorch oracle on the host "
+                                               "cores (CFG batch 2 x 768 tokens); x249 for a 250-step Euler stage"}
     fl, fl_attn = dit_flops_per_nfe(model.embed_dim, model.depth, L, M, 1024, B)
     tf = fl / (ms * 1e-3) / 1e12
     return {"arch": arch, "cfg_batch": B, "tokens": L, "ctx_tokens": M, "ms_per_nfe": round(ms, 4),
             "algorithmic_tflop_per_nfe": round(fl / 1e12, 4), "achieved_tflops": round(tf, 2),
             "bf16_mfma_peak_tflops": 2500.0, "frac_of_mfma_peak": round(tf / 2500.0, 4),
-            "sec_per_250_step_euler_stage": round(sec250, 4), "nfe_timed": nfe}
+            "sec_per_250_step_euler_stage": round(sec250, 4), "nfe_timed": nfe, **extra}
 
 
 def main():
@@ -272,7 +314,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(g, cams, H, W)
         if world == 1 and not a.no_dit:
             # second half of the headline metric ("sec/sample 250-step cascaded"): the two release-size denoisers
-            out["dit"] = [bench_dit(dev, arch, a.dit_nfe, 3) for arch in
+            out["dit"] = [bench_dit(dev, arch, a.dit_nfe, 3, parity_mode=(arch == "DiT-PixArt-PCD-CLAY-B")) for arch in
                           ("DiT-PixArt-PCD-CLAY-B", "DiT-PixArt-PCD-CLAY-L", "DiT-PixArt-PCD-CLAY-stage2-L")]
             out["sec_per_sample_250step_cascaded_L"] = round(
                 out["dit"][1]["sec_per_250_step_euler_stage"] + out["dit"][2]["sec_per_250_step_euler_stage"]
