@@ -24,13 +24,15 @@ __device__ __forceinline__ int f2i(float f) { return (int)f; }  // v_cvt_i32_f32
 
 // One (view, Gaussian).  `tc` is the tile-counter array of this view: the workgroup's LDS histogram (kLds) or the
 // global counters.
+// Returns true when the record was produced; it is left in `stg` (this lane's 96-byte LDS slot) for the wave's coalesced
+// copy-out.
 template <bool kLds>
-__device__ __forceinline__ void preprocess_one(
+__device__ __forceinline__ bool preprocess_one(
     const float *__restrict__ means3D, const float *__restrict__ opacities, const float *__restrict__ colors,
     const float *__restrict__ scales, const float *__restrict__ rotations, const float *__restrict__ vm,
     const float *__restrict__ pm, float scale_modifier, const Dims &dm, int v, int i, int32_t *__restrict__ radii,
     uint16_t *__restrict__ rect_out, float *__restrict__ depth_out,
-    float *__restrict__ rec_out, uint32_t *tc)
+    float4 *stg, uint32_t *tc)
 {
     const int64_t idx = (int64_t)v * dm.N + i;
 
@@ -42,7 +44,7 @@ __device__ __forceinline__ void preprocess_one(
     const float vx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
     const float vy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
     const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
-    if (vz <= 0.2f) return;
+    if (vz <= 0.2f) return false;
 
     const float4 q = *reinterpret_cast<const float4 *>(rotations + 4 * i);
     const float r = q.x, x = q.y, y = q.z, z = q.w;
@@ -77,13 +79,13 @@ __device__ __forceinline__ void preprocess_one(
     float nvy = vm[1] * nn[0] + vm[5] * nn[1] + vm[9] * nn[2];
     float nvz = vm[2] * nn[0] + vm[6] * nn[1] + vm[10] * nn[2];
     const float cs = -((vx * nvx + vy * nvy) + vz * nvz);
-    if (cs == 0.0f) return;
+    if (cs == 0.0f) return false;
     const float mult = cs > 0.0f ? 1.0f : -1.0f;
     nvx = mult * nvx; nvy = mult * nvy; nvz = mult * nvz;
 
     const float t0 = kCutoff * kCutoff, t1 = kCutoff * kCutoff, t2 = -1.0f;
     const float d = (t0 * (Tw[0] * Tw[0]) + t1 * (Tw[1] * Tw[1])) + t2 * (Tw[2] * Tw[2]);
-    if (d == 0.0f) return;
+    if (d == 0.0f) return false;
     const float inv = 1.0f / d;
     const float f0 = inv * t0, f1 = inv * t1, f2 = inv * t2;
     const float cx = (f0 * (Tu[0] * Tw[0]) + f1 * (Tu[1] * Tw[1])) + f2 * (Tu[2] * Tw[2]);
@@ -97,7 +99,7 @@ __device__ __forceinline__ void preprocess_one(
     const int rminy = min(dm.gy, max(0, f2i((cy - radius) / kTile)));
     const int rmaxx = min(dm.gx, max(0, f2i((cx + radius + kTile - 1) / kTile)));
     const int rmaxy = min(dm.gy, max(0, f2i((cy + radius + kTile - 1) / kTile)));
-    if ((rmaxx - rminx) * (rmaxy - rminy) == 0) return;
+    if ((rmaxx - rminx) * (rmaxy - rminy) == 0) return false;
 
     radii[idx] = f2i(radius);
     depth_out[idx] = vz;
@@ -146,7 +148,7 @@ __device__ __forceinline__ void preprocess_one(
     // fp16, rounded towards +inf (a value beyond the fp16 range becomes +inf = no bound)
     const uint32_t cull = (uint32_t)__half_as_ushort(__float2half_ru(rx)) |
                           ((uint32_t)__half_as_ushort(__float2half_ru(ry)) << 16);
-    float4 *rec = reinterpret_cast<float4 *>(rec_out + (size_t)idx * kRec);
+    float4 *rec = stg;
     rec[0] = make_float4(Ax, Ay, Bx, By);
     rec[1] = make_float4(Cx, Cy, Az, Bz);
     rec[2] = make_float4(cx, cy, Cz, opa);
@@ -156,6 +158,7 @@ __device__ __forceinline__ void preprocess_one(
 
     for (int ty = rminy; ty < rmaxy; ++ty)
         for (int tx = rminx; tx < rmaxx; ++tx) atomicAdd(tc + ty * dm.gx + tx, 1u);
+    return true;
 }
 
 // One workgroup = 256 threads x kPreSplats consecutive Gaussians of ONE view (blockIdx.y).  Tile occupancy is
@@ -172,6 +175,10 @@ __global__ __launch_bounds__(256) void surfel_preprocess_kernel(
     float *__restrict__ rec_out, uint32_t *__restrict__ tile_count)
 {
     extern __shared__ uint32_t hist[];
+    // Records leave through LDS: a lane's record is 96 contiguous bytes, so direct stores would be six 16-byte pieces
+    // at a 96-byte stride per instruction (partial lines); the wave's 64 records are one contiguous 6 KiB block, written
+    // with six fully coalesced 1 KiB stores instead.
+    __shared__ __attribute__((aligned(16))) float4 stage[256 * (kRec / 4)];
     const int v = blockIdx.y;
     if (kLds) {
         for (int t = threadIdx.x; t < dm.tiles; t += 256) hist[t] = 0;
@@ -179,11 +186,24 @@ __global__ __launch_bounds__(256) void surfel_preprocess_kernel(
     }
     const float *vm = viewmatrix + 16 * v, *pm = projmatrix + 16 * v;
     uint32_t *tcg = tile_count + (size_t)v * dm.tiles;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 *wstage = stage + wave * 64 * (kRec / 4);
     for (int k = 0; k < kPreSplats; ++k) {
         const int i = (blockIdx.x * kPreSplats + k) * 256 + threadIdx.x;
+        bool live = false;
         if (i < dm.N)
-            preprocess_one<kLds>(means3D, opacities, colors, scales, rotations, vm, pm, scale_modifier, dm, v, i, radii,
-                                 rect_out, depth_out, rec_out, kLds ? hist : tcg);
+            live = preprocess_one<kLds>(means3D, opacities, colors, scales, rotations, vm, pm, scale_modifier, dm, v, i, radii,
+                                        rect_out, depth_out, wstage + lane * (kRec / 4), kLds ? hist : tcg);
+        if (__builtin_amdgcn_ballot_w64(live) != 0) {  // wave-uniform; records of culled lanes are never read
+            const int first = i - lane;                                    // first Gaussian of this wave
+            const int nq = min(64, dm.N - first) * (kRec / 4);             // float4s inside the array
+            float4 *dst = reinterpret_cast<float4 *>(rec_out + ((size_t)v * dm.N + first) * kRec);
+#pragma unroll
+            for (int j = 0; j < kRec / 4; ++j) {
+                const int q = lane + 64 * j;
+                if (q < nq) dst[q] = wstage[q];
+            }
+        }
     }
     if (kLds) {
         __syncthreads();
