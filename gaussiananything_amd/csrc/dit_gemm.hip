@@ -221,120 +221,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
     gemm_epilogue<EPI, MT>(p, acc, m0, n0, wn, wm, lane);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Register-FIFO variant.  The LDS-DMA ring above holds at most 3 K-tiles in flight per CU (~74 KiB); with ~1.1 us from
-// issue to arrival that caps a workgroup at ~68 GB/s = one K-tile per 0.36 us, three times the tile's MFMA time (sweep
-// in tools/gemm_sweep.py: 8 us fixed + 6 us per 1024 of K at M = 1536).  Bytes in flight are what is missing and the
-// register file is the big buffer of a CU (512 KiB vs 160 KiB of LDS): here every wave keeps D K-tiles of its share of
-// the operands in flight in VGPRs (global_load_dwordx4, (4 + MT) x 4 registers per tile), drops tile t into one of two
-// LDS buffers when it arrives (the XOR swizzle moves from the DMA source to the ds_write address) and re-issues the
-// registers for tile t + D.  One barrier per K-tile: a wave writes buffer (t+1)&1 while others still read buffer t&1.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in registers (HIP's uint4 is a struct)
-
-template <int EPI, int D, int MT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_rf_kernel(GemmP p)
-{
-    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];  // [2][W | A][row][slot]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 1, wm = wave & 1;
-    constexpr int BMT = 2 * MT * 16;
-    constexpr int SLOT = (BN + BMT) * BK;
-    constexpr int LPT = 4 + MT;  // loads per wave per K-tile
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BMT;
-    const int M = p.M, N = p.N, K = p.K;
-
-    // load i of wave w covers rows (w*4+i)*8 .. +7 (W) / (w*MT+i)*8 .. +7 (A): lane -> row + (lane>>3), 16-byte chunk lane&7
-    const u32x4 *src[LPT];
-    int dst[LPT];  // byte offset inside a buffer, swizzled: chunk c of row r sits at slot c ^ (r & 7)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + (lane >> 3);
-        src[i] = reinterpret_cast<const u32x4 *>(p.W + (size_t)min(n0 + row, N - 1) * K + (lane & 7) * 8);
-        dst[i] = (row * BK + (((lane & 7) ^ (row & 7)) * 8)) * 2;
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int row = (wave * MT + i) * 8 + (lane >> 3);
-        src[4 + i] = reinterpret_cast<const u32x4 *>(p.A + (size_t)min(m0 + row, M - 1) * p.lda + (lane & 7) * 8);
-        dst[4 + i] = (TILE_ELEMS + row * BK + (((lane & 7) ^ (row & 7)) * 8)) * 2;
-    }
-    f32x4 acc[4][MT];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15, g = lane >> 4;
-    const int nk = K / BK;
-
-    u32x4 fifo0[LPT], fifo1[LPT], fifo2[LPT], fifo3[LPT], fifo4[LPT], fifo5[LPT], fifo6[LPT], fifo7[LPT];  // sets >= D stay unused
-#define GA_ISSUE(SET, KT)                                                                             \
-    do {                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < LPT; ++i) fifo##SET[i] = src[i][(size_t)(KT) * (BK / 8)]; \
-    } while (0)
-#define GA_DROP(SET, BUF)                                                                             \
-    do {                                                                                              \
-        char *b_ = reinterpret_cast<char *>(smem) + (BUF) * SLOT * 2;                                  \
-        _Pragma("unroll") for (int i = 0; i < LPT; ++i) *reinterpret_cast<u32x4 *>(b_ + dst[i]) = fifo##SET[i]; \
-    } while (0)
-#define GA_COMPUTE(BUF)                                                                               \
-    do {                                                                                              \
-        const uint16_t *bw_ = smem + (BUF) * SLOT, *ba_ = bw_ + TILE_ELEMS;                            \
-        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                            \
-            bf16x8 fw[4], fa[MT];                                                                     \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
-                const int rw = wn * 64 + i * 16 + frow;                                               \
-                fw[i] = *reinterpret_cast<const bf16x8 *>(bw_ + rw * BK + (((kk * 4 + g) ^ (rw & 7)) * 8)); \
-            }                                                                                         \
-            _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                          \
-                const int ra = wm * (MT * 16) + i * 16 + frow;                                        \
-                fa[i] = *reinterpret_cast<const bf16x8 *>(ba_ + ra * BK + (((kk * 4 + g) ^ (ra & 7)) * 8)); \
-            }                                                                                         \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
-                _Pragma("unroll") for (int j = 0; j < MT; ++j)                                        \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0); \
-        }                                                                                             \
-    } while (0)
-#define GA_PHASE(SET, KT)                                                                             \
-    do {                                                                                              \
-        GA_DROP(SET, (KT) & 1);           /* waits for tile KT only: the younger loads stay in flight */ \
-        GA_ISSUE(SET, min((KT) + D, nk - 1)); /* unconditional: see below */                           \
-        __syncthreads();                  /* tile KT is in LDS; everyone has left tile KT-1's buffer */ \
-        GA_COMPUTE((KT) & 1);                                                                          \
-    } while (0)
-
-    // Requires nk % D == 0 (host-checked).  The loop body is branch-free on purpose: hipcc's wait-count insertion only
-    // keeps the younger loads in flight (vmcnt(N > 0) in front of the LDS writes) when the order of the outstanding loads is
-    // the same on every path into the loop; with conditional issues it drains everything (vmcnt(0)) every tile.  The
-    // tail therefore re-loads the last tile into sets that are never consumed.
-    GA_ISSUE(0, 0);
-    GA_ISSUE(1, 1);
-    if (D > 2) GA_ISSUE(2, 2);
-    if (D > 3) GA_ISSUE(3, 3);
-    if (D > 4) GA_ISSUE(4, 4);
-    if (D > 5) GA_ISSUE(5, 5);
-    if (D > 6) GA_ISSUE(6, 6);
-    if (D > 7) GA_ISSUE(7, 7);
-    // 16 K-tiles per trip, straight-line: the wait-count pass drains all loads at a loop back-edge, which costs one
-    // exposed load latency per trip (none at all for K = 1024)
-    for (int kt0 = 0; kt0 < nk; kt0 += 16)
-#pragma unroll
-    for (int kt = kt0; kt < kt0 + 16; kt += D) {
-        GA_PHASE(0, kt);
-        GA_PHASE(1, kt + 1);
-        if (D > 2) GA_PHASE(2, kt + 2);
-        if (D > 3) GA_PHASE(3, kt + 3);
-        if (D > 4) GA_PHASE(4, kt + 4);
-        if (D > 5) GA_PHASE(5, kt + 5);
-        if (D > 6) GA_PHASE(6, kt + 6);
-        if (D > 7) GA_PHASE(7, kt + 7);
-    }
-#undef GA_PHASE
-#undef GA_COMPUTE
-#undef GA_DROP
-#undef GA_ISSUE
-    gemm_epilogue<EPI, MT>(p, acc, m0, n0, wn, wm, lane);
-}
+// A register-FIFO variant of this kernel (global_load_dwordx4 into D = 4 / 8 K-tiles of VGPRs, ds_write into a double
+// buffer) was built and measured in round 1 to test whether more bytes in flight would lift the small-M GEMMs: it does
+// not (N = 4096: 46 us vs 29 us; deeper FIFOs slower still).  PMC (tools/pmc_gemm.sh): L1->L2 read latency averages
+// 320 cycles and the L1 streams ~25 B/clk/CU, far below its 64 B/clk port -- the miss path of the L1, not the prefetch
+// depth, caps these tiles, so only more reuse per byte (larger workgroup tiles on grids that still fill the chip) helps.
 
 }  // namespace gadit
 
@@ -363,7 +254,7 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
     //   <= 128 (the N = 1024 GEMMs at M=1536) -> 64-row tiles, 4-slot ring (96 KiB): twice the workgroups
     const long long wg128 = (long long)((a->N + BN - 1) / BN) * ((a->M + 127) / 128);
     int cfg = wg128 > 256 ? 0 : (wg128 > 128 ? 1 : 2);
-    if (const char *e = getenv("GA_GEMM_CFG")) cfg = atoi(e);  // tuning aid
+    if (const char *e = getenv("GA_GEMM_CFG")) cfg = atoi(e) % 3;  // tuning aid
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KiB of dynamic LDS has to be opted into once per kernel
 #define GA_ATTR(E)                                                                                                  \
@@ -385,30 +276,6 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
     else                                                                                                           \
         hipLaunchKernelGGL((gemm_bf16_kernel<E, 4, 2>), dim3((a->N + BN - 1) / BN, (a->M + 63) / 64), dim3(256),    \
                            4 * (BN + 64) * BK * 2, s, p);
-#define GA_LAUNCH_RF(E)                                                                                            \
-    if (cfg == 3)                                                                                                  \
-        hipLaunchKernelGGL((gemm_bf16_rf_kernel<E, 4, 4>), dim3((a->N + BN - 1) / BN, (a->M + 127) / 128), dim3(256), \
-                           2 * (BN + 128) * BK * 2, s, p);                                                          \
-    else if (cfg == 4)                                                                                             \
-        hipLaunchKernelGGL((gemm_bf16_rf_kernel<E, 8, 4>), dim3((a->N + BN - 1) / BN, (a->M + 127) / 128), dim3(256), \
-                           2 * (BN + 128) * BK * 2, s, p);                                                          \
-    else if (cfg == 5)                                                                                             \
-        hipLaunchKernelGGL((gemm_bf16_rf_kernel<E, 4, 2>), dim3((a->N + BN - 1) / BN, (a->M + 63) / 64), dim3(256),  \
-                           2 * (BN + 64) * BK * 2, s, p);                                                           \
-    else                                                                                                           \
-        hipLaunchKernelGGL((gemm_bf16_rf_kernel<E, 8, 2>), dim3((a->N + BN - 1) / BN, (a->M + 63) / 64), dim3(256),  \
-                           2 * (BN + 64) * BK * 2, s, p);
-    if (cfg >= 3 && (a->K / BK) % ((cfg == 4 || cfg == 6) ? 8 : 4) != 0) cfg = wg128 > 256 ? 0 : (wg128 > 128 ? 1 : 2);
-    if (cfg >= 3) {
-        switch (a->epilogue) {
-        case GA_GEMM_EPI_STORE_BF16: GA_LAUNCH_RF(0) break;
-        case GA_GEMM_EPI_GELU_BF16: GA_LAUNCH_RF(1) break;
-        case GA_GEMM_EPI_RESIDUAL: GA_LAUNCH_RF(2) break;
-        case GA_GEMM_EPI_STORE_F32: GA_LAUNCH_RF(3) break;
-        default: return GA_DIT_ERR_BAD_SHAPE;
-        }
-        return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
-    }
     switch (a->epilogue) {
     case GA_GEMM_EPI_STORE_BF16: GA_LAUNCH(0) break;
     case GA_GEMM_EPI_GELU_BF16: GA_LAUNCH(1) break;

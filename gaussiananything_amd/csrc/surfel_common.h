@@ -26,7 +26,10 @@ constexpr float kCutoff = 3.0f;
 constexpr float kFilterSize = 0.707106f;
 constexpr float kFilterInvSquare = 2.0f;
 
-constexpr int kBinSplats = 8;           // splats per thread in the fill kernel (2048 per workgroup)
+#ifndef GA_BIN_SPLATS
+#define GA_BIN_SPLATS 8
+#endif
+constexpr int kBinSplats = GA_BIN_SPLATS;           // splats per thread in the fill kernel (2048 per workgroup)
 #ifndef GA_PRE_SPLATS
 #define GA_PRE_SPLATS 2
 #endif

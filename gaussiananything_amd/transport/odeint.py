@@ -15,6 +15,8 @@ promoted to fp32 by the first update, because the model returns fp32: dit_i23d.p
 from __future__ import annotations
 
 import math
+import os
+import warnings
 
 import torch
 
@@ -58,6 +60,44 @@ _C_ERR = [35 / 384 - 1951 / 21600, 0, 500 / 1113 - 22642 / 50085, 125 / 192 - 45
           -2187 / 6784 - -12231 / 42400, 11 / 84 - 649 / 6300, -1.0 / 60.0]
 _C_MID = [6025192743 / 30085553152 / 2, 0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
           187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2]
+
+
+_EVALS = {"euler": 1, "midpoint": 2, "heun2": 2, "heun3": 3, "rk4": 4}
+
+
+def _fixed_grid_graph(method, func, y, tt, out):
+    """Fixed-grid integration with ONE step captured into a HIP graph and replayed per grid interval.
+
+    A function evaluation of the DiT is ~290 kernel launches; enqueued from Python/ctypes one by one the GPU idles ~9 % of
+    the time between them (rocprofv3: 4.83 ms of kernels in a 5.29 ms step).  The step reads its time and step size from
+    two device scalars that are refreshed (device-to-device, asynchronously) before every replay, so nothing is baked
+    into the graph; the state is advanced in place.  For ``euler`` the arithmetic is identical to the eager loop; the
+    multi-stage methods form their intermediate times in fp32 on the device instead of fp64 on the host."""
+    dev = y.device
+    t_dev = torch.tensor(tt[:-1], dtype=torch.float32, device=dev)
+    dt_dev = torch.tensor([b - a for a, b in zip(tt[:-1], tt[1:])], dtype=torch.float32, device=dev)
+    t_cur, dt_cur = torch.zeros((), device=dev), torch.zeros((), device=dev)
+    y_st = y.clone()
+
+    def ff(ts, yy):
+        return func(ts, yy).float()
+
+    cur = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):  # warm-up outside the capture: lazy initialisation, workspace sizing, K/V caches
+        t_cur.copy_(t_dev[0])
+        dt_cur.copy_(dt_dev[0])
+        _rk_fixed(method, ff, t_cur, dt_cur, t_cur + dt_cur, y_st)
+    cur.wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y_st.add_(_rk_fixed(method, ff, t_cur, dt_cur, t_cur + dt_cur, y_st))
+    for j in range(1, len(tt)):
+        t_cur.copy_(t_dev[j - 1])
+        dt_cur.copy_(dt_dev[j - 1])
+        graph.replay()
+        out[j].copy_(y_st)
 
 
 def _rms(x):
@@ -113,6 +153,18 @@ def odeint(func, y0, t, method="dopri5", atol=1e-6, rtol=1e-3, stats=None):
         return func(torch.tensor(ts, dtype=torch.float32, device=dev), yy).float()
 
     if method in FIXED:
+        if dev.type == "cuda" and len(tt) > 4 and os.environ.get("GA_ODE_GRAPH", "1") != "0":
+            try:
+                _fixed_grid_graph(method, func, y, tt, out)
+                if stats is not None:
+                    stats.update(nfe=(len(tt) - 1) * _EVALS[method], steps=len(tt) - 1, rejected=0, graph=True)
+                return out
+            except Exception as e:  # capture refused (a host synchronisation inside ``func``, ...): eager loop below
+                if os.environ.get("GA_ODE_GRAPH") == "1":
+                    raise
+                warnings.warn(f"ODE step could not be captured into a HIP graph ({type(e).__name__}: {e}); running eagerly")
+                y = y0.float()
+                out[0] = y
         for j in range(1, len(tt)):
             t0, t1 = tt[j - 1], tt[j]
             y = y + _rk_fixed(method, f, t0, t1 - t0, t1, y)

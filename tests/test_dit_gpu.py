@@ -221,3 +221,24 @@ def test_cpu_tensors_raise(gpu_device):
     z, model, ctx = _load_golden(1, gpu_device)
     with pytest.raises(RuntimeError):
         model(z["x"], z["t"], {k: v.cpu() for k, v in ctx.items()})
+
+
+@pytest.mark.parametrize("method", ["euler", "heun2"])
+def test_sampler_graph_replay_equals_eager_loop(gpu_device, method, monkeypatch):
+    """The fixed-grid sampler captures one step into a HIP graph and replays it; the eager Python loop (GA_ODE_GRAPH=0)
+    is the reference for it.  Euler is the same arithmetic (bit-identical); heun2 forms t1 in fp32 on the device."""
+    from gaussiananything_amd.transport import Sampler, create_transport
+    z, model, ctx = _load_golden(1, gpu_device)
+    x = z["x"].to(gpu_device)
+    sampler = Sampler(create_transport("GVP", "velocity", None, None, None, snr_type="uniform"))
+    outs = {}
+    for flag in ("0", "1"):   # "1": a refused capture raises instead of silently falling back
+        monkeypatch.setenv("GA_ODE_GRAPH", flag)
+        fn = sampler.sample_ode(sampling_method=method, num_steps=7)
+        with torch.no_grad():
+            outs[flag] = fn(x, model.forward_with_cfg, context=ctx, cfg_scale=z["cfg_scale"])
+    assert outs["1"].shape == (7,) + tuple(x.shape)
+    if method == "euler":
+        assert torch.equal(outs["0"], outs["1"])
+    else:
+        assert rel_l2(outs["1"], outs["0"]) < 1e-5
