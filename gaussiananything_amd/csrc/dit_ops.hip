@@ -21,32 +21,39 @@ __global__ __launch_bounds__(256) void rmsnorm_modulate_kernel(GaRmsNormArgs a)
     if (row >= a.M) return;
     const int D = a.D;
     const float *x = a.x + (size_t)row * D;
-    float4 v[8];  // D <= 2048, D % 4 == 0: lane owns the float4 at d = c*256 + lane*4 of every 256-wide chunk c
-    float ss = 0.f;
+    // D <= 2048, D % 4 == 0: lane owns the float4 at d = c*256 + lane*4 of every 256-wide chunk c.  Everything the row
+    // needs (x, norm weight, scale, shift) is requested up front: the kernel is one memory round trip plus a wave sum.
+    const int b = row / a.rows_per_batch;
+    const float *sc = a.scale ? a.scale + (size_t)b * a.mod_stride : nullptr;
+    const float *sh = a.shift ? a.shift + (size_t)b * a.mod_stride : nullptr;
+    float4 v[8], w[8], s4[8], h4[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int d = c * 256 + lane * 4;
         if (d < D) {
             v[c] = *reinterpret_cast<const float4 *>(x + d);
-            ss += v[c].x * v[c].x + v[c].y * v[c].y + v[c].z * v[c].z + v[c].w * v[c].w;
+            w[c] = *reinterpret_cast<const float4 *>(a.weight + d);
+            if (sc) {
+                s4[c] = *reinterpret_cast<const float4 *>(sc + d);
+                h4[c] = *reinterpret_cast<const float4 *>(sh + d);
+            }
         }
     }
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (c * 256 + lane * 4 < D) ss += v[c].x * v[c].x + v[c].y * v[c].y + v[c].z * v[c].z + v[c].w * v[c].w;
     ss = wave_sum(ss);
     const float rs = rsqrtf(ss / (float)D + 1e-5f);
-    const int b = row / a.rows_per_batch;
-    const float *sc = a.scale ? a.scale + (size_t)b * a.mod_stride : nullptr;
-    const float *sh = a.shift ? a.shift + (size_t)b * a.mod_stride : nullptr;
     uint16_t *o = a.out + (size_t)row * D;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int d = c * 256 + lane * 4;
         if (d < D) {
-            const float4 w = *reinterpret_cast<const float4 *>(a.weight + d);
-            float y[4] = {v[c].x * rs * w.x, v[c].y * rs * w.y, v[c].z * rs * w.z, v[c].w * rs * w.w};
+            float y[4] = {v[c].x * rs * w[c].x, v[c].y * rs * w[c].y, v[c].z * rs * w[c].z, v[c].w * rs * w[c].w};
             if (sc) {
-                const float4 s4 = *reinterpret_cast<const float4 *>(sc + d), h4 = *reinterpret_cast<const float4 *>(sh + d);
-                y[0] = y[0] * (1.f + s4.x) + h4.x; y[1] = y[1] * (1.f + s4.y) + h4.y;
-                y[2] = y[2] * (1.f + s4.z) + h4.z; y[3] = y[3] * (1.f + s4.w) + h4.w;
+                y[0] = y[0] * (1.f + s4[c].x) + h4[c].x; y[1] = y[1] * (1.f + s4[c].y) + h4[c].y;
+                y[2] = y[2] * (1.f + s4[c].z) + h4[c].z; y[3] = y[3] * (1.f + s4[c].w) + h4[c].w;
             }
             *reinterpret_cast<uint2 *>(o + d) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
         }
