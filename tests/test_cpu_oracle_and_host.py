@@ -227,3 +227,17 @@ def test_shard_samples_partition():
         parts = [shard_samples(n, r, w) for r in range(w)]
         assert sorted(sum(parts, [])) == list(range(n))
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_decode_oracle_matches_reference_golden():
+    """oracle/decode.py against outputs of the reference's own surfel-decode classes / methods
+    (tests/golden/make_decode_golden.py): all four Gaussian levels and the decoder features, exactly."""
+    import torch
+    from gaussiananything_amd import synthetic
+    from oracle import decode as od
+    z = torch.load(synthetic.fixture_path("decode_ref.pt"))
+    out = od.decode(z["state_dict"], z["latent"], z["xyz"])
+    for k in ("latent_from_vit", "gaussians_base", "gaussians_upsampled", "gaussians_upsampled_2", "gaussians_upsampled_3"):
+        assert out[k].shape == z[k].shape
+        assert float((out[k] - z[k]).abs().max()) <= 1e-6, k
+    assert out["gaussians_upsampled_3"].shape[1] == z["latent"].shape[1] * 8 * 4 * 3
