@@ -116,45 +116,79 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(GaAssembleArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// One wave per (group, head); lane = head dimension.  S*S scores are wave sums, the softmax and the S*S weighted sums of
-// V are lane-local.  At S = 4 ... 9 this is a few hundred instructions per wave and the kernel streams qkv once.
+// Tiny-sequence attention on the matrix cores.  One wave per (head, tile of G = 16 / S whole groups): the tile's <= 16
+// rows are both the queries and the keys of ONE 16x16 score block, attention between different groups is masked out
+// (block-diagonal), so 4 groups of 4 / 3 groups of 5 / 1 group of 9 rows cost two v_mfma_f32_16x16x32_bf16 for the
+// scores and four for P V.  The layout follows dit_attention.hip: the swapped product S^T = K Q^T leaves query c in
+// lanes {c, c+16, c+32, c+48} with four keys each, so the softmax needs two xor-shuffles, and those four probabilities
+// ARE the lane's B-operand of O^T = V^T P^T (keys 4g..4g+3 of the k-block, the other 28 k-slots are zero) -- P never
+// moves.  V^T fragments are gathered straight from global memory (4 bf16 per lane and 16-wide d block; the lines are
+// shared by the whole wave).  The first version (one wave per (group, head), lane = head dimension, S^2 wave sums)
+// took 272 us per call at the release sizes.
 __global__ __launch_bounds__(256) void tiny_attention_kernel(GaTinyAttentionArgs a)
 {
-    const long long gh = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (gh >= (long long)a.groups * a.heads) return;
-    const int grp = (int)(gh / a.heads), h = (int)(gh - (long long)grp * a.heads);
-    const int S = a.S, C = a.heads * 64;
-    const uint16_t *base = a.qkv + (size_t)grp * S * 3 * C + h * 64 + lane;
-    float q[16], k[16], v[16];
+    const int S = a.S, G = 16 / S, C = a.heads * 64;
+    const long long ntile = (a.groups + G - 1) / G;
+    const long long wt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wt >= ntile * a.heads) return;
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const long long tile = wt / a.heads;
+    const int h = (int)(wt - tile * a.heads);
+    const long long row0 = tile * G * S;
+    const int nrow = (int)min((long long)G, a.groups - tile * G) * S;   // valid rows of this tile
+    const uint16_t *base = a.qkv + (size_t)row0 * 3 * C + h * 64;
+    const int rc = min(c, nrow - 1);                                      // padding rows re-read a valid one
+    // S^T = K Q^T: A = K rows (key = lane & 15), B = Q rows (query = lane & 15), k-chunk (lane >> 4) * 8 of each 32
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (i < S) {
-            const uint16_t *r = base + (size_t)i * 3 * C;
-            q[i] = bf16_to_f32(r[0]);
-            k[i] = bf16_to_f32(r[C]);
-            v[i] = bf16_to_f32(r[2 * C]);
+    for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 qf = *reinterpret_cast<const bf16x8 *>(base + (size_t)rc * 3 * C + kk * 32 + g * 8);
+        const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(base + (size_t)rc * 3 * C + C + kk * 32 + g * 8);
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, s, 0, 0, 0);
+    }
+    // lane (g, c): s[r] = score(query c, key 4g + r); keys of another group or past the tile are masked
+    const int qgrp = c / S;
+    float p[4], mx = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int key = 4 * g + r;
+        const bool ok = key < nrow && key / S == qgrp;
+        p[r] = ok ? s[r] * 0.125f : -1e30f;
+        mx = fmaxf(mx, p[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float den = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        p[r] = p[r] > -1e29f ? __expf(p[r] - mx) : 0.f;
+        den += p[r];
+    }
+    den += __shfl_xor(den, 16, 64);
+    den += __shfl_xor(den, 32, 64);
+    const float inv = 1.0f / den;
+    bf16x8 pf;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        pf[r] = (short)f32_to_bf16(p[r] * inv);
+        pf[4 + r] = 0;
+    }
+    // O^T = V^T P^T per 16-wide d block: A = V^T rows (d = db*16 + (lane & 15)), k-slot e <-> key 16*(e>>2) + 4g + (e&3)
+    const uint16_t *vb = base + 2 * C;
+    uint16_t *out = a.out + (size_t)(row0 + c) * C + h * 64 + 4 * g;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        bf16x8 vf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = min(4 * g + r, nrow - 1);        // its probability is zero when it is padding
+            vf[r] = (short)vb[(size_t)key * 3 * C + db * 16 + c];
+            vf[4 + r] = 0;
         }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        if (i < S) {
-            float sc[16], mx = -1e30f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (j < S) {
-                    sc[j] = wave_sum(q[i] * k[j]) * 0.125f;
-                    mx = fmaxf(mx, sc[j]);
-                }
-            float den = 0.f, o = 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (j < S) {
-                    const float pj = __expf(sc[j] - mx);
-                    den += pj;
-                    o += pj * v[j];
-                }
-            a.out[((size_t)grp * S + i) * C + h * 64 + lane] = f32_to_bf16(o / den);
-        }
+        f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        // lane (g, c): o[r] = O[query c][d = db*16 + 4g + r]
+        if (c < nrow)
+            *reinterpret_cast<uint2 *>(out + db * 16) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
     }
 }
 
@@ -257,7 +291,7 @@ extern "C" int ga_tiny_attention(const GaTinyAttentionArgs *a, void *stream)
 {
     if (!a || !a->qkv || !a->out) return GA_DIT_ERR_NULL_ARG;
     if (a->groups < 0 || a->S < 1 || a->S > 16 || a->heads < 1) return GA_DIT_ERR_BAD_SHAPE;
-    GA_LAUNCH_ROWS(tiny_attention_kernel, (long long)a->groups * a->heads, a, stream);
+    GA_LAUNCH_ROWS(tiny_attention_kernel, (long long)((a->groups + 16 / a->S - 1) / (16 / a->S)) * a->heads, a, stream);
 }
 
 extern "C" int ga_surfel_head(const GaSurfelHeadArgs *a, void *stream)
