@@ -205,22 +205,49 @@ __global__ __launch_bounds__(256) void surfel_head_kernel(GaSurfelHeadArgs a)
         xr = p * (1 + a.f) + 1 + (row - p * a.f);
     }
     const float *x = a.x + xr * D;
+    // the row lives in registers (float4 at d = c*256 + lane*4, D <= 2048): one pass over HBM
+    float4 v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (c * 256 + lane * 4 < D) v[c] = *reinterpret_cast<const float4 *>(x + c * 256 + lane * 4);
     float mean = 0.f, rs = 1.f;
     if (a.mode == 1) {
         float s = 0.f;
-        for (int d = lane; d < D; d += 64) s += x[d];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c * 256 + lane * 4 < D) s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
         mean = wave_sum(s) / (float)D;
         float q = 0.f;
-        for (int d = lane; d < D; d += 64) { const float e = x[d] - mean; q += e * e; }
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c * 256 + lane * 4 < D) {
+                const float e0 = v[c].x - mean, e1 = v[c].y - mean, e2 = v[c].z - mean, e3 = v[c].w - mean;
+                q += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+            }
         rs = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
     }
     float acc[13];
 #pragma unroll
     for (int c = 0; c < 13; ++c) acc[c] = 0.f;
-    for (int d = lane; d < D; d += 64) {
-        const float y = a.mode == 1 ? (x[d] - mean) * rs * a.ln_weight[d] + a.ln_bias[d] : silu_f(x[d]);
 #pragma unroll
-        for (int c = 0; c < 13; ++c) acc[c] += y * a.w[(size_t)c * D + d];
+    for (int c = 0; c < 8; ++c) {
+        const int d = c * 256 + lane * 4;
+        if (d < D) {
+            float y[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
+            if (a.mode == 1) {
+                const float4 lw = *reinterpret_cast<const float4 *>(a.ln_weight + d), lb = *reinterpret_cast<const float4 *>(a.ln_bias + d);
+                y[0] = (y[0] - mean) * rs * lw.x + lb.x; y[1] = (y[1] - mean) * rs * lw.y + lb.y;
+                y[2] = (y[2] - mean) * rs * lw.z + lb.z; y[3] = (y[3] - mean) * rs * lw.w + lb.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = silu_f(y[e]);
+            }
+#pragma unroll
+            for (int o = 0; o < 13; ++o) {
+                const float4 w4 = *reinterpret_cast<const float4 *>(a.w + (size_t)o * D + d);
+                acc[o] += (y[0] * w4.x + y[1] * w4.y) + (y[2] * w4.z + y[3] * w4.w);
+            }
+        }
     }
     float pre[13];
 #pragma unroll
@@ -298,6 +325,6 @@ extern "C" int ga_surfel_head(const GaSurfelHeadArgs *a, void *stream)
 {
     if (!a || !a->x || !a->w || !a->b || !a->anchor || !a->gaussians || !a->pre_out) return GA_DIT_ERR_NULL_ARG;
     if (a->mode == 1 && (!a->ln_weight || !a->ln_bias || !a->base_pre || a->f < 1 || a->rows % a->f)) return GA_DIT_ERR_NULL_ARG;
-    if (a->rows < 0 || a->D < 1 || (a->mode != 0 && a->mode != 1)) return GA_DIT_ERR_BAD_SHAPE;
+    if (a->rows < 0 || a->D < 4 || a->D % 4 || a->D > 2048 || (a->mode != 0 && a->mode != 1)) return GA_DIT_ERR_BAD_SHAPE;
     GA_LAUNCH_ROWS(surfel_head_kernel, a->rows, a, stream);
 }
