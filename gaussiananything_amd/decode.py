@@ -84,8 +84,11 @@ class SurfelDecoder(nn.Module):
     output_size = {"gaussians_base": 128, "gaussians_upsampled": 256, "gaussians_upsampled_2": 384,
                    "gaussians_upsampled_3": 512}
 
-    def __init__(self, embed_dim=768, depth=12, num_heads=12, tokens=768, ldm_z_channels=10):
+    rand_base_render = True   # the cascaded decoder renders one random coarse level + the finest unless asked for all
+
+    def __init__(self, embed_dim=768, depth=12, num_heads=12, tokens=768, ldm_z_channels=10, triplane_decoder=None):
         super().__init__()
+        self.gs = triplane_decoder  # a GaussianRenderer2DGS (no parameters); only triplane_decode needs it
         if embed_dim % 64 or embed_dim // num_heads != 64:
             raise ValueError("the MI355X attention kernels are built for head_dim 64 (DiT2-B/2: 12 heads of 64)")
         self.embed_dim, self.ldm_z_channels = embed_dim, ldm_z_channels
@@ -207,6 +210,27 @@ class SurfelDecoder(nn.Module):
         ret_after_decoder.update({"pos": ret_after_decoder["gaussians"][..., :3],
                                   "gaussians_base_opa": ret_after_decoder["gaussians_base"][..., 3:4]})
         return ret_after_decoder
+
+    def triplane_decode(self, ret_after_gaussian_forward, c, bg_color=None, render_all_scale=False, **kwargs):
+        """vit_triplane.py:1550-1591: render every level at its own resolution (128 / 256 / 384 / 512) for the cameras in
+        ``c`` ({cam_view, cam_view_proj [B,V,4,4], cam_pos [B,V,3], tanfov}); all V views of a level are one rasterizer
+        call per batch item."""
+        if self.gs is None:
+            from .gs_surfel import GaussianRenderer2DGS
+            self.gs = GaussianRenderer2DGS(output_size=512, out_chans=3, rendering_kwargs={})
+        keys = list(self.output_size.keys())
+        if self.rand_base_render and not render_all_scale:
+            import random
+            keys = [random.choice(keys[:-1])] + [keys[-1]]
+        out = {}
+        for key in keys:
+            res = self.gs.render(ret_after_gaussian_forward[key], c["cam_view"], c["cam_view_proj"], c["cam_pos"],
+                                 tanfov=c["tanfov"], bg_color=bg_color, output_size=self.output_size[key])
+            res["image_raw"] = res["image"] * 2 - 1  # [0,1] -> [-1,1]
+            res["image_depth"] = res["depth"]
+            res["image_mask"] = res["alpha"]
+            out[key] = res
+        return out
 
     @torch.no_grad()
     def decode(self, latent_normalized, query_pcd_xyz):

@@ -112,21 +112,31 @@ def test_decode_matches_reference_golden(gpu_device):
     assert torch.equal(out["gaussians"], out["gaussians_upsampled"]) and out["pos"].shape[-1] == 3
 
 
-def test_decoded_surfels_rasterize(gpu_device):
-    """End of the cascade: the finest level goes straight into the rasterizer (same [B, N, 13] layout)."""
+def test_triplane_decode_renders_every_level_like_the_oracle(gpu_device):
+    """End of the cascade (vit_triplane.py:1550-1591): each decoded level rendered at its own resolution; pixels against
+    the CPU raster oracle on the very same surfels (MSE <= 1e-5, the rasterizer's bar)."""
+    import numpy as np
     from gaussiananything_amd import synthetic
     from gaussiananything_amd.decode import SurfelDecoder
-    from gaussiananything_amd.gs_surfel import GaussianRenderer2DGS
+    from tests import _util
     z = torch.load(synthetic.fixture_path("decode_ref.pt"))
     cfg = z["config"]
     model = SurfelDecoder(embed_dim=cfg["D"], depth=cfg["depth"], num_heads=cfg["heads"], tokens=cfg["tokens"],
                           ldm_z_channels=cfg["z_channels"])
     model.load_state_dict(z["state_dict"])
     model.to(gpu_device)
-    g = model.decode(z["latent"].to(gpu_device), z["xyz"].to(gpu_device))["gaussians_upsampled_3"]
+    ret = model.decode(z["latent"][:1].to(gpu_device), z["xyz"][:1].to(gpu_device))
     cams = synthetic.eval_cameras(2)
-    r = GaussianRenderer2DGS(output_size=64, out_chans=3, rendering_kwargs={})
-    res = r.render(g[:1], cams["cam_view"][None, :2].to(gpu_device), cams["cam_view_proj"][None, :2].to(gpu_device),
-                   cams["cam_pos"][None, :2].to(gpu_device), tanfov=cams["tanfov"])
-    assert res["image"].shape == (1, 2, 3, 64, 64) and bool(torch.isfinite(res["image"]).all())
-    assert float(res["alpha"].max()) > 0.0
+    c = {"cam_view": cams["cam_view"][None].to(gpu_device), "cam_view_proj": cams["cam_view_proj"][None].to(gpu_device),
+         "cam_pos": cams["cam_pos"][None].to(gpu_device), "tanfov": cams["tanfov"]}
+    res = model.triplane_decode(ret, c, render_all_scale=True)
+    assert list(res) == ["gaussians_base", "gaussians_upsampled", "gaussians_upsampled_2", "gaussians_upsampled_3"]
+    for key, size in model.output_size.items():
+        img = res[key]["image"]
+        assert img.shape == (1, 2, 3, size, size) and bool(torch.isfinite(img).all())
+        assert torch.equal(res[key]["image_raw"], img * 2 - 1) and res[key]["image_mask"].shape == (1, 2, 1, size, size)
+        o = _util.oracle_view(ret[key][0].cpu(), cams, 1, size, size)
+        mse = float(np.mean((img[0, 1].cpu().numpy() - np.clip(o["color"], 0, 1)) ** 2))
+        assert mse <= 1e-5, (key, mse)
+    sub = model.triplane_decode(ret, c)                   # the reference's default: one random coarse level + the finest
+    assert len(sub) == 2 and "gaussians_upsampled_3" in sub
