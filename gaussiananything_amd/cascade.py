@@ -1,0 +1,56 @@
+"""The cascaded image-to-3D sampling loop around the hot path: what ``FlowMatchingEngine.sample`` and the two sampling
+scripts do between the conditioner and the renderer (/root/reference/nsr/lsgm/flow_matching_trainer.py:700-744 ``sample``;
+:1206-1225 stage hand-off; :1400-1424 ``render_gs_video_given_latent``; shell_scripts/release/inference/i23d/*.sh).
+
+    stage 1  z ~ N(0, I) [S, 768, 3]  --250-step ODE, CFG-->  normalised point cloud;  x 0.164 (``xyz_std``, :987-1000), clipped to
+             +-0.45 when it is read back as the stage-2 condition (:1079)
+    stage 2  z ~ N(0, I) [S, 768, 10], context + {'fps-xyz'}  --250-step ODE, CFG-->  KL latent
+    decode   {latent_normalized, query_pcd_xyz} -> surfels (SurfelDecoder)  ->  triplane_decode -> renders per level
+
+The reference writes the stage-1 cloud to a PLY file and a second script loads it; here the tensor stays on the device.
+Host orchestration only -- every kernel launch is behind the three C-ABI headers.
+"""
+from __future__ import annotations
+
+import torch
+
+from .transport import Sampler, create_transport
+
+XYZ_STD = 0.164  # flow_matching_trainer.py:987
+
+
+@torch.no_grad()
+def sample(model, cond, uc, shape, batch_size=1, cfg_scale=4.0, seed=42, num_steps=250, sampling_method="dopri5",
+           transport_sampler=None, **ode_kwargs):
+    """``FlowMatchingEngine.sample`` (flow_matching_trainer.py:700-744): CPU-seeded noise, CFG batch = [cond | uncond],
+    ``sample_ode(num_steps=250, cfg=True)`` (dopri5 by default, as upstream), last state, conditional half."""
+    if transport_sampler is None:
+        transport_sampler = Sampler(create_transport("GVP", "velocity", None, None, None, snr_type="uniform"))
+    sample_fn = transport_sampler.sample_ode(sampling_method=sampling_method, num_steps=num_steps, cfg=True, **ode_kwargs)
+    dev = next(model.parameters()).device
+    torch.manual_seed(seed)
+    zs = torch.randn(batch_size, *shape).to(dev)
+    c_out = {k: torch.cat((cond[k], uc[k]), 0) for k in cond}
+    zs = torch.cat([zs, zs], 0)
+    samples = sample_fn(zs, model.forward_with_cfg, context=c_out, cfg_scale=cfg_scale)[-1]
+    samples, _ = samples.chunk(2, dim=0)
+    return samples
+
+
+@torch.no_grad()
+def cascade(stage1, stage2, decoder, cond, uc, cameras=None, cfg_scale=4.0, seed=42, num_steps=250,
+            sampling_method="dopri5", render_all_scale=True, **ode_kwargs):
+    """Stage 1 -> stage 2 -> surfel decode (-> renders when ``cameras`` = {cam_view, cam_view_proj [B,V,4,4], cam_pos
+    [B,V,3], tanfov} is given).  ``cond`` / ``uc``: {'img_crossattn' [S,1369,1024], 'img_vector' [S,1024]}."""
+    S = cond["img_crossattn"].shape[0]
+    L = decoder.vit_decoder.pos_embed.shape[1]  # 768 latent tokens in the release (z_shape, flow_matching_trainer.py:1158)
+    xyz = sample(stage1, cond, uc, (L, stage1.in_channels), S, cfg_scale, seed, num_steps, sampling_method, **ode_kwargs)
+    fps_xyz = (xyz * XYZ_STD).clip(-0.45, 0.45)
+    cond2, uc2 = dict(cond), dict(uc)
+    cond2["fps-xyz"] = uc2["fps-xyz"] = fps_xyz
+    latent = sample(stage2, cond2, uc2, (L, stage2.in_channels), S, cfg_scale, seed, num_steps, sampling_method,
+                    **ode_kwargs)
+    ret = decoder.decode(latent, fps_xyz)
+    if cameras is not None:
+        ret["renders"] = decoder.triplane_decode(ret, cameras, render_all_scale=render_all_scale)
+    return ret

@@ -145,7 +145,9 @@ class SurfelDecoder(nn.Module):
         D, H = self.embed_dim, self.vit_decoder.num_heads
         M = B * N
         sc = dops.tiny_mlp_silu(latent.reshape(M, -1).float().contiguous(), *pk["pq"])           # bf16 silu(c) [M, D]
-        x = pk["pos"].unsqueeze(0).expand(B, -1, -1).reshape(M, D).contiguous()                  # fp32 residual stream
+        # fp32 residual stream, updated in place by the GEMM epilogues: a fresh copy (for B = 1 the expand / reshape /
+        # contiguous chain would hand back the parameter's own storage)
+        x = pk["pos"].unsqueeze(0).expand(B, -1, -1).reshape(M, D).clone()
         Lp = (N + 63) // 64 * 64
         for blk in pk["blocks"]:
             mod = ops.gemm(sc, blk["ada_w"], blk["ada_b"], ops.EPI_STORE_F32)                     # [M, 6D] per token

@@ -110,6 +110,13 @@ def test_decode_matches_reference_golden(gpu_device):
         assert rel_l2(got, ref) < 2e-2, (k, rel_l2(got, ref))
         assert float((got[..., :3] - ref[..., :3]).abs().max()) < 4e-3, k
     assert torch.equal(out["gaussians"], out["gaussians_upsampled"]) and out["pos"].shape[-1] == 3
+    # the residual streams are updated in place: a second call must see untouched parameters and give the same surfels
+    again = model.decode(z["latent"].to(gpu_device), z["xyz"].to(gpu_device))
+    assert all(torch.equal(out[k], again[k]) for k in ("gaussians_base", "gaussians_upsampled_3"))
+    assert all(torch.equal(v.cpu(), z["state_dict"][k]) for k, v in model.state_dict().items())
+    one = model.decode(z["latent"][:1].to(gpu_device), z["xyz"][:1].to(gpu_device))      # batch of one: same as row 0
+    assert torch.equal(one["gaussians_upsampled_3"][0], out["gaussians_upsampled_3"][0])
+    assert all(torch.equal(v.cpu(), z["state_dict"][k]) for k, v in model.state_dict().items())
 
 
 def test_triplane_decode_renders_every_level_like_the_oracle(gpu_device):
@@ -140,3 +147,40 @@ def test_triplane_decode_renders_every_level_like_the_oracle(gpu_device):
         assert mse <= 1e-5, (key, mse)
     sub = model.triplane_decode(ret, c)                   # the reference's default: one random coarse level + the finest
     assert len(sub) == 2 and "gaussians_upsampled_3" in sub
+
+
+def test_cascade_equals_its_parts(gpu_device):
+    """stage 1 -> x0.164 / clip -> stage 2 (xyz-conditioned) -> decode -> renders, on the small golden models: the driver
+    must give exactly what the pieces give when called one after the other."""
+    from gaussiananything_amd import cascade, synthetic
+    from gaussiananything_amd.decode import SurfelDecoder
+    from gaussiananything_amd.dit import DiT_I23D_PCD_PixelArt_noclip, DiT_I23D_PCD_PixelArt_noclip_clay_stage2
+    zs = [torch.load(synthetic.fixture_path(f"dit_ref_stage{k}.pt")) for k in (1, 2)]
+    m1 = DiT_I23D_PCD_PixelArt_noclip(**zs[0]["kwargs"])
+    m1.load_state_dict(zs[0]["state_dict"])
+    kw2 = dict(zs[1]["kwargs"], use_pe_cond=True)
+    m2 = DiT_I23D_PCD_PixelArt_noclip_clay_stage2(**kw2)
+    m2.load_state_dict(zs[1]["state_dict"])
+    zd = torch.load(synthetic.fixture_path("decode_ref.pt"))
+    cfg = zd["config"]
+    dec = SurfelDecoder(embed_dim=cfg["D"], depth=cfg["depth"], num_heads=cfg["heads"], tokens=cfg["tokens"],
+                        ldm_z_channels=cfg["z_channels"])
+    dec.load_state_dict(zd["state_dict"])
+    for m in (m1, m2, dec):
+        m.to(gpu_device)
+    ctx = zs[0]["context"]
+    cond = {k: v[:1].to(gpu_device) for k, v in ctx.items()}
+    uc = {k: torch.zeros_like(v) for k, v in cond.items()}
+    cams = synthetic.eval_cameras(2)
+    c = {"cam_view": cams["cam_view"][None].to(gpu_device), "cam_view_proj": cams["cam_view_proj"][None].to(gpu_device),
+         "cam_pos": cams["cam_pos"][None].to(gpu_device), "tanfov": cams["tanfov"]}
+    out = cascade.cascade(m1, m2, dec, cond, uc, cameras=c, num_steps=6, sampling_method="euler", seed=3)
+    L = cfg["tokens"]
+    xyz = cascade.sample(m1, cond, uc, (L, 3), 1, 4.0, 3, 6, "euler")
+    fps = (xyz * 0.164).clip(-0.45, 0.45)
+    lat = cascade.sample(m2, dict(cond, **{"fps-xyz": fps}), dict(uc, **{"fps-xyz": fps}), (L, 10), 1, 4.0, 3, 6, "euler")
+    ref = dec.decode(lat, fps)
+    assert torch.equal(out["query_pcd_xyz"], fps) and torch.equal(out["gaussians_upsampled_3"], ref["gaussians_upsampled_3"])
+    assert out["gaussians_upsampled_3"].shape == (1, L * 96, 13)
+    assert set(out["renders"]) == set(dec.output_size) and out["renders"]["gaussians_upsampled_3"]["image"].shape[-1] == 512
+    assert bool(torch.isfinite(out["renders"]["gaussians_upsampled_3"]["image"]).all())
