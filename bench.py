@@ -179,6 +179,47 @@ def bench_dit(dev, arch, nfe, warmup, parity_mode=False):
             "sec_per_250_step_euler_stage": round(sec250, 4), "nfe_timed": nfe, **extra}
 
 
+def bench_cascade(dev, cams):
+    """BASELINE configs[3] end to end, one sample, as ONE measured wall-clock figure: stage-1 DiT-L and stage-2 DiT-L
+    (250-step Euler each, CFG batch 2) -> surfel decode -> renders of all four levels for 8 views
+    (gaussiananything_amd/cascade.py); conditioning tensors start on the device, random weights."""
+    from gaussiananything_amd import cascade
+    from gaussiananything_amd.decode import SurfelDecoder
+    from gaussiananything_amd.dit import DiT_models
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(4)
+    models = []
+    for arch, C in (("DiT-PixArt-PCD-CLAY-L", 3), ("DiT-PixArt-PCD-CLAY-stage2-L", 10)):
+        m = DiT_models[arch](input_size=16, in_channels=C, context_dim=1024, pooling_ctx_dim=768, num_classes=0,
+                             learn_sigma=False, roll_out=True)
+        with torch.no_grad():
+            for p_ in m.parameters():
+                if float(p_.abs().max()) == 0.0:
+                    p_.copy_(torch.randn(p_.shape, generator=g) * 0.02)
+        models.append(m.to(dev))
+    dec = SurfelDecoder()
+    with torch.no_grad():
+        for name, p_ in dec.named_parameters():
+            if name.endswith("pos_embed") or "latent_embedding" in name:
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.5)
+            elif p_.dim() >= 2:
+                p_.copy_(torch.randn(p_.shape, generator=g) * (0.5 / p_.shape[-1] ** 0.5))
+    dec.to(dev)
+    cond = {"img_crossattn": torch.randn(1, 1369, 1024, generator=g).to(dev), "img_vector": torch.randn(1, 1024, generator=g).to(dev)}
+    uc = {k: torch.zeros_like(v) for k, v in cond.items()}
+    c = {"cam_view": cams["cam_view"][None].to(dev), "cam_view_proj": cams["cam_view_proj"][None].to(dev),
+         "cam_pos": cams["cam_pos"][None].to(dev), "tanfov": cams["tanfov"]}
+    kw = dict(cameras=c, num_steps=250, sampling_method="euler", render_all_scale=True)
+    cascade.cascade(models[0], models[1], dec, cond, uc, **dict(kw, num_steps=5))   # warm-up: lazy init, workspaces
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = cascade.cascade(models[0], models[1], dec, cond, uc, **kw)
+    torch.cuda.synchronize()
+    sec = time.perf_counter() - t0
+    return {"sec_per_sample": round(sec, 4), "stages": "DiT-L x 249 NFE, stage2 DiT-L x 249 NFE, decode -> 73728 surfels, "
+            "renders 8 views x {128,256,384,512}^2", "surfels": int(out["gaussians_upsampled_3"].shape[1])}
+
+
 def bench_decode(dev, cams, reps=5):
     """Surfel decode at the release size (DiT2-B/2 backbone: width 768, depth 12, 768 anchors; upsamplers x8, x4, x3 ->
     73 728 surfels; seeded random weights, anchors = one in-tree FPS cloud) and the raster of its finest level at 8 x 512^2
@@ -365,6 +406,7 @@ def main():
             out["dit"] = [bench_dit(dev, arch, a.dit_nfe, 3, parity_mode=(arch == "DiT-PixArt-PCD-CLAY-B")) for arch in
                           ("DiT-PixArt-PCD-CLAY-B", "DiT-PixArt-PCD-CLAY-L", "DiT-PixArt-PCD-CLAY-stage2-L")]
             out["decode"] = bench_decode(dev, cams)
+            out["cascade_measured"] = bench_cascade(dev, cams)
             # BASELINE configs[3]: stage-1 DiT + stage-2 DiT (250-step Euler each) + surfel decode + raster of the result
             out["sec_per_sample_250step_cascaded_L"] = round(
                 out["dit"][1]["sec_per_250_step_euler_stage"] + out["dit"][2]["sec_per_250_step_euler_stage"]
