@@ -32,6 +32,11 @@ __global__ __launch_bounds__(256) void rmsnorm_modulate_kernel(GaRmsNormArgs a)
         const int d = c * 256 + lane * 4;
         if (d < D) {
             v[c] = *reinterpret_cast<const float4 *>(x + d);
+            if (a.row_bias && row >= a.row_bias_first) {  // wave-uniform
+                const float4 rb = *reinterpret_cast<const float4 *>(a.row_bias + d);
+                v[c].x += rb.x; v[c].y += rb.y; v[c].z += rb.z; v[c].w += rb.w;
+                *reinterpret_cast<float4 *>(const_cast<float *>(x) + d) = v[c];
+            }
             w[c] = *reinterpret_cast<const float4 *>(a.weight + d);
             if (sc) {
                 s4[c] = *reinterpret_cast<const float4 *>(sc + d);
@@ -366,26 +371,30 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     const size_t kv_rows = (size_t)B * a->ctx_tokens;
     const int64_t Mp = ((int64_t)a->ctx_tokens + 63) / 64 * 64, Lp = ((int64_t)L + 63) / 64 * 64;
     if (Lp != L && hipMemsetAsync(w.vt, 0, w.vt_bytes, s) != hipSuccess) return GA_DIT_ERR_LAUNCH;  // zero key padding
+    const int ca_batch = (a->ca_batch <= 0 || a->ca_batch > B) ? B : a->ca_batch;
+    const int Mca = ca_batch * L;
     for (int i = 0; i < m->depth; ++i) {
         const GaDitBlockWeights &bw = m->blocks[i];
         const float *mod = w.mod + (size_t)i * B * 6 * D;  // [B][6][D]: shift_msa scale_msa gate_msa shift_mlp scale_mlp gate_mlp
         // cross-attention on the image tokens
-        GaRmsNormArgs n0{Mrows, D, L, w.xres, bw.prenorm_ca_w, nullptr, nullptr, 0, w.xn};
+        GaRmsNormArgs n0{Mca, D, L, w.xres, bw.prenorm_ca_w, nullptr, nullptr, 0, w.xn, nullptr, 0};
         GA_TRY(ga_rmsnorm_modulate(&n0, stream));
         GaGemmArgs gq{};
-        gq.M = Mrows; gq.N = D; gq.K = D; gq.epilogue = GA_GEMM_EPI_STORE_BF16; gq.A = w.xn; gq.lda = D; gq.W = bw.ca_q_w;
+        gq.M = Mca; gq.N = D; gq.K = D; gq.epilogue = GA_GEMM_EPI_STORE_BF16; gq.A = w.xn; gq.lda = D; gq.W = bw.ca_q_w;
         gq.out = w.qkv; gq.ldo = D;
         gq.qk_w0 = bw.ca_q_norm_w; gq.qk_cols0 = D; gq.qk_cols1 = D;           // q_norm fused into the projection
         GA_TRY(ga_gemm_bf16(&gq, stream));
-        GaAttentionArgs ca{B, m->heads, L, a->ctx_tokens, w.qkv, a->ca_k + (size_t)i * kv_rows * D,
+        GaAttentionArgs ca{ca_batch, m->heads, L, a->ctx_tokens, w.qkv, a->ca_k + (size_t)i * kv_rows * D,
                            a->ca_vt + (size_t)i * B * D * Mp, D, D, Mp, nullptr, nullptr, w.att, D};
         GA_TRY(ga_attention_bf16(&ca, stream));
         GaGemmArgs go{};
-        go.M = Mrows; go.N = D; go.K = D; go.epilogue = GA_GEMM_EPI_RESIDUAL; go.A = w.att; go.lda = D; go.W = bw.ca_out_w;
+        go.M = Mca; go.N = D; go.K = D; go.epilogue = GA_GEMM_EPI_RESIDUAL; go.A = w.att; go.lda = D; go.W = bw.ca_out_w;
         go.bias = bw.ca_out_b; go.out = w.xres; go.ldo = D; go.gate = nullptr; go.rows_per_batch = L;
         GA_TRY(ga_gemm_bf16(&go, stream));
         // self-attention
-        GaRmsNormArgs n1{Mrows, D, L, w.xres, bw.norm1_w, mod + 1 * D, mod + 0 * D, 6 * (int64_t)D, w.xn};
+        // (rows of the items that skipped the cross-attention pick up its output bias here)
+        GaRmsNormArgs n1{Mrows, D, L, w.xres, bw.norm1_w, mod + 1 * D, mod + 0 * D, 6 * (int64_t)D, w.xn,
+                         Mca < Mrows ? bw.ca_out_b : nullptr, Mca};
         GA_TRY(ga_rmsnorm_modulate(&n1, stream));
         GaGemmArgs gqkv{};
         gqkv.M = Mrows; gqkv.N = 3 * D; gqkv.K = D; gqkv.epilogue = GA_GEMM_EPI_STORE_BF16; gqkv.A = w.xn; gqkv.lda = D;
@@ -401,7 +410,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         gp.rows_per_batch = L;
         GA_TRY(ga_gemm_bf16(&gp, stream));
         // FusedMLP
-        GaRmsNormArgs n2{Mrows, D, L, w.xres, bw.norm2_w, mod + 4 * D, mod + 3 * D, 6 * (int64_t)D, w.xn};
+        GaRmsNormArgs n2{Mrows, D, L, w.xres, bw.norm2_w, mod + 4 * D, mod + 3 * D, 6 * (int64_t)D, w.xn, nullptr, 0};
         GA_TRY(ga_rmsnorm_modulate(&n2, stream));
         GaGemmArgs g1{};
         g1.M = Mrows; g1.N = 4 * D; g1.K = D; g1.epilogue = GA_GEMM_EPI_GELU_BF16; g1.A = w.xn; g1.lda = D; g1.W = bw.fc1_w;

@@ -212,6 +212,8 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         self._ctx_cache = None
         return self._pack
 
+    ca_skip = True  # skip the cross-attention of batch items whose image tokens are all zero (exact; tests switch it off)
+
     def _context_kv(self, pack, ctx_tokens: torch.Tensor):
         key = (ctx_tokens.data_ptr(), ctx_tokens._version, tuple(ctx_tokens.shape), ctx_tokens.dtype)
         if self._ctx_cache is not None and self._ctx_cache[0] == key:
@@ -224,8 +226,12 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         stream = ctypes.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream)
         ops.check(ops.lib().ga_dit_cache_context(ctypes.byref(pack["model"]), B, M, ctx.data_ptr(), ck.data_ptr(),
                                                  cvt.data_ptr(), stream), "ga_dit_cache_context")
-        self._ctx_cache = (key, (ck, cvt), ctx_tokens)  # keep the key tensor alive so that its address cannot be reused
-        return ck, cvt
+        # leading batch items with a non-zero context; the all-zero ones (unconditional half of a CFG batch) skip the
+        # cross-attention exactly (include/ga_dit.h: ca_batch).  One host read per conditioning tensor.
+        nz = (ctx_tokens.detach().reshape(B, -1) != 0).any(dim=1).tolist()
+        ca_batch = sum(nz) if (self.ca_skip and nz == sorted(nz, reverse=True)) else B
+        self._ctx_cache = (key, (ck, cvt, max(ca_batch, 1)), ctx_tokens)  # keeps the key tensor alive (address not reused)
+        return ck, cvt, max(ca_batch, 1)
 
     # -- the reference surface ------------------------------------------------------------------------------------------
     def forward(self, x, timesteps=None, context=None, y=None, get_attr="", **kwargs):
@@ -236,7 +242,7 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         pack = self._prepare(dev)
         B, L, C = x.shape
         assert C == self.in_channels
-        ck, cvt = self._context_kv(pack, context["img_crossattn"])
+        ck, cvt, ca_batch = self._context_kv(pack, context["img_crossattn"])
         Mctx = context["img_crossattn"].shape[1]
         xin = x.detach().float().contiguous()
         t = timesteps.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
@@ -257,7 +263,7 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         base = buf.data_ptr() + ((-buf.data_ptr()) % 256)
         args = ops.GaDitForwardArgs(B, L, Mctx, xin.data_ptr(), t.data_ptr(), vec.data_ptr(),
                                     xyz.data_ptr() if xyz is not None else None, ck.data_ptr(), cvt.data_ptr(), out.data_ptr(), base,
-                                    pack["ws_bytes"])
+                                    pack["ws_bytes"], ca_batch)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         ops.check(Lib.ga_dit_forward(ctypes.byref(pack["model"]), ctypes.byref(args), stream), "ga_dit_forward")
         return out

@@ -29,7 +29,7 @@ class GaAttentionArgs(ctypes.Structure):
 
 class GaRmsNormArgs(ctypes.Structure):
     _fields_ = [("M", i32), ("D", i32), ("rows_per_batch", i32), ("x", c_p), ("weight", c_p), ("scale", c_p),
-                ("shift", c_p), ("mod_stride", i64), ("out", c_p)]
+                ("shift", c_p), ("mod_stride", i64), ("out", c_p), ("row_bias", c_p), ("row_bias_first", i32)]
 
 
 class GaSmallLinearArgs(ctypes.Structure):
@@ -55,7 +55,7 @@ class GaDitModel(ctypes.Structure):
 class GaDitForwardArgs(ctypes.Structure):
     _fields_ = [("batch", i32), ("tokens", i32), ("ctx_tokens", i32), ("x", c_p), ("timesteps", c_p),
                 ("img_vector", c_p), ("fps_xyz", c_p), ("ca_k", c_p), ("ca_vt", c_p), ("out", c_p), ("workspace", c_p),
-                ("workspace_bytes", ctypes.c_size_t)]
+                ("workspace_bytes", ctypes.c_size_t), ("ca_batch", i32)]
 
 
 DIT_EXPORTS = ("ga_gemm_bf16", "ga_attention_bf16", "ga_rmsnorm_modulate", "ga_small_linear", "ga_dit_workspace_bytes",
@@ -152,7 +152,7 @@ def rmsnorm_modulate(x, weight, scale=None, shift=None, rows_per_batch=1):
     M, D = x.shape
     out = torch.empty((M, D), device=x.device, dtype=torch.bfloat16)
     a = GaRmsNormArgs(M, D, rows_per_batch, x.data_ptr(), weight.data_ptr(), _ptr(scale), _ptr(shift),
-                      scale.stride(0) if scale is not None else 0, out.data_ptr())
+                      scale.stride(0) if scale is not None else 0, out.data_ptr(), None, 0)
     check(lib().ga_rmsnorm_modulate(ctypes.byref(a), _stream(x)), "ga_rmsnorm_modulate")
     return out
 

@@ -94,6 +94,10 @@ typedef struct GaRmsNormArgs {
     const float *scale, *shift; /* [M / rows_per_batch, mod_stride]                                  */
     int64_t mod_stride;
     ga_bf16 *out;
+    /* optional: rows >= row_bias_first first receive x[row] += row_bias (WRITTEN BACK to x, which is then not const) --
+     * how the residual stream of batch items whose cross-attention was skipped gets the projection bias (see ca_batch) */
+    const float *row_bias;      /* [D] or NULL */
+    int32_t row_bias_first;
 } GaRmsNormArgs;
 
 int ga_rmsnorm_modulate(const GaRmsNormArgs *args, void *stream);
@@ -165,6 +169,11 @@ typedef struct GaDitForwardArgs {
     float *out;               /* [B', L, Cout] fp32 (the reference returns x.float())                  */
     void *workspace;          /* ga_dit_workspace_bytes()                                              */
     size_t workspace_bytes;
+    /* Number of LEADING batch items whose image tokens are not all zero (<= 0 or > batch: all).  For an all-zero context
+     * (the unconditional half of a CFG batch: sgm's force_uc_zero_embeddings) K = V = 0 exactly (to_k / to_v have no bias,
+     * RMSNorm(0) = 0), the softmax is uniform over zeros and the block's cross-attention reduces to `x += to_out.bias`:
+     * those items skip the q projection, the 1369-key attention and the output projection -- bit-identical result. */
+    int32_t ca_batch;
 } GaDitForwardArgs;
 
 size_t ga_dit_workspace_bytes(const GaDitModel *model, int32_t batch, int32_t tokens, int32_t ctx_tokens);

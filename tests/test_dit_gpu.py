@@ -190,6 +190,28 @@ def test_model_matches_reference_golden(gpu_device, stage):
     assert rel_l2(ycfg, z["y_cfg"].to(gpu_device)) < 6e-2        # CFG amplifies the difference by the guidance scale
 
 
+def test_zero_context_items_skip_cross_attention_exactly(gpu_device):
+    """The unconditional half of a CFG batch has all-zero image tokens: K = V = 0, uniform softmax over zeros, so its
+    cross-attention is `x += to_out.bias`; the forward skips the work for those items.  Must be BIT-identical to running
+    it, and must not trigger when a zero item precedes a non-zero one."""
+    z, model, ctx = _load_golden(1, gpu_device)
+    x, t = z["x"].to(gpu_device), z["t"].to(gpu_device)
+    assert float(ctx["img_crossattn"][2:].abs().max()) == 0.0 and float(ctx["img_crossattn"][:2].abs().max()) > 0.0
+    with torch.no_grad():
+        y_skip = model(x, t, ctx)
+        assert model._ctx_cache[1][2] == 2
+        model.ca_skip = False
+        model._ctx_cache = None
+        y_full = model(x, t, ctx)
+        assert model._ctx_cache[1][2] == 4
+        assert torch.equal(y_skip, y_full)
+        model.ca_skip = True
+        ctx2 = dict(ctx, img_crossattn=ctx["img_crossattn"].flip(0).contiguous())       # zero items first: no skipping
+        y_flip = model(x.flip(0).contiguous(), t, dict(ctx2, img_vector=ctx["img_vector"].flip(0).contiguous()))
+        assert model._ctx_cache[1][2] == 4
+        assert torch.equal(y_flip.flip(0), y_full)
+
+
 def test_model_release_shape_against_oracle(gpu_device):
     """DiT-B sized block stack (hidden 768, 12 heads, 768 tokens, 1369 x 1024 context, CFG batch 2) against the fp32
     oracle on the same weights -- the configuration of BASELINE.json configs[2], shortened to depth 2."""

@@ -20,6 +20,8 @@ model.to(dev)
 B, L, M = 2, 768, 1369
 x = torch.randn(B, L, 3, generator=g).to(dev)
 ctx = {"img_crossattn": torch.randn(B, M, 1024, generator=g).to(dev), "img_vector": torch.randn(B, 1024, generator=g).to(dev)}
+ctx["img_crossattn"][1] = 0   # the unconditional half of a CFG batch (sgm force_uc_zero_embeddings)
+ctx["img_vector"][1] = 0
 sampler = Sampler(create_transport("GVP", "velocity", None, None, None, snr_type="uniform"))
 fn = sampler.sample_ode(sampling_method="euler", num_steps=steps)
 with torch.no_grad():
