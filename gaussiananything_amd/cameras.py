@@ -73,6 +73,29 @@ def c_to_3dgs_format_batched(poses, znear=0.01, zfar=100.0):
                 tanfov=items[0]["tanfov"])
 
 
+def c_to_3dgs_format_device(poses: torch.Tensor, znear=0.01, zfar=100.0):
+    """The same conversion as ONE batched tensor program on whatever device ``poses`` lives on (SURVEY.md section 8(f)-2:
+    the video path renders 50 cameras x 4 levels per sample, flow_matching_trainer.py:1545-1616, and the reference converts
+    them one by one in numpy).  poses: [..., 25] -> ``cam_view`` / ``cam_view_proj`` [..., 4, 4] (row-vector convention),
+    ``cam_pos`` [..., 3], ``tanfov`` (python float of the first camera, as the reference passes a scalar)."""
+    poses = poses.float()
+    c2w = poses[..., :16].reshape(*poses.shape[:-1], 4, 4)
+    w2c = torch.linalg.inv(c2w)                       # column-vector world->view (getWorld2View2 with no re-centring)
+    cam_view = w2c.transpose(-1, -2)
+    fx = poses[..., 16]
+    tan = 1.0 / (2.0 * fx)                            # tan(focal2fov(fx, 1) / 2)
+    P = torch.zeros(*poses.shape[:-1], 4, 4, device=poses.device)
+    P[..., 0, 0] = 1.0 / tan
+    P[..., 1, 1] = 1.0 / tan
+    P[..., 2, 2] = zfar / (zfar - znear)
+    P[..., 2, 3] = -(zfar * znear) / (zfar - znear)
+    P[..., 3, 2] = 1.0
+    cam_view_proj = cam_view @ P.transpose(-1, -2)
+    cam_pos = c2w[..., :3, 3]                         # = inverse(cam_view)[3, :3]
+    return dict(cam_view=cam_view, cam_view_proj=cam_view_proj, cam_pos=cam_pos,
+                tanfov=float(tan.reshape(-1)[0]))
+
+
 def orbit_poses(num_views, radius=1.77, fx=1.3889, elevation_deg=15.0, seed=None):
     """Synthetic look-at-origin orbit in the pose25 format (c2w + normalised K), for inputs that must not depend
     on reference assets.  Camera looks down its +z axis at the origin (the convention of ``eval_pose.pt``)."""

@@ -241,3 +241,15 @@ def test_decode_oracle_matches_reference_golden():
         assert out[k].shape == z[k].shape
         assert float((out[k] - z[k]).abs().max()) <= 1e-6, k
     assert out["gaussians_upsampled_3"].shape[1] == z["latent"].shape[1] * 8 * 4 * 3
+
+
+def test_batched_device_camera_conversion_matches_the_per_view_one():
+    import torch
+    from gaussiananything_amd import cameras
+    poses = cameras.orbit_poses(12, seed=3)
+    ref = cameras.c_to_3dgs_format_batched(poses)
+    got = cameras.c_to_3dgs_format_device(torch.from_numpy(poses).reshape(3, 4, 25))
+    for k in ("cam_view", "cam_view_proj", "cam_pos"):
+        assert got[k].shape[:2] == (3, 4)
+        assert float((got[k].reshape(12, *ref[k].shape[1:]) - ref[k]).abs().max()) < 2e-6, k
+    assert abs(got["tanfov"] - ref["tanfov"]) < 1e-7
