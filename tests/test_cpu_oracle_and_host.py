@@ -253,3 +253,26 @@ def test_batched_device_camera_conversion_matches_the_per_view_one():
         assert got[k].shape[:2] == (3, 4)
         assert float((got[k].reshape(12, *ref[k].shape[1:]) - ref[k]).abs().max()) < 2e-6, k
     assert abs(got["tanfov"] - ref["tanfov"]) < 1e-7
+
+
+def test_ply_and_npy_handoff_formats(tmp_path):
+    from gaussiananything_amd import io_formats as io
+    rng = np.random.default_rng(0)
+    xyz = (rng.random((768, 3), dtype=np.float32) - 0.5) * 1.2
+    p = tmp_path / "stage1.ply"
+    io.save_points_ply(p, xyz)
+    head = open(p, "rb").read(200)
+    assert head.startswith(b"ply\nformat binary_little_endian 1.0\nelement vertex 768\nproperty float x\n")
+    assert np.array_equal(io.load_points_ply(p), xyz)
+    got = io.load_stage1_points(p)
+    assert got.shape == (1, 768, 3) and float(np.abs(got).max()) <= 0.45 and np.array_equal(got[0], np.clip(xyz, -0.45, 0.45))
+    # ascii PLY with extra properties in another order (what other tools write)
+    a = tmp_path / "ascii.ply"
+    with open(a, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex 3\nproperty uchar red\nproperty double z\nproperty float x\n"
+                "property float y\nelement face 0\nproperty list uchar int vertex_indices\nend_header\n")
+        f.write("255 3.0 1.0 2.0\n0 6.0 4.0 5.0\n7 9.0 7.0 8.0\n")
+    assert np.array_equal(io.load_points_ply(a), np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9]], np.float32))
+    g = rng.random((100, 13), dtype=np.float32)
+    io.save_gaussians_npy(tmp_path / "g.npy", g)
+    assert io.load_gaussians_npy(tmp_path / "g.npy").shape == (1, 100, 13)
