@@ -3,54 +3,99 @@
 // Computes what the reference obtains from xformers.ops.memory_efficient_attention between the projections of
 //   MemEffAttention.forward               /root/reference/vit/vision_transformer.py:284-297  (self-attention, L = 768)
 //   MemoryEfficientCrossAttention.forward /root/reference/ldm/modules/attention.py:514-548   (image tokens, Lk = 1369)
-// INCLUDING the per-head RMSNorm of q and k that precedes it (learned weight[64], eps 1e-5, dit/norm.py:29-43), which
-// is applied while the tiles are staged, and the softmax scale 64^-1/2.
+// INCLUDING the per-head RMSNorm of q and k that precedes it (learned weight[64], eps 1e-5, dit/norm.py:29-43) when the
+// caller has not already applied it in the projection GEMM, and the softmax scale 64^-1/2.
 //
 // MI355X mapping (flash-style, one pass over the keys, online softmax in fp32):
-//   * grid (ceil(Lq/128), heads, batch); 8 waves per workgroup, each wave owns 16 query rows; two waves share a SIMD
-//     so that one wave's softmax (VALU) overlaps the other's MFMAs; the workgroup shares the staged K / V^T tiles
-//     (64 keys) in LDS;
-//   * "swapped" products so that every reduction is lane-local or a 2-step lane shuffle: S^T = K Q^T puts one query
-//     in a lane (column lane&15) with 4 keys per accumulator fragment, and O^T = V^T P^T keeps that query in the same
-//     lane, so the running max / sum / rescale never cross lanes except for two xor-shuffles per tile;
-//   * P never leaves registers: the PV product defines its own key order inside each 32-key block (lane-group g,
-//     element e  <->  key 16*(e>>2) + 4*g + (e&3)), which is exactly how the S^T accumulators already sit in the lane;
-//     V arrives TRANSPOSED from the projection GEMM's epilogue (keys contiguous), so staging it is two 8-byte LDS
-//     writes per 16-byte chunk (the permutation above) and its MFMA fragments are plain 16-byte LDS reads;
-//   * tiles are double-buffered in LDS (global -> VGPR one tile ahead, VGPR -> LDS for tile t+1 before the math of
-//     tile t), one barrier per tile; rows are 128 bytes with the 16-byte slot XOR-swizzled by (row & 7): conflict-free
-//     for the hardware's ds_read_b128 lane groups;
-//   * K rows are RMS-normalised by the 8 lanes that stage a row (3 xor-shuffles), Q rows by the 4 lane-groups that
-//     hold a row's fragments; the softmax scale and log2(e) are folded into Q so the exponentials are bare v_exp_f32.
+//   * grid (ceil(Lq / (16 NW)), heads, batch); NW query waves x KS key groups per workgroup, each wave owns 16 query rows
+//     and every KS-th 64-key tile; a key group shares its staged K / V^T tiles in LDS;
+//   * "swapped" products so that every reduction is lane-local or a lane swap: S^T = K Q^T puts one query in a lane
+//     (column lane&15) with 4 keys per accumulator fragment, and O^T = V^T P^T keeps that query in the same lane, so
+//     the running max / sum / rescale never cross lanes except for two v_permlane swaps per tile;
+//   * P never leaves registers, and BOTH tiles are plain row-major images of global memory: the K fragment of MFMA row
+//     i reads key row 32 (kf>>1) + 8 (i>>2) + 4 (kf&1) + (i&3) of the tile, which makes the 8 P values a lane holds for a
+//     32-key block (fragments kf = 2 kb, 2 kb + 1) the 8 CONSECUTIVE keys 32 kb + 8 g .. + 7 -- exactly the 16-byte
+//     V^T fragment (V arrives transposed from the projection GEMM's epilogue, keys contiguous);
+//   * staging is LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR round trip) into a ring of three
+//     slots, two tiles ahead, with a counted vmcnt before the one barrier per tile (stamps of the register-staged
+//     predecessor: ~400 of the ~2450 cycles of a step were the wait for loads issued one step earlier -- the six
+//     workgroups of a (batch, head) sit on different XCDs, so every tile is an L2 miss -- and ~200 more the
+//     VGPR -> LDS copy).  Rows are 128 bytes; the DMA writes LDS in lane order, so the bank-conflict-free image is made
+//     on the SOURCE side: slot s of row r holds global 16-byte chunk s ^ ((r & 3) | ((r >> 3) & 1) << 2), conflict-free
+//     for the hardware's ds_read_b128 lane groups under both row patterns (K: permuted, V^T: natural);
+//   * a caller that wants K normalised here (k_norm_weight != NULL) gets the register-staged variant: K rows are
+//     RMS-normalised by the 8 lanes that stage a row (3 xor-shuffles); Q rows by the 4 lane-groups that hold a row's
+//     fragments; the softmax scale and log2(e) are folded into Q so the exponentials are bare v_exp_f32.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "dit_common.h"
 
 namespace gadit {
 
+// GA_ATTN_STAMP builds record the cycle counter at eight points of one step (tools/attn_stamp.py); the product build has none.
+#ifdef GA_ATTN_STAMP
+__device__ unsigned long long g_attn_stamps[8 * 16 * 16];
+#define STAMP(k)                                                                                                   \
+    do {                                                                                                           \
+        if (blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 8 && t_stamp == GA_ATTN_STAMP && lane == 0)              \
+            g_attn_stamps[(blockIdx.x * 16 + wave) * 16 + (k)] = __builtin_readcyclecounter();                      \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 constexpr int KB = 64, HD = 64;
 constexpr int TILE = KB * HD;  // elements of one staged tile (8 KiB)
+#ifndef GA_ATTN_ABLATE
+#define GA_ATTN_ABLATE 0   // tools/attn_ablate.sh builds timing-only variants with phases removed (wrong results)
+#endif
+constexpr float kLazy = 8.f;    // log2 units a row maximum may exceed its reference before the reference moves
 
-__device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ (row & 7)) * 8); }
+__device__ __forceinline__ int swz_of(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ swz_of(row)) * 8); }
 
-// NW waves per workgroup, QI 16-row query fragments per wave: query rows per workgroup = NW * QI * 16.
-// <8,1>: 8 waves x 16 rows -- two waves per SIMD, so one wave's softmax VALU work overlaps the other's MFMAs (PMC of the
-// <4,2> shape: one wave per SIMD, 58 % of its cycles spent issuing ~9 k instructions at the lone-wave rate of one per
-// ~4.5 cycles, MFMA pipe 7 % busy).
-template <int NW, int QI>
-__global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(GaAttentionArgs a)
+__device__ __forceinline__ void glds16(const uint16_t *gsrc, uint16_t *lds_wave_base)
 {
-    constexpr int QB = NW * QI * 16, NT = NW * 64, CPT = 512 / NT;  // chunks (16 B) per thread per staged tile
-    __shared__ __attribute__((aligned(16))) uint16_t sK[2 * TILE];   // [buf][key][d]      (swizzled)
-    __shared__ __attribute__((aligned(16))) uint16_t sV[2 * TILE];   // [buf][d][perm key] (swizzled)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, c16 = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB + wave * (QI * 16);
-    const int Lq = a.Lq, Lk = a.Lk;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
 
-    // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + qi*16 + c16][kk*32 + g*8 .. +7], normalised, scaled
-    bf16x8 qf[QI][2];
-#pragma unroll
-    for (int qi = 0; qi < QI; ++qi) {
-        const int row = min(q0 + qi * 16 + c16, Lq - 1);
+// max over the four lane groups that hold one query's keys (lanes l, l^16, l^32, l^48): two VALU lane swaps instead of two
+// LDS round trips (ds_bpermute) on the tile's critical path
+__device__ __forceinline__ float group_max(float t)
+{
+    const unsigned u = __float_as_uint(t);
+    const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const unsigned v = __float_as_uint(m);
+    const auto c = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return fmaxf(__uint_as_float(c[0]), __uint_as_float(c[1]));
+}
+
+// NW query waves x KS key groups per workgroup.  Wave (ks, wq) owns query rows wq*16 .. +15 of the workgroup's NW*16 and
+// the 64-key tiles ks, ks + KS, ks + 2 KS, ...; every key group stages its own K / V^T tiles (KS rings in LDS) and the
+// groups' partial (max, sum, O) are merged through LDS at the end.  KS > 1 only pays when 128-query workgroups would
+// leave most CUs empty (see the launcher).  KNORM: K is RMS-normalised while it is staged (through registers).
+template <int NW, int KS, bool KNORM>
+__global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttentionArgs a)
+{
+    constexpr int QB = NW * 16, GT = NW * 64, CPT = (512 + GT - 1) / GT;  // 16-byte chunks per thread per staged tile
+    constexpr int DPW = 16 / NW;                                          // DMA instructions per wave per tile (K + V^T)
+    static_assert(16 % NW == 0, "a tile is 16 one-KiB DMA pieces");
+    __shared__ __attribute__((aligned(16))) uint16_t smem[KS * 6 * TILE];  // per key group: K[3][key][d], V^T[3][d][key]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: uniform branches
+    const int ks = wave / NW, wq = wave - ks * NW, tg = tid - ks * GT;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB + wq * 16;
+    const int Lq = a.Lq, Lk = a.Lk;
+    uint16_t *sK = smem + ks * 6 * TILE, *sV = sK + 3 * TILE;
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + c16][kk*32 + g*8 .. +7], normalised, scaled
+    bf16x8 qf[2];
+    {
+        const int row = min(q0 + c16, Lq - 1);
         const uint16_t *qp = a.q + ((size_t)b * Lq + row) * a.q_stride + h * HD;
         float qv[16];
         float ss = 0.f;
@@ -76,159 +121,277 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(GaAttentionArgs 
             for (int e = 0; e < 8; ++e) {
                 float v = qv[kk * 8 + e];
                 if (a.q_norm_weight) v *= a.q_norm_weight[kk * 32 + g * 8 + e];
-                qf[qi][kk][e] = (short)f32_to_bf16(v * rs);
+                qf[kk][e] = (short)f32_to_bf16(v * rs);
             }
     }
 
-    f32x4 o[QI][4];
+    f32x4 o[4];
 #pragma unroll
-    for (int qi = 0; qi < QI; ++qi)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[qi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run[QI], l_run[QI];
-#pragma unroll
-    for (int qi = 0; qi < QI; ++qi) { m_run[qi] = -1e30f; l_run[qi] = 0.f; }
+    for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = 0.f, l_run = 0.f;  // the group's first tile sets the first reference maximum
 
-    // ---- staging: K and V^T tiles are 512 16-byte chunks each, 2 per thread; chunk c -> row c>>3, part c&7
-    const int ntiles = (Lk + KB - 1) / KB;
+    const int ntiles = (Lk + KB - 1) / KB, nfull = Lk / KB;
     const uint16_t *vt_base = a.vt + ((size_t)b * a.heads + h) * HD * a.vt_ld;
+    const uint16_t *k_base = a.k + (size_t)b * Lk * a.k_stride + h * HD;
+    int t_stamp = -1;
+    (void)t_stamp;
+
+    // ---- staging, DMA form: piece p (0..15) of a tile is 8 rows (p < 8: K rows 8p .., else V^T rows 8(p-8) ..); wave wq
+    // of the key group moves pieces wq*DPW .. +DPW-1; lane l -> row 8p + (l>>3), LDS slot l&7 <- global chunk slot ^ swz
+    auto dma_tile = [&](int tile_raw, int slot) {
+        const int tile = min(tile_raw, ntiles - 1);  // past the end: a harmless re-fetch (keeps the vmcnt arithmetic exact)
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+            const int p = wq * DPW + i, r8 = (p & 7) * 8, row = r8 + (lane >> 3), chunk = (lane & 7) ^ swz_of(row);
+            if (p < 8) {
+                const int key = min(tile * KB + row, Lk - 1);
+                glds16(k_base + (size_t)key * a.k_stride + chunk * 8, sK + slot * TILE + r8 * 64);
+            } else {
+                glds16(vt_base + (size_t)row * a.vt_ld + tile * KB + chunk * 8, sV + slot * TILE + r8 * 64);
+            }
+        }
+    };
+    // ---- staging, register form (KNORM): 512 16-byte chunks per tile and operand; chunk c -> row c>>3, part c&7
     uint4 rk[CPT], rv[CPT];
-    auto issue = [&](int tile) {
+    auto issue = [&](int tile_raw) {
+        const int tile = min(tile_raw, ntiles - 1);
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const int c = tid + NT * i, row = c >> 3, part = c & 7;
+            const int c = tg + GT * i, row = c >> 3, part = c & 7;
             const int key = min(tile * KB + row, Lk - 1);
-            rk[i] = *reinterpret_cast<const uint4 *>(a.k + ((size_t)b * Lk + key) * a.k_stride + h * HD + part * 8);
+            rk[i] = *reinterpret_cast<const uint4 *>(k_base + (size_t)key * a.k_stride + part * 8);
             rv[i] = *reinterpret_cast<const uint4 *>(vt_base + (size_t)row * a.vt_ld + tile * KB + part * 8);
         }
     };
-    auto write_lds = [&](int buf) {
-        uint16_t *dk = sK + buf * TILE, *dv = sV + buf * TILE;
+    auto write_lds = [&](int slot) {
+        uint16_t *dk = sK + slot * TILE, *dv = sV + slot * TILE;
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const int c = tid + NT * i, row = c >> 3, part = c & 7;
+            const int c = tg + GT * i, row = c >> 3, part = c & 7;
             // K: RMS-normalise the row (8 consecutive lanes hold it)
             const uint32_t kw[4] = {rk[i].x, rk[i].y, rk[i].z, rk[i].w};
-            uint4 pk = rk[i];
-            if (a.k_norm_weight) {
-                float kv[8];
-                float ss = 0.f;
+            float kv[8];
+            float ss = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    kv[2 * e] = __uint_as_float(kw[e] << 16);
-                    kv[2 * e + 1] = __uint_as_float(kw[e] & 0xffff0000u);
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ss += kv[e] * kv[e];
-                ss += __shfl_xor(ss, 1, 64);
-                ss += __shfl_xor(ss, 2, 64);
-                ss += __shfl_xor(ss, 4, 64);
-                const float rs = rsqrtf(ss * (1.0f / HD) + 1e-5f);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) kv[e] *= rs * a.k_norm_weight[part * 8 + e];
-                pk.x = pack_bf16x2(kv[0], kv[1]); pk.y = pack_bf16x2(kv[2], kv[3]);
-                pk.z = pack_bf16x2(kv[4], kv[5]); pk.w = pack_bf16x2(kv[6], kv[7]);
+            for (int e = 0; e < 4; ++e) {
+                kv[2 * e] = __uint_as_float(kw[e] << 16);
+                kv[2 * e + 1] = __uint_as_float(kw[e] & 0xffff0000u);
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += kv[e] * kv[e];
+            ss += __shfl_xor(ss, 1, 64);
+            ss += __shfl_xor(ss, 2, 64);
+            ss += __shfl_xor(ss, 4, 64);
+            const float rs = rsqrtf(ss * (1.0f / HD) + 1e-5f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kv[e] *= rs * a.k_norm_weight[part * 8 + e];
+            const uint4 pk = make_uint4(pack_bf16x2(kv[0], kv[1]), pack_bf16x2(kv[2], kv[3]), pack_bf16x2(kv[4], kv[5]),
+                                        pack_bf16x2(kv[6], kv[7]));
             *reinterpret_cast<uint4 *>(dk + swz(row, part)) = pk;
-            // V^T row d = row, keys 8*part .. +7 of the tile: permute inside the 32-key block (see header)
-            const int kb = part >> 2, cc = part & 3;
-            const int pc0 = kb * 4 + 2 * (cc & 1), off = (cc >> 1) * 4;
-            *reinterpret_cast<uint2 *>(dv + swz(row, pc0) + off) = make_uint2(rv[i].x, rv[i].y);
-            *reinterpret_cast<uint2 *>(dv + swz(row, pc0 + 1) + off) = make_uint2(rv[i].z, rv[i].w);
+            *reinterpret_cast<uint4 *>(dv + swz(row, part)) = rv[i];
         }
     };
 
-    issue(0);
-    write_lds(0);
-    if (ntiles > 1) issue(1);
-    __syncthreads();
+    // One 64-key tile.  TAIL = the tile holds keys >= Lk (masked to -inf); full tiles carry no masking code at all.
+    // Softmax bookkeeping is "lazy": the S^T accumulators start at -m_run (the C operand of the first MFMA, so the
+    // subtraction is free), and as long as no row's tile maximum exceeds its reference m_run by more than kLazy (2^8 --
+    // harmless in fp32 sums and in the relative precision of the bf16 P) the reference is kept: no max update, no
+    // exp2(m_old - m_new), no rescale of the 16 O accumulators.  m_run is always the true maximum at the time it was
+    // set, so the largest P of a row lies in [1, 256] and the row sum is >= 1.  The decision is wave-uniform.
+    auto tile_math = [&](int tile, bool first, int slot, int dma_slot, auto tail_c) {
+        constexpr bool TAIL = decltype(tail_c)::value;
+        const uint16_t *bk = sK + slot * TILE, *bv = sV + slot * TILE;
+        // The fragment reads are issued in two batches into their own registers (the compiler, left alone, funnels them
+        // through one register quad: read -> wait -> MFMA, eight LDS latencies in a row, twice per tile); the V^T
+        // fragments are requested as soon as the S MFMAs have consumed the K fragments and land while the softmax runs.
+        bf16x8 frag[4][2];
+        const int krow = 8 * (c16 >> 2) + (c16 & 3);
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                frag[kf][kk] = *reinterpret_cast<const bf16x8 *>(bk + swz((kf >> 1) * 32 + (kf & 1) * 4 + krow, kk * 4 + g));
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(2);
 
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int cur = tile & 1;
-        if (tile + 1 < ntiles) write_lds(cur ^ 1);     // buffer cur^1 was last read before the previous barrier
-        if (tile + 2 < ntiles) issue(tile + 2);        // flies during the MFMAs below
-        const uint16_t *bk = sK + cur * TILE, *bv = sV + cur * TILE;
-
-        // ---- S^T = K Q^T : s[qi][kf][r] = S[key = kf*16 + g*4 + r][q = qi*16 + c16]
-        f32x4 s[QI][4];
+        // ---- S^T - m_run = K Q^T - m_run : s[kf][r] <-> key (kf>>1)*32 + g*8 + (kf&1)*4 + r of the tile, query c16
+        f32x4 s[4];
+        const float nm = -m_run;
 #pragma unroll
-        for (int kf = 0; kf < 4; ++kf) {
+        for (int kf = 0; kf < 4; ++kf) s[kf] = f32x4{nm, nm, nm, nm};
 #pragma unroll
-            for (int qi = 0; qi < QI; ++qi) s[qi][kf] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const bf16x8 kfrag = *reinterpret_cast<const bf16x8 *>(bk + swz(kf * 16 + c16, kk * 4 + g));
-#pragma unroll
-                for (int qi = 0; qi < QI; ++qi)
-                    s[qi][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[qi][kk], s[qi][kf], 0, 0, 0);
-            }
-        }
-        const int kbase = tile * KB + g * 4;
-        const bool tail = tile * KB + KB > Lk;
-        bf16x8 pf[QI][2];
-#pragma unroll
-        for (int qi = 0; qi < QI; ++qi) {
-            float tmax = -1e30f;
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (tail && kbase + kf * 16 + r >= Lk) s[qi][kf][r] = -1e30f;
-                    tmax = fmaxf(tmax, s[qi][kf][r]);
-                }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run[qi], tmax);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
-            m_run[qi] = m_new;
-            float psum = 0.f;
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(s[qi][kf][r] - m_new);
-                    psum += p;
-                    pf[qi][kf >> 1][(kf & 1) * 4 + r] = (short)f32_to_bf16(p);
-                }
-            l_run[qi] = l_run[qi] * alpha + psum;
-#pragma unroll
-            for (int df = 0; df < 4; ++df) {
-                o[qi][df][0] *= alpha; o[qi][df][1] *= alpha; o[qi][df][2] *= alpha; o[qi][df][3] *= alpha;
-            }
-        }
-        // ---- O^T += V^T P^T : o[qi][df][r] = O[q = qi*16 + c16][d = df*16 + g*4 + r]
+                if (GA_ATTN_ABLATE != 2) s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag[kf][kk], qf[kk], s[kf], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(3);
+        // the next-but-one tile's DMA is requested here, behind the head of the step's dependency chain (K fragments ->
+        // S MFMAs) rather than in front of it
+        if (!KNORM && GA_ATTN_ABLATE != 5) dma_tile(tile + 2 * KS, dma_slot);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int df = 0; df < 4; ++df)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const bf16x8 vfrag = *reinterpret_cast<const bf16x8 *>(bv + swz(df * 16 + c16, kb * 4 + g));
-#pragma unroll
-                for (int qi = 0; qi < QI; ++qi)
-                    o[qi][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pf[qi][kb], o[qi][df], 0, 0, 0);
-            }
-        __syncthreads();
-    }
+            for (int kb = 0; kb < 2; ++kb)
+                if (GA_ATTN_ABLATE != 4) frag[df][kb] = *reinterpret_cast<const bf16x8 *>(bv + swz(df * 16 + c16, kb * 4 + g));
+        __builtin_amdgcn_sched_barrier(0);
 
+        if (TAIL) {
+            const int kbase = tile * KB + g * 8;
 #pragma unroll
-    for (int qi = 0; qi < QI; ++qi) {
-        float l = l_run[qi];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        const float inv = 1.0f / l;
-        const int row = q0 + qi * 16 + c16;
-        if (row < Lq) {
-            uint16_t *op = a.out + ((size_t)b * Lq + row) * a.out_stride + h * HD + g * 4;
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kbase + (kf >> 1) * 32 + (kf & 1) * 4 + r >= Lk) s[kf][r] = -1e30f;
+        }
+        float tmax = fmaxf(s[0][0], s[0][1]);
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[kf][r]);
+        tmax = group_max(tmax);
+        STAMP(4);
+        if (__builtin_amdgcn_ballot_w64(first || tmax > kLazy) != 0) {  // rare after the first tile
+            const float delta = first ? tmax : fmaxf(tmax, 0.f);
+            const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+            m_run += delta;
+            l_run *= alpha;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) {
+                s[kf][0] -= delta; s[kf][1] -= delta; s[kf][2] -= delta; s[kf][3] -= delta;
+            }
 #pragma unroll
             for (int df = 0; df < 4; ++df) {
-                const uint2 p = make_uint2(pack_bf16x2(o[qi][df][0] * inv, o[qi][df][1] * inv),
-                                           pack_bf16x2(o[qi][df][2] * inv, o[qi][df][3] * inv));
-                *reinterpret_cast<uint2 *>(op + df * 16) = p;
+                o[df][0] *= alpha; o[df][1] *= alpha; o[df][2] *= alpha; o[df][3] *= alpha;
             }
+        }
+        bf16x8 pf[2];
+        f32x2_t psum = {0.f, 0.f};
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                const f32x2_t p = GA_ATTN_ABLATE == 3 ? f32x2_t{s[kf][r], s[kf][r + 1]}
+                                                      : f32x2_t{__builtin_amdgcn_exp2f(s[kf][r]), __builtin_amdgcn_exp2f(s[kf][r + 1])};
+                psum += p;
+                pf[kf >> 1][(kf & 1) * 4 + r] = (short)f32_to_bf16(p[0]);
+                pf[kf >> 1][(kf & 1) * 4 + r + 1] = (short)f32_to_bf16(p[1]);
+            }
+        l_run += psum[0] + psum[1];
+        // ---- O^T += V^T P^T : o[df][r] = O[q = c16][d = df*16 + g*4 + r]; the lane's 8 P of block kb are keys 32 kb + 8 g ..
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(5);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int df = 0; df < 4; ++df)
+                if (GA_ATTN_ABLATE != 1) o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag[df][kb], pf[kb], o[df], 0, 0, 0);
+                else o[df][0] += __builtin_bit_cast(float, (int)frag[df][kb][0] ^ (int)pf[kb][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(6);
+    };
+
+    // ---- the walk: step t works on tile t*KS + ks in ring slot t % 3 while tile t+2 (DMA) / t+1 (registers) is staged.
+    // DMA form: counted wait for this wave's pieces of tile t, then a RAW s_barrier (everyone's pieces have landed and
+    // everyone has left tile t-1, whose slot the next DMA overwrites) -- __syncthreads() would drain vmcnt to 0.
+    if (KNORM) {
+        issue(ks);
+        write_lds(0);
+        issue(KS + ks);
+    } else {
+        dma_tile(ks, 0);
+        dma_tile(KS + ks, 1);
+    }
+    const int steps = (ntiles + KS - 1) / KS;
+    int s0 = 0, s1 = 1, s2 = 2;
+    for (int t = 0; t < steps; ++t) {
+        const int tile = t * KS + ks;
+        t_stamp = t;
+        STAMP(0);
+        if (KNORM) {
+            __syncthreads();
+            write_lds(s1);                        // tile t+1 into the slot tile t-2 left two barriers ago
+            issue(tile + 2 * KS);
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA_ATTN_ABLATE == 5 ? 0 : DPW) : "memory");
+            if (GA_ATTN_ABLATE != 6) __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(1);
+        if (tile < nfull) tile_math(tile, t == 0, s0, s2, std::false_type{});      // DMA of tile t+2 into the slot of tile t-1
+        else if (tile < ntiles) tile_math(tile, t == 0, s0, s2, std::true_type{});
+        else if (!KNORM && GA_ATTN_ABLATE != 5) dma_tile(tile + 2 * KS, s2);       // keeps the vmcnt arithmetic exact
+        STAMP(7);
+        const int r = s0; s0 = s1; s1 = s2; s2 = r;
+    }
+    if (!KNORM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS allocation
+    if (KS > 1) __syncthreads();                                   // ... nor land in the exchange area below
+
+    // ---- merge the key groups' partial softmax states (group 0 ends up with the total); the LDS tiles are dead
+    if (KS > 1) {
+        float *xch = reinterpret_cast<float *>(smem);  // [KS-1][NW][18][64]
+        if (ks > 0) {
+            float *dst = xch + ((size_t)(ks - 1) * NW + wq) * 18 * 64 + lane;
+            dst[0] = ks < ntiles ? m_run : -1e30f;
+            dst[64] = l_run;
+#pragma unroll
+            for (int df = 0; df < 4; ++df)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(2 + df * 4 + r) * 64] = o[df][r];
+        }
+        __syncthreads();
+        if (ks > 0) return;
+        float m_all = m_run;  // group 0 always has a tile (Lk >= 1)
+#pragma unroll
+        for (int k2 = 1; k2 < KS; ++k2) m_all = fmaxf(m_all, xch[((size_t)(k2 - 1) * NW + wq) * 18 * 64 + lane]);
+        const float w0 = __builtin_amdgcn_exp2f(m_run - m_all);
+        l_run *= w0;
+#pragma unroll
+        for (int df = 0; df < 4; ++df) { o[df][0] *= w0; o[df][1] *= w0; o[df][2] *= w0; o[df][3] *= w0; }
+#pragma unroll
+        for (int k2 = 1; k2 < KS; ++k2) {
+            const float *src = xch + ((size_t)(k2 - 1) * NW + wq) * 18 * 64 + lane;
+            const float wk = __builtin_amdgcn_exp2f(src[0] - m_all);
+            l_run += wk * src[64];
+#pragma unroll
+            for (int df = 0; df < 4; ++df)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[df][r] += wk * src[(2 + df * 4 + r) * 64];
+        }
+    }
+
+    float l = l_run;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int row = q0 + c16;
+    if (row < Lq) {
+        uint16_t *op = a.out + ((size_t)b * Lq + row) * a.out_stride + h * HD + g * 4;
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+            const uint2 p = make_uint2(pack_bf16x2(o[df][0] * inv, o[df][1] * inv), pack_bf16x2(o[df][2] * inv, o[df][3] * inv));
+            *reinterpret_cast<uint2 *>(op + df * 16) = p;
         }
     }
 }
 
+template <int NW, int KS>
+static void launch_attention(const GaAttentionArgs &a, hipStream_t s)
+{
+    const dim3 grid((a.Lq + NW * 16 - 1) / (NW * 16), a.heads, a.batch);
+    if (a.k_norm_weight) hipLaunchKernelGGL((attention_fwd_kernel<NW, KS, true>), grid, dim3(NW * KS * 64), 0, s, a);
+    else hipLaunchKernelGGL((attention_fwd_kernel<NW, KS, false>), grid, dim3(NW * KS * 64), 0, s, a);
+}
+
 }  // namespace gadit
+
+#ifdef GA_ATTN_STAMP
+extern "C" int ga_attn_debug_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gadit::g_attn_stamps), sizeof(unsigned long long) * 8 * 16 * 16);
+}
+#endif
 
 extern "C" int ga_attention_bf16(const GaAttentionArgs *a, void *stream)
 {
@@ -238,8 +401,13 @@ extern "C" int ga_attention_bf16(const GaAttentionArgs *a, void *stream)
         a->vt_ld < ((a->Lk + KB - 1) / KB) * KB || a->out_stride % 4)
         return GA_DIT_ERR_BAD_SHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    constexpr int QB = 128;  // 8 waves x 16 rows
-    const dim3 grid((a->Lq + QB - 1) / QB, a->heads, a->batch);
-    hipLaunchKernelGGL((attention_fwd_kernel<8, 1>), grid, dim3(512), 0, s, *a);
+    // 128-query workgroups when they fill the chip; otherwise (the conditional half of a CFG pair alone in the image
+    // cross-attention: 6 x 16 x 1 = 96 workgroups for 256 CUs) 64-query workgroups with two key groups -- measured on
+    // MI355X, B = 1, 16 heads, 768 x 1369: 20.7 -> 15.0 us; B = 2: 22.3 us (<8,1>) vs 28.5 us (<4,2>).
+    static const int cfg = [] { const char *e = getenv("GA_ATTN_CFG"); return e ? atoi(e) : 0; }();  // NW*10 + KS
+    const int64_t wgs128 = (int64_t)((a->Lq + 127) / 128) * a->heads * a->batch;
+    const bool split = cfg ? cfg == 42 : wgs128 <= 128;
+    if (split) launch_attention<4, 2>(*a, s);
+    else launch_attention<8, 1>(*a, s);
     return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
 }

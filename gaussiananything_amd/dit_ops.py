@@ -138,9 +138,12 @@ def attention(q, k, vt, q_norm_weight=None, k_norm_weight=None):
     B, Lq, H, d = q.shape
     Lk = k.shape[1]
     assert d == 64 and q.stride(3) == 1 and q.stride(2) == 64 and k.stride(2) == 64 and vt.stride(1) == 1
-    assert q.stride(0) == Lq * q.stride(1) and k.stride(0) == Lk * k.stride(1) and vt.shape[0] == B * H * 64
+    # the C-ABI addresses row (b, i) at (b * L + i) * stride; a size-1 token axis has no meaningful stride of its own in torch
+    qs = q.stride(1) if Lq > 1 else q.stride(0)
+    ks = k.stride(1) if Lk > 1 else k.stride(0)
+    assert q.stride(0) == Lq * qs and k.stride(0) == Lk * ks and vt.shape[0] == B * H * 64
     out = torch.empty((B, Lq, H * 64), device=q.device, dtype=torch.bfloat16)
-    a = GaAttentionArgs(B, H, Lq, Lk, q.data_ptr(), k.data_ptr(), vt.data_ptr(), q.stride(1), k.stride(1), vt.stride(0),
+    a = GaAttentionArgs(B, H, Lq, Lk, q.data_ptr(), k.data_ptr(), vt.data_ptr(), qs, ks, vt.stride(0),
                         _ptr(q_norm_weight), _ptr(k_norm_weight), out.data_ptr(), H * 64)
     check(lib().ga_attention_bf16(ctypes.byref(a), _stream(q)), "ga_attention_bf16")
     return out

@@ -90,8 +90,14 @@ def test_gemm_is_transpose_sensitive(gpu_device):
     assert torch.equal(out, W.float().T)
 
 
-@pytest.mark.parametrize("B,H,Lq,Lk,norm", [(2, 2, 64, 64, True), (1, 3, 100, 137, True), (2, 16, 768, 768, True),
-                                             (2, 4, 96, 1369, True), (1, 2, 48, 80, False)])
+# norm: "qk" = q and k RMS-normalised in the kernel (register-staged variant), "q" = only q (k arrives normalised from the
+# projection GEMM, as in the DiT forward), "" = neither: the last two run the LDS-DMA variants -- 128-query workgroups when
+# they fill half the chip, else 64-query workgroups with two key groups (ragged last tiles, 1-tile and 1-key inputs included)
+@pytest.mark.parametrize("B,H,Lq,Lk,norm", [(2, 2, 64, 64, "qk"), (1, 3, 100, 137, "qk"), (2, 16, 768, 768, "qk"),
+                                             (2, 4, 96, 1369, "qk"), (1, 2, 48, 80, ""), (2, 16, 768, 768, ""),
+                                             (2, 16, 768, 768, "q"), (2, 16, 700, 1369, ""), (1, 16, 768, 1369, "q"),
+                                             (3, 16, 768, 100, ""), (3, 16, 520, 1, ""), (1, 1, 5, 63, ""),
+                                             (1, 2, 130, 129, "q")])
 def test_attention(gpu_device, B, H, Lq, Lk, norm):
     from gaussiananything_amd import dit_ops as ops
     g = torch.Generator(device="cpu").manual_seed(B * 1000 + Lq + Lk)
@@ -103,10 +109,11 @@ def test_attention(gpu_device, B, H, Lq, Lk, norm):
     q = qkv_q[..., :D].unflatten(-1, (H, 64))
     k = kvbuf[..., :D].unflatten(-1, (H, 64))
     v = kvbuf[..., D:].unflatten(-1, (H, 64))
-    out = ops.attention(q, k, ops.transpose_v(v), qn if norm else None, kn if norm else None)
+    out = ops.attention(q, k, ops.transpose_v(v), qn if "q" in norm else None, kn if "k" in norm else None)
     qf, kf, vf = q.float().permute(0, 2, 1, 3), k.float().permute(0, 2, 1, 3), v.float().permute(0, 2, 1, 3)
-    if norm:
+    if "q" in norm:
         qf = qf * torch.rsqrt(qf.pow(2).mean(-1, keepdim=True) + 1e-5) * qn
+    if "k" in norm:
         kf = kf * torch.rsqrt(kf.pow(2).mean(-1, keepdim=True) + 1e-5) * kn
     ref = torch.softmax(qf @ kf.transpose(-1, -2) * 0.125, -1) @ vf
     ref = ref.permute(0, 2, 1, 3).reshape(B, Lq, D)

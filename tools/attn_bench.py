@@ -16,7 +16,7 @@ def timeit(fn, n=200):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3  # us
 
-for (B, H, Lq, Lk) in [(2, 16, 768, 768), (2, 16, 768, 1369), (2, 12, 768, 768), (2, 12, 768, 1369)]:
+for (B, H, Lq, Lk) in [(2, 16, 768, 768), (2, 16, 768, 1369), (1, 16, 768, 1369), (2, 12, 768, 768), (1, 12, 768, 1369)]:
     D = H * 64
     q = torch.randn(B, Lq, D, device=dev).bfloat16(); kv = torch.randn(B, Lk, 2 * D, device=dev).bfloat16()
     qq = q.unflatten(-1, (H, 64)); k = kv[..., :D].unflatten(-1, (H, 64)); v = kv[..., D:].unflatten(-1, (H, 64))
