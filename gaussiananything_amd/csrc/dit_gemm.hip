@@ -25,6 +25,10 @@
 
 namespace gadit {
 
+#ifndef GA_GEMM_ABLATE
+#define GA_GEMM_ABLATE 0   // tools/gemm_ablate.sh: timing-only builds with phases removed (wrong results); bit mask:
+                           // 1 MFMAs, 2 DMA in the K loop, 4 barrier, 8 epilogue, 16 fragment reads; 32 = no K loop at all
+#endif
 constexpr int BN = 128, BK = 64;
 constexpr int TILE_ELEMS = 128 * BK;  // one operand tile: 128 rows x 64 bf16 = 16 KiB
 
@@ -47,28 +51,86 @@ __device__ __forceinline__ void glds16(const uint16_t *gsrc, uint16_t *lds_wave_
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <int EPI, int MT>
-__device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[4][MT], int m0, int n0, int wn, int wm, int lane)
+// exact-GELU's erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of the result): ~14 VALU
+// instructions instead of erff()'s ~45 with branches -- in the fc1 GEMM (6.3 M evaluations) the libm form was 40 % of the
+// kernel (in-situ ablation, tools/gemm_ablate.py)
+__device__ __forceinline__ float gelu_erf(float v)
+{
+    const float x = fabsf(v) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);
+    const float erf_abs = 1.0f - poly * t * e;            // erf(|v| / sqrt 2)
+    return 0.5f * (v + fabsf(v) * erf_abs);               // 0.5 v (1 + sign(v) erf(|v|/sqrt 2))
+}
+
+// The accumulator fragment layout gives a lane 4 consecutive columns per fragment (n = i*16 + g*4 + r for row m = lane&15);
+// one v_permlane16_swap per register between the fragments of a pair (2q, 2q+1) turns that into 8 consecutive columns per
+// lane, n = q*32 + (g&1)*16 + (g>>1)*8 + e, so the four lanes of a row cover 32 consecutive columns: whole 128-byte lines
+// of the fp32 residual stream (two float4 per lane) and 16-byte bf16 stores, instead of 64- / 32-byte pieces per row.
+__device__ __forceinline__ void pair_exchange(const f32x4 &a, const f32x4 &b, float (&w)[8])
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[r]), __float_as_uint(b[r]), false, false);
+        w[r] = __uint_as_float(sw[0]);
+        w[4 + r] = __uint_as_float(sw[1]);
+    }
+}
+
+// residual-stream operands of the gated-accumulate epilogue in the exchanged layout, fetched before the K loop
+template <int MT>
+struct ResidualPrefetch {
+    f32x4 x[MT][2][2], gate[MT][2][2];
+};
+
+template <int MT>
+__device__ __forceinline__ void residual_prefetch(const GemmP &p, ResidualPrefetch<MT> &pf, int m0, int n0, int wn, int wm, int lane)
+{
+    const int g = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int m = min(m0 + wm * (MT * 16) + j * 16 + (lane & 15), p.M - 1);
+        const float *gate_row = p.gate ? p.gate + (size_t)(m / p.rows_per_batch) * p.gate_stride : nullptr;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int n = min(n0 + wn * 64 + q * 32 + (g & 1) * 16 + (g >> 1) * 8 + hh * 4, p.N - 4);
+                const float4 xv = *reinterpret_cast<const float4 *>(static_cast<const float *>(p.out) + (size_t)m * p.ldo + n);
+                pf.x[j][q][hh] = f32x4{xv.x, xv.y, xv.z, xv.w};
+                float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (gate_row) gv = *reinterpret_cast<const float4 *>(gate_row + n);
+                pf.gate[j][q][hh] = f32x4{gv.x, gv.y, gv.z, gv.w};
+            }
+    }
+}
+
+template <int EPI, int MT, bool PRE>
+__device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[4][MT], const ResidualPrefetch<MT> *pre, int m0, int n0,
+                                              int wn, int wm, int lane)
 {
     const int M = p.M, N = p.N;
     // epilogue: lane holds acc[i][j][r] = C[m = m0 + wm*MT*16 + j*16 + (lane&15)][n = n0 + wn*64 + i*16 + (lane>>4)*4 + r];
     // the 64 columns of a wave are one attention head: its 64 values of row m sit in 4 fragments x 4 lane-groups x 4
     // registers, so the per-head RMSNorm is an in-lane sum plus two xor-shuffles
-    const int nhead = n0 + wn * 64;
+    const int nhead = n0 + wn * 64, g = lane >> 4;
     const float *qkw = nullptr;
     if (EPI == GA_GEMM_EPI_STORE_BF16) {
         if (nhead < p.qk_cols0) qkw = p.qk_w0;
         else if (nhead < p.qk_cols1) qkw = p.qk_w1;
     }
+    const bool to_vt = EPI == GA_GEMM_EPI_STORE_BF16 && p.vt && nhead >= p.vt_col0;  // wave-uniform (vt_col0 % 64 == 0)
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int m = m0 + wm * (MT * 16) + j * 16 + (lane & 15);
-        const float *gate_row = nullptr;
-        if (EPI == GA_GEMM_EPI_RESIDUAL && p.gate && m < M) gate_row = p.gate + (size_t)(m / p.rows_per_batch) * p.gate_stride;
         f32x4 v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int n = nhead + i * 16 + (lane >> 4) * 4;
+            const int n = nhead + i * 16 + g * 4;
             v[i] = acc[i][j];
             if (p.bias && n < N) {
                 const float4 b = *reinterpret_cast<const float4 *>(p.bias + n);
@@ -84,37 +146,67 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[4][MT
             const float rs = rsqrtf(ss * (1.0f / 64.0f) + 1e-5f);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float4 w = *reinterpret_cast<const float4 *>(qkw + i * 16 + (lane >> 4) * 4);
+                const float4 w = *reinterpret_cast<const float4 *>(qkw + i * 16 + g * 4);
                 v[i][0] *= rs * w.x; v[i][1] *= rs * w.y; v[i][2] *= rs * w.z; v[i][3] *= rs * w.w;
             }
         }
-        if (m >= M) continue;
+        if (EPI == GA_GEMM_EPI_GELU_BF16) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = nhead + i * 16 + (lane >> 4) * 4;
-            if (n >= N) continue;
-            if (EPI == GA_GEMM_EPI_GELU_BF16) {
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[i][r] = 0.5f * v[i][r] * (1.0f + erff(v[i][r] * 0.70710678118654752f));
-            }
-            if (EPI == GA_GEMM_EPI_STORE_BF16 && p.vt && n >= p.vt_col0) {
-                // V projection: write V^T[(b*heads + h)*64 + d][token]; 16 consecutive lanes hold 16 consecutive tokens
-                const int b = m / p.rows_per_batch, tok = m - b * p.rows_per_batch, dn = n - p.vt_col0;
-                uint16_t *dst = p.vt + ((size_t)b * p.heads * 64 + dn) * p.vt_ld + tok;
+                for (int r = 0; r < 4; ++r) v[i][r] = gelu_erf(v[i][r]);
+        }
+        if (to_vt) {
+            // V projection: write V^T[(b*heads + h)*64 + d][token]; 16 consecutive lanes hold 16 consecutive tokens
+            if (m >= M) continue;
+            const int b = m / p.rows_per_batch, tok = m - b * p.rows_per_batch;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = nhead + i * 16 + g * 4;
+                if (n >= N) continue;
+                uint16_t *dst = p.vt + ((size_t)b * p.heads * 64 + (n - p.vt_col0)) * p.vt_ld + tok;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dst[(size_t)r * p.vt_ld] = f32_to_bf16(v[i][r]);
-            } else if (EPI == GA_GEMM_EPI_STORE_BF16 || EPI == GA_GEMM_EPI_GELU_BF16) {
-                uint2 pk = make_uint2(pack_bf16x2(v[i][0], v[i][1]), pack_bf16x2(v[i][2], v[i][3]));
-                *reinterpret_cast<uint2 *>(static_cast<uint16_t *>(p.out) + (size_t)m * p.ldo + n) = pk;
+            }
+            continue;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float w[8];
+            pair_exchange(v[2 * q], v[2 * q + 1], w);   // every lane takes part, also rows m >= M
+            const int n = nhead + q * 32 + (g & 1) * 16 + (g >> 1) * 8;
+            if (m >= M || n >= N) continue;
+            const bool hi = n + 4 < N;                   // N % 4 == 0: the second half of the 8 may lie past the edge
+            if (EPI == GA_GEMM_EPI_STORE_BF16 || EPI == GA_GEMM_EPI_GELU_BF16) {
+                uint16_t *dst = static_cast<uint16_t *>(p.out) + (size_t)m * p.ldo + n;
+                const uint2 lo = make_uint2(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]));
+                const uint2 hi2 = make_uint2(pack_bf16x2(w[4], w[5]), pack_bf16x2(w[6], w[7]));
+                if (hi && (p.ldo & 7) == 0) *reinterpret_cast<uint4 *>(dst) = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+                else {
+                    *reinterpret_cast<uint2 *>(dst) = lo;
+                    if (hi) *reinterpret_cast<uint2 *>(dst + 4) = hi2;
+                }
             } else {
                 float4 *dst = reinterpret_cast<float4 *>(static_cast<float *>(p.out) + (size_t)m * p.ldo + n);
                 if (EPI == GA_GEMM_EPI_RESIDUAL) {
-                    float4 gt = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (gate_row) gt = *reinterpret_cast<const float4 *>(gate_row + n);
-                    const float4 x = *dst;
-                    *dst = make_float4(x.x + gt.x * v[i][0], x.y + gt.y * v[i][1], x.z + gt.z * v[i][2], x.w + gt.w * v[i][3]);
+                    f32x4 x0, x1, g0 = f32x4{1.f, 1.f, 1.f, 1.f}, g1 = g0;
+                    if (PRE) {
+                        x0 = pre->x[j][q][0]; x1 = pre->x[j][q][1]; g0 = pre->gate[j][q][0]; g1 = pre->gate[j][q][1];
+                    } else {
+                        const float4 a0 = dst[0], a1 = hi ? dst[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        x0 = f32x4{a0.x, a0.y, a0.z, a0.w}; x1 = f32x4{a1.x, a1.y, a1.z, a1.w};
+                        if (p.gate) {
+                            const float *gate_row = p.gate + (size_t)(m / p.rows_per_batch) * p.gate_stride + n;
+                            const float4 b0 = *reinterpret_cast<const float4 *>(gate_row);
+                            const float4 b1 = hi ? *reinterpret_cast<const float4 *>(gate_row + 4) : b0;
+                            g0 = f32x4{b0.x, b0.y, b0.z, b0.w}; g1 = f32x4{b1.x, b1.y, b1.z, b1.w};
+                        }
+                    }
+                    dst[0] = make_float4(x0[0] + g0[0] * w[0], x0[1] + g0[1] * w[1], x0[2] + g0[2] * w[2], x0[3] + g0[3] * w[3]);
+                    if (hi) dst[1] = make_float4(x1[0] + g1[0] * w[4], x1[1] + g1[1] * w[5], x1[2] + g1[2] * w[6], x1[3] + g1[3] * w[7]);
                 } else {
-                    *dst = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+                    dst[0] = make_float4(w[0], w[1], w[2], w[3]);
+                    if (hi) dst[1] = make_float4(w[4], w[5], w[6], w[7]);
                 }
             }
         }
@@ -154,6 +246,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the residual rows and gates of the gated-accumulate epilogue are requested before the K loop (they are older than every
+    // DMA, so the counted vmcnt waits below still mean what they say); only with one workgroup per CU, where the 64-128
+    // extra VGPRs are free
+    constexpr bool PRE = EPI == GA_GEMM_EPI_RESIDUAL && NST >= 4;
+    ResidualPrefetch<PRE ? MT : 1> pre;
+    if (PRE) residual_prefetch<MT>(p, reinterpret_cast<ResidualPrefetch<MT> &>(pre), m0, n0, wn, wm, lane);
 
     const int frow = lane & 15, g = lane >> 4;
     const int nk = K / BK;
@@ -171,26 +269,37 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
     } while (0)
 #define GA_COMPUTE(BUF)                                                                               \
     do {                                                                                              \
+        /* all fragment reads of the K-tile go out in one batch (pinned), then the MFMAs */            \
         const uint16_t *bw_ = smem + (BUF) * SLOT, *ba_ = bw_ + TILE_ELEMS;                            \
+        bf16x8 fw[2][4], fa[2][MT];                                                                   \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                            \
-            bf16x8 fw[4], fa[MT];                                                                     \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
                 const int rw = wn * 64 + i * 16 + frow;                                               \
-                fw[i] = *reinterpret_cast<const bf16x8 *>(bw_ + rw * BK + (((kk * 4 + g) ^ (rw & 7)) * 8)); \
+                if (GA_GEMM_ABLATE & 16) fw[kk][i] = bf16x8{(short)rw, 1, 2, 3, 4, 5, 6, 7};              \
+                else fw[kk][i] = *reinterpret_cast<const bf16x8 *>(bw_ + rw * BK + (((kk * 4 + g) ^ (rw & 7)) * 8)); \
             }                                                                                         \
             _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                          \
                 const int ra = wm * (MT * 16) + i * 16 + frow;                                        \
-                fa[i] = *reinterpret_cast<const bf16x8 *>(ba_ + ra * BK + (((kk * 4 + g) ^ (ra & 7)) * 8)); \
+                if (GA_GEMM_ABLATE & 16) fa[kk][i] = bf16x8{(short)ra, 1, 2, 3, 4, 5, 6, 7};              \
+                else fa[kk][i] = *reinterpret_cast<const bf16x8 *>(ba_ + ra * BK + (((kk * 4 + g) ^ (ra & 7)) * 8)); \
             }                                                                                         \
+        }                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                              \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
                 _Pragma("unroll") for (int j = 0; j < MT; ++j)                                        \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0); \
-        }                                                                                             \
+                    if (!(GA_GEMM_ABLATE & 1)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kk][i], fa[kk][j], acc[i][j], 0, 0, 0); \
+                    else acc[i][j][0] += __builtin_bit_cast(float, (int)fw[kk][i][0] ^ (int)fa[kk][j][0]); \
     } while (0)
 
     // ring of NST slots: tiles kt+1 .. kt+NST-1 are in flight while tile kt is multiplied (NST-1 tiles of look-ahead).
     // NST = 4 (128 KiB, one workgroup per CU) for the small grids, NST = 2 (64 KiB, two workgroups per CU, which hide each
     // other's latency) when the grid has more than one workgroup per CU -- chosen by the host from the grid size.
+    // What bounds the K loop at the DiT shapes is LDS traffic, not latency or the matrix pipe (in-situ ablation,
+    // tools/gemm_ablate.py, N = 1024, K = 4096: 30.3 us; without MFMAs 29.2; without the fragment reads 22.9; without the
+    // DMA 22.1; without all three 12.7): a 128 x 64 tile reads 48 KiB of fragments and takes 24 KiB of DMA writes per
+    // 272 cycles of MFMA work.  Reading the next tile's fragments under the current MFMAs (register double buffer) and a
+    // 6-slot ring were both measured: no gain.
 #define GA_WAIT_TILES_IN_FLIGHT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((N) * DMA_PER_TILE) : "memory")
 #define GA_PHASE(BUF, KT)                                                                              \
     do {                                                                                               \
@@ -198,13 +307,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
         if (NST >= 4 && rem_ >= 2) GA_WAIT_TILES_IN_FLIGHT(2);                                          \
         else if (NST >= 3 && rem_ >= 1) GA_WAIT_TILES_IN_FLIGHT(1);                                     \
         else GA_WAIT_TILES_IN_FLIGHT(0);                                                                \
-        __builtin_amdgcn_s_barrier(); /* everyone's part of tile KT landed; everyone left tile KT-1 */  \
-        if ((KT) + NST - 1 < nk) GA_STAGE(((BUF) + NST - 1) % NST, (KT) + NST - 1);                     \
+        if (!(GA_GEMM_ABLATE & 4)) __builtin_amdgcn_s_barrier(); /* everyone's part of tile KT landed; everyone left tile KT-1 */  \
+        if (!(GA_GEMM_ABLATE & 2) && (KT) + NST - 1 < nk) GA_STAGE(((BUF) + NST - 1) % NST, (KT) + NST - 1); \
         GA_COMPUTE(BUF);                                                                                \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* my fragment reads of this buffer are done */ \
     } while (0)
 
     GA_STAGE(0, 0);
+    if (GA_GEMM_ABLATE == 32) {  // launch + prologue + epilogue only
+        gemm_epilogue<EPI, MT, PRE>(p, acc, reinterpret_cast<const ResidualPrefetch<MT> *>(&pre), m0, n0, wn, wm, lane);
+        return;
+    }
     if (NST > 2 && nk > 1) GA_STAGE(1 % NST, 1);
     if (NST > 3 && nk > 2) GA_STAGE(2 % NST, 2);
     for (int kt = 0; kt < nk; kt += NST) {
@@ -218,7 +331,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
 #undef GA_STAGE
 #undef GA_COMPUTE
 
-    gemm_epilogue<EPI, MT>(p, acc, m0, n0, wn, wm, lane);
+    if (GA_GEMM_ABLATE & 8) {  // one store per lane instead of the epilogue
+        float t = 0.f;
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < MT; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 12345.f) static_cast<float *>(p.out)[tid] = t;
+        return;
+    }
+    gemm_epilogue<EPI, MT, PRE>(p, acc, reinterpret_cast<const ResidualPrefetch<MT> *>(&pre), m0, n0, wn, wm, lane);
 }
 
 // A register-FIFO variant of this kernel (global_load_dwordx4 into D = 4 / 8 K-tiles of VGPRs, ds_write into a double

@@ -15,12 +15,20 @@ def timeit(fn, n=100):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3  # us
 
+COLD = bool(os.environ.get("GA_COLD"))   # rotate through > 512 MB of distinct weights, as one DiT evaluation does (0.8 GB)
+
 def run(M, N, K, epi):
-    A = torch.randn(M, K, device=dev).bfloat16(); W = torch.randn(N, K, device=dev).bfloat16() / 32
+    A = torch.randn(M, K, device=dev).bfloat16()
+    nW = max(1, (640 << 20) // (N * K * 2)) if COLD else 1
+    Ws = [torch.randn(N, K, device=dev).bfloat16() / 32 for _ in range(nW)]
     bias = torch.randn(N, device=dev)
     out = torch.zeros(M, N, device=dev) if epi in (2, 3) else torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    us = timeit(lambda: ops.gemm(A, W, bias, epi, out=out))
-    print(f"gemm M={M:5d} N={N:5d} K={K:5d} epi={epi}: {us:7.1f} us  {2*M*N*K/us/1e6:7.1f} TF/s", flush=True)
+    it = [0]
+    def fn():
+        it[0] = (it[0] + 1) % nW
+        ops.gemm(A, Ws[it[0]], bias, epi, out=out)
+    us = timeit(fn, 200 if COLD else 100)
+    print(f"gemm M={M:5d} N={N:5d} K={K:5d} epi={epi}{' cold' if COLD else ''}: {us:7.1f} us  {2*M*N*K/us/1e6:7.1f} TF/s", flush=True)
 
 if os.environ.get("GA_ONE_SHAPE"):
     n_, k_, e_ = [int(x) for x in os.environ["GA_ONE_SHAPE"].split(",")]
