@@ -68,6 +68,8 @@ __global__ __launch_bounds__(256) void rmsnorm_modulate_kernel(GaRmsNormArgs a)
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
 
+// One wave per output feature n; a lane owns 8 consecutive k of every 512-wide chunk (one 16-byte weight load, two float4
+// loads per batch row), so K = 1024 is two independent round trips instead of 16 dependent scalar ones.  K % 8 == 0.
 __global__ __launch_bounds__(256) void small_linear_kernel(GaSmallLinearArgs a)
 {
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -76,15 +78,28 @@ __global__ __launch_bounds__(256) void small_linear_kernel(GaSmallLinearArgs a)
 #pragma unroll
     for (int b = 0; b < 16; ++b) acc[b] = 0.f;
     const uint16_t *w = a.W + (size_t)n * a.K;
-    for (int k = lane; k < a.K; k += 64) {
-        const float wv = bf16_to_f32(w[k]);
+#pragma unroll 2
+    for (int k = lane * 8; k < a.K; k += 512) {
+        const uint4 wr = *reinterpret_cast<const uint4 *>(w + k);
+        const uint32_t ww[4] = {wr.x, wr.y, wr.z, wr.w};
+        float wv[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            wv[2 * e] = __uint_as_float(ww[e] << 16);
+            wv[2 * e + 1] = __uint_as_float(ww[e] & 0xffff0000u);
+        }
 #pragma unroll
         for (int b = 0; b < 16; ++b)
             if (b < a.B) {
-                float xv = a.x[(size_t)b * a.K + k];
-                if (a.act_in == 1) xv = silu(xv);
-                // the reference runs these Linear layers under bf16 autocast: inputs are rounded to bf16
-                acc[b] += bf16_to_f32(f32_to_bf16(xv)) * wv;
+                const float4 x0 = *reinterpret_cast<const float4 *>(a.x + (size_t)b * a.K + k);
+                const float4 x1 = *reinterpret_cast<const float4 *>(a.x + (size_t)b * a.K + k + 4);
+                float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (a.act_in == 1) xv[e] = silu(xv[e]);
+                    // the reference runs these Linear layers under bf16 autocast: inputs are rounded to bf16
+                    acc[b] += bf16_to_f32(f32_to_bf16(xv[e])) * wv[e];
+                }
             }
     }
 #pragma unroll
@@ -195,34 +210,66 @@ struct FinalArgs {
     float *out;
 };
 
+// One wave per row, the row (D <= 2048, D % 4 == 0) held in registers as in rmsnorm_modulate_kernel: one memory round trip
+// for x / table / t, the LayerNorm statistics by two wave sums, then Cout <= 16 dot products against the L2-resident weight.
 __global__ __launch_bounds__(256) void final_layer_kernel(FinalArgs a)
 {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= a.M) return;
     const int D = a.D, b = row / a.rows_per_batch;
-    const float *x = a.x + (size_t)row * D;
+    const float *x = a.x + (size_t)row * D, *tb = a.t + (size_t)b * D;
+    float4 v[8], sh[8], sc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int d = c * 256 + lane * 4;
+        if (d < D) {
+            v[c] = *reinterpret_cast<const float4 *>(x + d);
+            const float4 t4 = *reinterpret_cast<const float4 *>(tb + d);
+            const float4 h4 = *reinterpret_cast<const float4 *>(a.table + d);
+            const float4 s4 = *reinterpret_cast<const float4 *>(a.table + D + d);
+            sh[c] = make_float4(h4.x + t4.x, h4.y + t4.y, h4.z + t4.z, h4.w + t4.w);
+            sc[c] = make_float4(s4.x + t4.x, s4.y + t4.y, s4.z + t4.z, s4.w + t4.w);
+        }
+    }
     float s = 0.f;
-    for (int d = lane; d < D; d += 64) s += x[d];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (c * 256 + lane * 4 < D) s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
-    for (int d = lane; d < D; d += 64) { const float c = x[d] - mean; q += c * c; }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (c * 256 + lane * 4 < D) {
+            v[c].x -= mean; v[c].y -= mean; v[c].z -= mean; v[c].w -= mean;
+            q += v[c].x * v[c].x + v[c].y * v[c].y + v[c].z * v[c].z + v[c].w * v[c].w;
+        }
     const float rs = rsqrtf(wave_sum(q) / (float)D + 1e-6f);
     float acc[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) acc[c] = 0.f;
-    for (int d = lane; d < D; d += 64) {
-        const float shift = a.table[d] + a.t[(size_t)b * D + d];
-        const float scale = a.table[D + d] + a.t[(size_t)b * D + d];
-        const float y = bf16_to_f32(f32_to_bf16((x[d] - mean) * rs * (1.0f + scale) + shift));
 #pragma unroll
-        for (int c = 0; c < 16; ++c)
-            if (c < a.Cout) acc[c] += y * bf16_to_f32(f32_to_bf16(a.w[(size_t)c * D + d]));
+    for (int c = 0; c < 8; ++c) {
+        const int d = c * 256 + lane * 4;
+        if (d < D) {
+            // the reference runs the Linear under bf16 autocast: its input and weight are rounded to bf16
+            const float y[4] = {bf16_to_f32(f32_to_bf16(v[c].x * rs * (1.0f + sc[c].x) + sh[c].x)),
+                                bf16_to_f32(f32_to_bf16(v[c].y * rs * (1.0f + sc[c].y) + sh[c].y)),
+                                bf16_to_f32(f32_to_bf16(v[c].z * rs * (1.0f + sc[c].z) + sh[c].z)),
+                                bf16_to_f32(f32_to_bf16(v[c].w * rs * (1.0f + sc[c].w) + sh[c].w))};
+#pragma unroll
+            for (int o = 0; o < 16; ++o)
+                if (o < a.Cout) {
+                    const float4 w4 = *reinterpret_cast<const float4 *>(a.w + (size_t)o * D + d);
+                    acc[o] += y[0] * bf16_to_f32(f32_to_bf16(w4.x)) + y[1] * bf16_to_f32(f32_to_bf16(w4.y)) +
+                              y[2] * bf16_to_f32(f32_to_bf16(w4.z)) + y[3] * bf16_to_f32(f32_to_bf16(w4.w));
+                }
+        }
     }
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
-        if (c < a.Cout) {
-            const float v = wave_sum(acc[c]);
-            if (lane == 0) a.out[(size_t)row * a.Cout + c] = v + a.bias[c];
+    for (int o = 0; o < 16; ++o)
+        if (o < a.Cout) {
+            const float r = wave_sum(acc[o]);
+            if (lane == 0) a.out[(size_t)row * a.Cout + o] = r + a.bias[o];
         }
 }
 
@@ -243,7 +290,7 @@ extern "C" int ga_small_linear(const GaSmallLinearArgs *a, void *stream)
 {
     using namespace gadit;
     if (!a || !a->x || !a->W || !a->y) return GA_DIT_ERR_NULL_ARG;
-    if (a->B <= 0 || a->B > 16 || a->N <= 0 || a->K <= 0) return GA_DIT_ERR_BAD_SHAPE;
+    if (a->B <= 0 || a->B > 16 || a->N <= 0 || a->K <= 0 || a->K % 8 != 0) return GA_DIT_ERR_BAD_SHAPE;
     hipLaunchKernelGGL(small_linear_kernel, dim3((a->N + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
     return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
 }

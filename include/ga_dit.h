@@ -103,7 +103,7 @@ typedef struct GaRmsNormArgs {
 int ga_rmsnorm_modulate(const GaRmsNormArgs *args, void *stream);
 
 /* Small dense layer for the conditioning path (a handful of rows):
- *   y[b][n] = act_out( sum_k act_in(x[b][k]) * W[n][k] + bias[n] ) (+ add[b][n]);  act: 0 none, 1 SiLU.  B <= 16. */
+ *   y[b][n] = act_out( sum_k act_in(x[b][k]) * W[n][k] + bias[n] ) (+ add[b][n]);  act: 0 none, 1 SiLU.  B <= 16, K % 8 == 0. */
 typedef struct GaSmallLinearArgs {
     int32_t B, N, K, act_in, act_out;
     const float *x;      /* [B, K]            */
