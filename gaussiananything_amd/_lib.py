@@ -40,7 +40,14 @@ class GaSurfelWorkspaceLayout(ctypes.Structure):
         "point_list", "total_bytes")]
 
 
-EXPORTS = ("ga_surfel_version", "ga_surfel_workspace_layout", "ga_surfel_forward")
+class GaSurfelPostArgs(ctypes.Structure):
+    """include/ga_surfel.h: GaSurfelPostArgs"""
+    _fields_ = [("num_views", ctypes.c_int32), ("image_height", ctypes.c_int32), ("image_width", ctypes.c_int32),
+                ("color", ctypes.c_void_p), ("allmap", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p),
+                ("image", ctypes.c_void_p), ("rend_normal", ctypes.c_void_p), ("depth", ctypes.c_void_p)]
+
+
+EXPORTS = ("ga_surfel_version", "ga_surfel_workspace_layout", "ga_surfel_forward", "ga_surfel_postprocess")
 
 _lib = None
 
@@ -70,6 +77,8 @@ def lib():
                                                                        ctypes.POINTER(GaSurfelWorkspaceLayout)]
         L.ga_surfel_forward.restype = ctypes.c_int
         L.ga_surfel_forward.argtypes = [ctypes.POINTER(GaSurfelForwardArgs), ctypes.c_void_p]
+        L.ga_surfel_postprocess.restype = ctypes.c_int
+        L.ga_surfel_postprocess.argtypes = [ctypes.POINTER(GaSurfelPostArgs), ctypes.c_void_p]
         _lib = L
     return _lib
 

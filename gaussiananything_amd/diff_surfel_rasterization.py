@@ -90,6 +90,28 @@ def _f32c(t: torch.Tensor, name: str, device) -> torch.Tensor:
 _warned_grad = False
 
 
+def postprocess_views(color, allmap, viewmatrix, image=None, rend_normal=None, depth=None):
+    """The per-pixel post-processing of ``GaussianRenderer2DGS.render`` (nsr/gs_surfel.py:121-163) over the stacked outputs
+    of ``rasterize_views`` in ONE pass (``ga_surfel_postprocess``): ``image = clamp(color, 0, 1)``, ``rend_normal`` =
+    ``allmap[:, 2:5]`` rotated from view to world space, ``depth = nan_to_num(allmap[:, 5:6], 0, 0)``.  The optional
+    outputs are written in place (contiguous ``[V,3,H,W]``, ``[V,3,H,W]``, ``[V,1,H,W]``)."""
+    if color.device.type != "cuda":
+        raise RuntimeError("gaussiananything_amd surfel post-processing only runs on an MI355X (HIP) device")
+    V, _, H, W = color.shape
+    assert allmap.shape == (V, 7, H, W) and color.is_contiguous() and allmap.is_contiguous()
+    vm = viewmatrix.detach().to(device=color.device, dtype=torch.float32).reshape(V, 16).contiguous()
+    image = torch.empty_like(color) if image is None else image
+    rend_normal = torch.empty_like(color) if rend_normal is None else rend_normal
+    depth = torch.empty((V, 1, H, W), dtype=torch.float32, device=color.device) if depth is None else depth
+    for t, shp in ((image, (V, 3, H, W)), (rend_normal, (V, 3, H, W)), (depth, (V, 1, H, W))):
+        assert t.shape == shp and t.is_contiguous() and t.dtype == torch.float32 and t.device == color.device
+    args = _lib.GaSurfelPostArgs(V, H, W, color.data_ptr(), allmap.data_ptr(), vm.data_ptr(), image.data_ptr(),
+                                 rend_normal.data_ptr(), depth.data_ptr())
+    stream = ctypes.c_void_p(torch.cuda.current_stream(color.device).cuda_stream)
+    _lib.check(_lib.lib().ga_surfel_postprocess(ctypes.byref(args), stream), "ga_surfel_postprocess")
+    return image, rend_normal, depth
+
+
 def rasterize_views(means3D, opacities, colors_precomp, scales, rotations, viewmatrix, projmatrix, bg,
                     image_height, image_width, scale_modifier=1.0, workspace: Optional[SurfelWorkspace] = None,
                     check_overflow: bool = True, stage_events=None):

@@ -3,14 +3,14 @@
 
 The reference loops over (batch, view) in Python and issues one extension call plus ~10 small torch ops per view.
 Here one C-ABI call rasterizes all V views of a batch item (``rasterize_views``) and the post-processing of
-``:121-163`` (alpha slice, view->world normal rotation, NaN scrubbing of the median depth, clamp of the image) is done
-once over the stacked ``[V,...]`` tensors.
+``:121-163`` (alpha slice, view->world normal rotation, NaN scrubbing of the median depth, clamp of the image) is one
+fused HIP pass over the stacked ``[V,...]`` tensors (``ga_surfel_postprocess``).
 """
 from __future__ import annotations
 
 import torch
 
-from .diff_surfel_rasterization import rasterize_views
+from .diff_surfel_rasterization import postprocess_views, rasterize_views
 
 
 class GaussianRenderer2DGS:
@@ -31,25 +31,22 @@ class GaussianRenderer2DGS:
         if bg_color is None:
             bg_color = self.bg_color
 
-        images, alphas, depths, rend_normals, dists = [], [], [], [], []
+        S = output_size
+        dev = gaussians.device
+        image = torch.empty((B, V, 3, S, S), dtype=torch.float32, device=dev)
+        rend_normal = torch.empty((B, V, 3, S, S), dtype=torch.float32, device=dev)
+        depth = torch.empty((B, V, 1, S, S), dtype=torch.float32, device=dev)
+        allmaps = []
         for b in range(B):
             g = gaussians[b]
             view = cam_view[b].float()
             color, _radii, allmap, _ = rasterize_views(
                 g[:, 0:3], g[:, 3:4], g[:, 10:13], g[:, 4:6], g[:, 6:10], view, cam_view_proj[b].float(),
-                bg_color.to(g.device), output_size, output_size, scale_modifier)
-            # normals: view space -> world space, n_world = n_view @ view[:3,:3].T   (nsr/gs_surfel.py:126-128)
-            normal = torch.einsum("vchw,vdc->vdhw", allmap[:, 2:5], view[:, :3, :3])
-            images.append(color.clamp(0, 1))
-            alphas.append(allmap[:, 1:2])
-            depths.append(torch.nan_to_num(allmap[:, 5:6], 0, 0))  # depth_ratio = 1: median depth (:133-134,150)
-            rend_normals.append(normal)
-            dists.append(allmap[:, 6:7])
-
-        return {
-            "image": torch.stack(images, dim=0).view(B, V, 3, output_size, output_size),
-            "alpha": torch.stack(alphas, dim=0).view(B, V, 1, output_size, output_size),
-            "depth": torch.stack(depths, dim=0).view(B, V, 1, output_size, output_size),
-            "rend_normal": torch.stack(rend_normals, dim=0).view(B, V, 3, output_size, output_size),
-            "dist": torch.stack(dists, dim=0).view(B, V, 1, output_size, output_size),
-        }
+                bg_color.to(g.device), S, S, scale_modifier)
+            # clamp of the image (:163), view -> world rotation of the normals (:126-128), NaN scrubbing of the median depth
+            # (:133-134, depth_ratio = 1) -- one fused pass written straight into the stacked outputs
+            postprocess_views(color, allmap, view, image[b], rend_normal[b], depth[b])
+            allmaps.append(allmap)
+        # alpha / dist are channels 1 / 6 of allmap (:121,142): views for one batch item, one stack otherwise
+        am = allmaps[0].unsqueeze(0) if B == 1 else torch.stack(allmaps, dim=0)
+        return {"image": image, "alpha": am[:, :, 1:2], "depth": depth, "rend_normal": rend_normal, "dist": am[:, :, 6:7]}

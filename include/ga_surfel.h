@@ -105,6 +105,22 @@ int ga_surfel_workspace_layout(int32_t num_points, int32_t num_views, int32_t im
  * (a hipStream_t passed as void* so that this header needs no HIP include). */
 int ga_surfel_forward(const GaSurfelForwardArgs *args, void *stream);
 
+/* host: the per-pixel post-processing of GaussianRenderer2DGS.render (/root/reference/nsr/gs_surfel.py:121-163) over the
+ * outputs of ga_surfel_forward, all views in one pass:
+ *   image = clamp(color, 0, 1) (:163);  rend_normal = allmap[2:5] rotated view -> world, n @ viewmatrix[:3,:3]^T (:126-128);
+ *   depth = nan_to_num(allmap[5], nan = 0, posinf = 0) (:133-134, depth_ratio = 1).
+ * alpha = allmap[1] and dist = allmap[6] need no computation.  Device pointers, fp32, contiguous; nothing is allocated. */
+typedef struct GaSurfelPostArgs {
+    int32_t num_views, image_height, image_width;
+    const float *color;       /* [V, 3, H, W]  out_color of ga_surfel_forward                */
+    const float *allmap;      /* [V, 7, H, W]  out_others of ga_surfel_forward               */
+    const float *viewmatrix;  /* [V, 4, 4]     row-vector world_view_transform (cam_view)     */
+    float *image;             /* [V, 3, H, W]                                                */
+    float *rend_normal;       /* [V, 3, H, W]                                                */
+    float *depth;             /* [V, 1, H, W]                                                */
+} GaSurfelPostArgs;
+int ga_surfel_postprocess(const GaSurfelPostArgs *args, void *stream);
+
 /* host: library identification, e.g. "ga_mi355 surfel gfx950 r1" */
 const char *ga_surfel_version(void);
 

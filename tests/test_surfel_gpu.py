@@ -221,4 +221,33 @@ def test_renderer_2dgs_dict(gpu_device):
         nrm = np.einsum("chw,dc->dhw", o["allmap"][2:5], view[:3, :3])
         assert float(np.mean((out["rend_normal"][0, v].cpu().numpy() - nrm) ** 2)) <= MSE_TOL
         assert float(np.mean((out["image"][0, v].cpu().numpy() - np.clip(o["color"], 0, 1)) ** 2)) <= MSE_TOL
-        assert float(np.mean((out["depth"][0, v, 0].cpu().numpy() - o["allmap"][5]) ** 2)) <= MSE_TOL
+        assert float(np.mean((out["depth"][0, v, 0].cpu().numpy() - np.nan_to_num(o["allmap"][5], nan=0.0, posinf=0.0)) ** 2)) <= MSE_TOL
+        assert float(np.mean((out["alpha"][0, v, 0].cpu().numpy() - o["allmap"][1]) ** 2)) <= MSE_TOL
+        assert float(np.mean((out["dist"][0, v, 0].cpu().numpy() - o["allmap"][6]) ** 2)) <= MSE_TOL
+
+
+def test_postprocess_kernel_exact(gpu_device):
+    """ga_surfel_postprocess against the torch formulation of nsr/gs_surfel.py:121-163, NaN / inf / out-of-range included,
+    image sizes with and without the 16-byte path; batch of two through the renderer."""
+    from gaussiananything_amd.diff_surfel_rasterization import postprocess_views
+    from gaussiananything_amd.gs_surfel import GaussianRenderer2DGS
+    g0 = torch.Generator().manual_seed(11)
+    for (V, H, W) in ((3, 32, 32), (2, 15, 17)):
+        color = (torch.randn(V, 3, H, W, generator=g0) * 0.8 + 0.5).to(gpu_device)
+        allmap = torch.randn(V, 7, H, W, generator=g0).to(gpu_device)
+        allmap[0, 5, 0, :4] = torch.tensor([float("nan"), float("inf"), float("-inf"), 2.5], device=gpu_device)
+        view = torch.randn(V, 4, 4, generator=g0).to(gpu_device)
+        image, normal, depth = postprocess_views(color, allmap, view)
+        assert torch.equal(image, color.clamp(0, 1))
+        assert torch.equal(depth, torch.nan_to_num(allmap[:, 5:6], 0, 0))
+        ref = torch.einsum("vchw,vdc->vdhw", allmap[:, 2:5].double(), view[:, :3, :3].double())
+        assert (normal.double() - ref).abs().max().item() < 1e-5
+    cams = synthetic.eval_cameras(2)
+    gs = torch.stack([synthetic.random_surfels(500, seed=s)[0] for s in (3, 4)]).to(gpu_device)
+    r = GaussianRenderer2DGS(64, 3, {})
+    cv, cvp, cp = (cams[k][None].expand(2, *cams[k].shape).to(gpu_device) for k in ("cam_view", "cam_view_proj", "cam_pos"))
+    both = r.render(gs, cv, cvp, cp, cams["tanfov"])
+    for b in range(2):
+        one = r.render(gs[b:b + 1], cv[b:b + 1], cvp[b:b + 1], cp[b:b + 1], cams["tanfov"])
+        for k in ("image", "alpha", "depth", "rend_normal", "dist"):
+            assert both[k].shape[0] == 2 and torch.equal(both[k][b], one[k][0]), k
