@@ -220,6 +220,36 @@ def bench_cascade(dev, cams):
             "renders 8 views x {128,256,384,512}^2", "surfels": int(out["gaussians_upsampled_3"].shape[1])}
 
 
+def bench_conditioner(dev, reps=5):
+    """Image conditioner at the release size: DINOv2 ViT-L/14 with 4 registers at 518 px (1374 tokens, 24 blocks; seeded
+    random weights), one image, preprocess (bicubic resize 512 -> 518 + normalisation) included.  FLOPs: 24 x (24 T D^2 +
+    4 T^2 D) + patch embedding."""
+    from gaussiananything_amd.conditioner import FrozenDinov2ImageEmbedder
+    torch.manual_seed(0)
+    e = FrozenDinov2ImageEmbedder(arch="vitl", output_cls=True, inp_size=518)
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for name, p_ in e.model.named_parameters():
+            if name.endswith("gamma"):
+                p_.fill_(0.5)
+            elif p_.dim() >= 2:
+                p_.copy_(torch.randn(p_.shape, generator=g) * (0.5 / p_[0].numel() ** 0.5))
+    e.to(dev)
+    img = (torch.rand(1, 3, 512, 512, generator=g) * 2 - 1).to(dev)
+    e(img)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        tok, cls = e(img)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    T, D = 1374, 1024
+    fl = 24 * (24 * T * D * D + 4 * T * T * D) + 2 * 1369 * 588 * D
+    return {"arch": "DINOv2 ViT-L/14 reg4 @518", "tokens": T, "ms_per_image": round(ms, 3), "algorithmic_tflop": round(fl / 1e12, 3),
+            "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 1),
+            "note": "parity unpinned (third-party model, no weights here): timing and shapes only; once per sample"}
+
+
 def bench_decode(dev, cams, reps=5):
     """Surfel decode at the release size (DiT2-B/2 backbone: width 768, depth 12, 768 anchors; upsamplers x8, x4, x3 ->
     73 728 surfels; seeded random weights, anchors = one in-tree FPS cloud) and the raster of its finest level at 8 x 512^2
@@ -418,6 +448,7 @@ def main():
             out["dit"] = [bench_dit(dev, arch, a.dit_nfe, 3, parity_mode=(arch == "DiT-PixArt-PCD-CLAY-B")) for arch in
                           ("DiT-PixArt-PCD-CLAY-B", "DiT-PixArt-PCD-CLAY-L", "DiT-PixArt-PCD-CLAY-stage2-L")]
             out["decode"] = bench_decode(dev, cams)
+            out["conditioner"] = bench_conditioner(dev)
             out["cascade_measured"] = bench_cascade(dev, cams)
             # BASELINE configs[3]: stage-1 DiT + stage-2 DiT (250-step Euler each) + surfel decode + raster of the result
             out["sec_per_sample_250step_cascaded_L"] = round(

@@ -38,6 +38,17 @@ def sample(model, cond, uc, shape, batch_size=1, cfg_scale=4.0, seed=42, num_ste
 
 
 @torch.no_grad()
+def condition_on_image(embedder, image):
+    """The conditioning dicts of the i23d release from an image batch in [-1, 1] (``FrozenDinov2ImageEmbedder`` with
+    ``output_cls=True``, configs: sgm/modules/encoders/modules.py:791-931): cond = {'img_crossattn': patch tokens
+    [S,1369,1024], 'img_vector': cls token [S,1024]}; the unconditional half of CFG is all zeros
+    (flow_matching_trainer.py:1148-1153 ``get_unconditional_conditioning`` with ucg force-zero)."""
+    tokens, cls = embedder(image)
+    cond = {"img_crossattn": tokens.contiguous(), "img_vector": cls.contiguous()}
+    return cond, {k: torch.zeros_like(v) for k, v in cond.items()}
+
+
+@torch.no_grad()
 def cascade(stage1, stage2, decoder, cond, uc, cameras=None, cfg_scale=4.0, seed=42, num_steps=250,
             sampling_method="dopri5", render_all_scale=True, **ode_kwargs):
     """Stage 1 -> stage 2 -> surfel decode (-> renders when ``cameras`` = {cam_view, cam_view_proj [B,V,4,4], cam_pos

@@ -1,0 +1,93 @@
+"""Image conditioner on the MI355X kernels vs oracle/dinov2.py.  Parity for this row is
+UNPINNED (see the oracle's header): these tests pin the HIP path to the restated algorithm, nothing more."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import dinov2 as od  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+def randomize(model, seed):
+    """Seeded, non-degenerate weights (DINOv2's LayerScale starts at 1e-5, which would hide the blocks)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("gamma"):
+                p.copy_(0.5 + 0.2 * torch.randn(p.shape, generator=g))
+            elif "norm" in name and name.endswith("weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            elif name in ("cls_token", "register_tokens", "pos_embed"):
+                p.copy_(0.3 * torch.randn(p.shape, generator=g))
+            elif p.dim() >= 2:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g) * (0.8 / fan_in ** 0.5))
+            else:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    return model
+
+
+@pytest.fixture(scope="module")
+def gpu_device():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("grid,in_size,batch", [(5, 70, 2), (9, 200, 1), (4, 56, 3)])
+def test_small_vit_matches_oracle(gpu_device, grid, in_size, batch):
+    """Two-head, three-block ViT with registers: patch GEMM with padded K, ragged token counts (1 + 4 + grid^2), resize with
+    and without the antialias blur, LayerScale through the residual gate."""
+    from gaussiananything_amd.conditioner import FrozenDinov2ImageEmbedder
+    S = 14 * grid
+    e = FrozenDinov2ImageEmbedder(arch="vitl", output_cls=True, inp_size=S,
+                                  _vit_kwargs=dict(embed_dim=128, depth=3, num_heads=2, img_size=S))
+    randomize(e.model, 7 + grid)
+    sd = {k: v.clone() for k, v in e.model.state_dict().items()}
+    img = torch.rand(batch, 3, in_size, in_size, generator=torch.Generator().manual_seed(grid)) * 2 - 1
+    tok_ref, cls_ref = od.embed(sd, img, S)
+    e = e.to(gpu_device)
+    tok, cls = e(img.to(gpu_device))
+    assert tok.shape == (batch, grid * grid, 128) and cls.shape == (batch, 128)
+    assert rel_l2(tok.cpu(), tok_ref) < 1.5e-2 and rel_l2(cls.cpu(), cls_ref) < 1.5e-2   # bf16 activations, fp32 residual stream
+    # the dict surface of the hub model (is_training=True) and the token-only mode of the embedder
+    e.output_cls = False
+    only = e(img.to(gpu_device))
+    assert torch.equal(only, tok)
+    ret = e.model(e.preprocess(img.to(gpu_device)), is_training=True)
+    assert set(ret) >= {"x_norm_clstoken", "x_norm_regtokens", "x_norm_patchtokens", "x_prenorm"}
+    assert ret["x_norm_regtokens"].shape == (batch, 4, 128)
+
+
+def test_release_size_vitl_518(gpu_device):
+    """ViT-L/14 with registers at 518 px: 1374 tokens, 24 blocks -- the conditioner of the release cascade
+    (img_crossattn [B, 1369, 1024], img_vector [B, 1024])."""
+    from gaussiananything_amd.conditioner import FrozenDinov2ImageEmbedder
+    e = FrozenDinov2ImageEmbedder(arch="vitl", output_cls=True, inp_size=518)
+    randomize(e.model, 3)
+    sd = {k: v.clone() for k, v in e.model.state_dict().items()}
+    img = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    tok_ref, cls_ref = od.embed(sd, img, 518)
+    e = e.to(gpu_device)
+    tok, cls = e(img.to(gpu_device))
+    assert tok.shape == (1, 1369, 1024) and cls.shape == (1, 1024)
+    assert rel_l2(tok.cpu(), tok_ref) < 2e-2 and rel_l2(cls.cpu(), cls_ref) < 2e-2
+    again = e(img.to(gpu_device))
+    assert torch.equal(again[0], tok) and torch.equal(again[1], cls)     # deterministic, parameters untouched
+    for k, v in e.model.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k]), k
+
+
+def test_wrong_grid_is_refused(gpu_device):
+    from gaussiananything_amd.conditioner import FrozenDinov2ImageEmbedder
+    e = FrozenDinov2ImageEmbedder(arch="vitl", inp_size=56, _vit_kwargs=dict(embed_dim=128, depth=1, num_heads=2, img_size=70)).to(gpu_device)
+    with pytest.raises(NotImplementedError):
+        e(torch.zeros(1, 3, 56, 56, device=gpu_device))

@@ -276,3 +276,40 @@ def test_ply_and_npy_handoff_formats(tmp_path):
     g = rng.random((100, 13), dtype=np.float32)
     io.save_gaussians_npy(tmp_path / "g.npy", g)
     assert io.load_gaussians_npy(tmp_path / "g.npy").shape == (1, 100, 13)
+
+
+def test_conditioner_oracle_and_host_surface():
+    """Section 8(f)-3 (parity unpinned): the preprocess restatement behaves as specified, the parameter container has the
+    DINOv2 state-dict layout, and the product path refuses to run without the GPU."""
+    from oracle import dinov2 as od
+    from gaussiananything_amd.conditioner import FrozenDinov2ImageEmbedder
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(2, 3, 28, 28, generator=g) * 2 - 1
+    same = od.preprocess(img, 28)
+    mean = torch.tensor(od.IMAGENET_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(od.IMAGENET_STD).view(1, 3, 1, 1)
+    assert torch.allclose(same, ((img + 1) / 2 - mean) / std, atol=1e-6)          # same size: no blur, no resampling
+    up = od.resize_bicubic(img, 56)
+    assert up.shape[-1] == 56 and torch.allclose(up[..., ::55, ::55], img[..., ::27, ::27], atol=1e-5)   # align_corners=True
+    const = od.resize_bicubic(torch.full((1, 3, 64, 64), 0.25), 28)
+    assert torch.allclose(const, torch.full_like(const, 0.25), atol=1e-5)         # blur and bicubic both preserve constants
+    e = FrozenDinov2ImageEmbedder(arch="vitl", output_cls=True, inp_size=28, _vit_kwargs=dict(embed_dim=128, depth=2, num_heads=2, img_size=28))
+    x = torch.rand(1, 3, 50, 50, generator=g) * 2 - 1
+    assert torch.allclose(e.preprocess(x), od.preprocess(x, 28), atol=1e-6)
+    keys = set(e.model.state_dict())
+    want = {"cls_token", "pos_embed", "register_tokens", "mask_token", "patch_embed.proj.weight", "patch_embed.proj.bias",
+            "norm.weight", "norm.bias"}
+    for i in range(2):
+        for k in ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
+                  "ls1.gamma", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight",
+                  "mlp.fc2.bias", "ls2.gamma"):
+            want.add(f"blocks.{i}.{k}")
+    assert keys == want
+    full = FrozenDinov2ImageEmbedder.__init__.__code__.co_varnames
+    for arg in ("arch", "version", "device", "max_length", "freeze", "antialias", "ucg_rate", "unsqueeze_dim",
+                "repeat_to_max_len", "num_image_crops", "output_tokens", "output_cls", "init_device", "inp_size"):
+        assert arg in full                                                         # modules.py:797-812
+    tok, cls = od.embed(e.model.state_dict(), img, 28)
+    assert tok.shape == (2, 4, 128) and cls.shape == (2, 128)
+    with pytest.raises(RuntimeError):
+        e(img)                                                                    # no CPU fallback
