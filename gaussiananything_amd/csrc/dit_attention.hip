@@ -400,6 +400,8 @@ extern "C" int ga_attention_bf16(const GaAttentionArgs *a, void *stream)
     if (a->batch <= 0 || a->heads <= 0 || a->Lq <= 0 || a->Lk <= 0 || a->q_stride % 8 || a->k_stride % 8 || a->vt_ld % 8 ||
         a->vt_ld < ((a->Lk + KB - 1) / KB) * KB || a->out_stride % 4)
         return GA_DIT_ERR_BAD_SHAPE;
+    // 16-byte accesses (vector loads of q, LDS-DMA of k / vt, 8-byte stores of out)
+    if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->vt) % 16 != 0 || (uintptr_t)a->out % 8 != 0) return GA_DIT_ERR_BAD_SHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // 128-query workgroups when they fill the chip; otherwise (the conditional half of a CFG pair alone in the image
     // cross-attention: 6 x 16 x 1 = 96 workgroups for 256 CUs) 64-query workgroups with two key groups -- measured on

@@ -73,7 +73,8 @@ int ga_gemm_bf16(const GaGemmArgs *args, void *stream);
  * what MemEffAttention / MemoryEfficientCrossAttention compute between their projections.  head_dim must be 64.
  * q row of (batch b, token i, head h) starts at q + (b*Lq + i)*q_stride + h*64 (same for k, out).
  * V is read TRANSPOSED: vt[(b*heads + h)*64 + d][key], row length vt_ld >= Lk rounded up to 64, zero beyond Lk
- * (written in that layout by ga_gemm_bf16's V^T store). */
+ * (written in that layout by ga_gemm_bf16's V^T store).  q, k, vt 16-byte aligned with strides % 8 == 0 (k and vt are moved
+ * by LDS-DMA unless k_norm_weight is given), out 8-byte aligned with out_stride % 4 == 0. */
 typedef struct GaAttentionArgs {
     int32_t batch, heads, Lq, Lk;
     const ga_bf16 *q, *k, *vt;
