@@ -14,6 +14,11 @@
  *   - call convention and argument meaning : /root/reference/nsr/gs_surfel.py:85-114
  *   - allmap channel meaning               : /root/reference/nsr/gs_surfel.py:121-142
  *   - row-vector matrix convention         : /root/reference/nsr/lsgm/flow_matching_trainer.py:2196-2205
+ * Short of the unavailable source, the one external anchor is the published method itself: tests/test_cpu_oracle_and_host.py
+ * (test_surfel_oracle_against_the_published_method) renders a fronto-parallel, a tilted and three overlapping surfels with an
+ * independent float64 ray-splat solve written from the 2DGS paper's equations (no homography trick, no tiles) and this file
+ * agrees with it to 5e-5 on colour, alpha, normals, expected / median depth and distortion.  That pins the method, not
+ * upstream's implementation choices (cut-offs, tile culling, tie order), which remain as recalled in SURVEY.md A.1.
  *
  * Floating point contract of this oracle (it DEFINES the bit patterns the HIP path must reproduce for the
  * integer artefacts): IEEE-754 binary32, one rounding per written operation, evaluated left to right,

@@ -83,6 +83,98 @@ def test_surfel_oracle_empty_and_culled():
     assert out["D"] == 0 and np.all(out["radii"] == 0) and np.allclose(out["color"][2], 0.3)
 
 
+def _analytic_surfel_render(means, opac, rgb, scales, quats, cam_view, cam_view_proj, bg, H, W):
+    """Independent float64 statement of the 2DGS forward for a FEW surfels, from the published method (Huang et al. 2024,
+    2D Gaussian Splatting, sec. 4: ray-splat intersection, object-space low-pass filter, front-to-back alpha blending,
+    depth distortion) and NOT from the homography / cross-product formulation the oracle restates: for every pixel and
+    surfel it solves directly for the (u, v) whose world point p0 + su u tu + sv v tv projects onto the pixel centre.
+    No tile culling: callers keep opacity small enough that everything outside the 3-sigma box is below 1/255 anyway."""
+    V, VP = cam_view.astype(np.float64), cam_view_proj.astype(np.float64)
+    py, px = np.mgrid[0:H, 0:W].astype(np.float64)
+    ndcx, ndcy = (2 * px + 1) / W - 1, (2 * py + 1) / H - 1        # pixel = ((ndc + 1) * size - 1) / 2
+    near, far = 0.2, 100.0
+    order = np.argsort([(np.append(m, 1.0) @ V)[2] for m in means], kind="stable")
+    T = np.ones((H, W)); C = np.zeros((3, H, W)); am = np.zeros((7, H, W)); M1 = np.zeros((H, W)); M2 = np.zeros((H, W))
+    for i in order:
+        w, x, y, z = quats[i].astype(np.float64) / np.linalg.norm(quats[i])
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        tu, tv, n = R[:, 0] * scales[i][0], R[:, 1] * scales[i][1], R[:, 2]
+        p0 = means[i].astype(np.float64)
+        c0, cu, cv = np.append(p0, 1.0) @ VP, np.append(tu, 0.0) @ VP, np.append(tv, 0.0) @ VP   # clip = c0 + u cu + v cv
+        # (c.x - ndcx c.w) = 0 and (c.y - ndcy c.w) = 0: two linear equations in (u, v) per pixel
+        a11, a12, b1 = cu[0] - ndcx * cu[3], cv[0] - ndcx * cv[3], -(c0[0] - ndcx * c0[3])
+        a21, a22, b2 = cu[1] - ndcy * cu[3], cv[1] - ndcy * cv[3], -(c0[1] - ndcy * c0[3])
+        det = a11 * a22 - a12 * a21
+        u, v = (b1 * a22 - a12 * b2) / det, (a11 * b2 - a21 * b1) / det
+        rho3d = u * u + v * v
+        xc, yc = ((c0[0] / c0[3] + 1) * W - 1) / 2, ((c0[1] / c0[3] + 1) * H - 1) / 2
+        rho2d = 2.0 * ((xc - px) ** 2 + (yc - py) ** 2)                                    # low-pass filter, 1/sqrt(2) px
+        zc = (np.append(p0, 1.0) @ V)[2]
+        depth = np.where(rho3d <= rho2d, zc + u * (np.append(tu, 0) @ V)[2] + v * (np.append(tv, 0) @ V)[2], zc)
+        alpha = np.minimum(0.99, opac[i] * np.exp(-0.5 * np.minimum(rho3d, rho2d)))
+        nv = n @ V[:3, :3]
+        nv = nv * np.sign(-np.dot((np.append(p0, 1.0) @ V)[:3], nv))                        # facing the camera
+        ok = (alpha >= 1.0 / 255.0) & (depth >= near) & (T * (1 - alpha) >= 1e-4)
+        wgt = np.where(ok, alpha * T, 0.0)
+        m = far / (far - near) * (1 - near / depth)
+        am[6] += np.where(ok, (m * m * (1 - T) + M2 - 2 * m * M1) * wgt, 0.0)
+        am[0] += depth * wgt; M1 += m * wgt; M2 += m * m * wgt
+        am[5] = np.where(ok & (T > 0.5), depth, am[5])
+        for k in range(3):
+            am[2 + k] += nv[k] * wgt
+            C[k] += rgb[i][k] * wgt
+        T = np.where(ok, T * (1 - alpha), T)
+    am[1] = 1 - T
+    return C + T[None] * np.asarray(bg, np.float64)[:, None, None], am
+
+
+def test_surfel_oracle_against_the_published_method():
+    """Known-answer test from the 2DGS paper's equations (the rasterizer itself is third-party and unavailable: 'parity
+    unpinned'): a fronto-parallel surfel, a tilted anisotropic one and three overlapping ones, 96 x 96, against an
+    independent float64 ray-splat solve.  Pins the oracle's homography, filter, sign conventions, blending order,
+    median depth and distortion to the method as published."""
+    from oracle import surfel as osurf
+    cams = synthetic.eval_cameras(3)
+    H = W = 96
+    q_tilt = np.array([np.cos(0.45), 0.3 * np.sin(0.45), 0.8 * np.sin(0.45), 0.52 * np.sin(0.45)])
+    for view, scene in ((0, "facing"), (1, "tilted"), (2, "stack")):
+        cv, cvp = cams["cam_view"][view].numpy(), cams["cam_view_proj"][view].numpy()
+        Rc = cv[:3, :3].astype(np.float64)                    # world -> view rotation (row-vector convention)
+        if scene == "facing":      # tangents = the camera's x / y axes: the surfel faces the camera on its axis
+            Rw = np.stack([Rc[:, 0], Rc[:, 1], np.cross(Rc[:, 0], Rc[:, 1])], axis=1)
+            w_ = 0.5 * np.sqrt(max(1 + np.trace(Rw), 1e-12))
+            quat = np.array([w_, (Rw[2, 1] - Rw[1, 2]) / (4 * w_), (Rw[0, 2] - Rw[2, 0]) / (4 * w_), (Rw[1, 0] - Rw[0, 1]) / (4 * w_)])
+            means, quats = np.zeros((1, 3)), quat[None]
+            opac, scales, rgb = np.array([0.3]), np.array([[0.05, 0.05]]), np.array([[0.9, 0.2, 0.1]])
+        elif scene == "tilted":
+            means, quats = np.array([[0.05, -0.03, 0.02]]), q_tilt[None]
+            opac, scales, rgb = np.array([0.3]), np.array([[0.09, 0.03]]), np.array([[0.1, 0.8, 0.3]])
+        else:
+            means = np.array([[0.0, 0.0, 0.0], [0.03, 0.01, 0.1], [-0.02, 0.02, -0.12]])
+            quats = np.stack([q_tilt, np.array([1.0, 0.1, -0.2, 0.05]), np.array([0.7, -0.4, 0.1, 0.3])])
+            quats /= np.linalg.norm(quats, axis=1, keepdims=True)   # unit quaternions, as rot_act = F.normalize hands them over
+            opac, scales = np.array([0.3, 0.25, 0.3]), np.array([[0.08, 0.05], [0.06, 0.09], [0.1, 0.04]])
+            rgb = np.array([[0.9, 0.1, 0.1], [0.1, 0.9, 0.1], [0.1, 0.1, 0.9]])
+        bg = np.array([0.2, 0.5, 0.7], np.float32)
+        out = osurf.rasterize(means.astype(np.float32), opac.astype(np.float32), rgb.astype(np.float32),
+                              scales.astype(np.float32), quats.astype(np.float32), cv, cvp, bg, H, W)
+        color, am = _analytic_surfel_render(means, opac, rgb, scales, quats, cv, cvp, bg, H, W)
+        assert am[1].max() > 0.2, scene                                      # the splats are on screen
+        assert np.abs(out["color"] - color).max() < 5e-5, scene        # fp32 oracle vs float64 statement
+        for ch, name in enumerate(("depth", "alpha", "nx", "ny", "nz", "median", "dist")):
+            assert np.abs(out["allmap"][ch] - am[ch]).max() < (5e-4 if name in ("depth", "median") else 5e-5), (scene, name)
+        if scene == "facing":     # closed form on the optical axis: alpha = o exp(-r^2 / 2 s^2), normal = -z, no distortion
+            assert abs(am[1].max() - 0.3) < 1e-2 and np.abs(out["allmap"][6]).max() < 1e-9   # centre lies between four pixel centres
+            cy, cx = np.unravel_index(np.argmax(out["allmap"][1]), (H, W))
+            nrm = out["allmap"][2:5, cy, cx] / out["allmap"][1, cy, cx]
+            assert np.allclose(nrm, [0, 0, -1], atol=1e-4)
+            assert abs(out["allmap"][0, cy, cx] / out["allmap"][1, cy, cx] - np.linalg.norm(cams["cam_pos"][view].numpy())) < 1e-3
+        if scene == "stack":      # distortion of two layers at the busiest pixel: w_i w_j (m_i - m_j)^2 summed over pairs > 0
+            assert out["allmap"][6].max() > 1e-7
+
+
 # ---- DiT oracle: pinned against the reference's own model code ----------------------------------------------------
 @pytest.mark.parametrize("stage", [1, 2])
 def test_dit_oracle_matches_reference_golden(stage):
