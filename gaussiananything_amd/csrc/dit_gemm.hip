@@ -371,16 +371,19 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
     //   > 256 workgroups of 128x128          -> 128-row tiles, 2-slot ring (64 KiB): two workgroups share a CU
     //   <= 256 of them, but > 128             -> 128-row tiles, 4-slot ring (128 KiB): one workgroup per CU, deep look-ahead
     //   <= 128 (the N = 1024 GEMMs at M=1536) -> 64-row tiles, 4-slot ring (96 KiB): twice the workgroups
+    //   <= 64  (the same at M = 768: one CFG half alone in the cross-attention) -> 32-row tiles: four times
     const long long wg128 = (long long)((a->N + BN - 1) / BN) * ((a->M + 127) / 128);
-    int cfg = wg128 > 256 ? 0 : (wg128 > 128 ? 1 : 2);
-    if (const char *e = getenv("GA_GEMM_CFG")) cfg = atoi(e) % 3;  // tuning aid
+    int cfg = wg128 > 256 ? 0 : (wg128 > 128 ? 1 : (wg128 > 64 ? 2 : 3));
+    if (const char *e = getenv("GA_GEMM_CFG")) cfg = atoi(e) % 4;  // tuning aid
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KiB of dynamic LDS has to be opted into once per kernel
 #define GA_ATTR(E)                                                                                                  \
         (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<E, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   4 * (BN + 128) * BK * 2);                                                          \
         (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<E, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  4 * (BN + 64) * BK * 2);
+                                  4 * (BN + 64) * BK * 2);                                                           \
+        (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<E, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  4 * (BN + 32) * BK * 2);
         GA_ATTR(0) GA_ATTR(1) GA_ATTR(2) GA_ATTR(3)
 #undef GA_ATTR
         attr_set = true;
@@ -392,9 +395,12 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
     else if (cfg == 1)                                                                                             \
         hipLaunchKernelGGL((gemm_bf16_kernel<E, 4, 4>), dim3((a->N + BN - 1) / BN, (a->M + 127) / 128), dim3(256),  \
                            4 * (BN + 128) * BK * 2, s, p);                                                          \
-    else                                                                                                           \
+    else if (cfg == 2)                                                                                             \
         hipLaunchKernelGGL((gemm_bf16_kernel<E, 4, 2>), dim3((a->N + BN - 1) / BN, (a->M + 63) / 64), dim3(256),    \
-                           4 * (BN + 64) * BK * 2, s, p);
+                           4 * (BN + 64) * BK * 2, s, p);                                                           \
+    else                                                                                                           \
+        hipLaunchKernelGGL((gemm_bf16_kernel<E, 4, 1>), dim3((a->N + BN - 1) / BN, (a->M + 31) / 32), dim3(256),    \
+                           4 * (BN + 32) * BK * 2, s, p);
     switch (a->epilogue) {
     case GA_GEMM_EPI_STORE_BF16: GA_LAUNCH(0) break;
     case GA_GEMM_EPI_GELU_BF16: GA_LAUNCH(1) break;

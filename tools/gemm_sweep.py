@@ -36,6 +36,8 @@ if os.environ.get("GA_ONE_SHAPE"):
     sys.exit(0)
 for (N, K, epi) in [(3072, 1024, 0), (4096, 1024, 1), (1024, 4096, 2), (1024, 1024, 2), (2048, 1024, 0)]:
     run(1536, N, K, epi)
+for (N, K, epi) in [(1024, 1024, 2), (1024, 1024, 0)]:   # one CFG half alone (cross-attention q / out projections)
+    run(768, N, K, epi)
 if os.environ.get("GA_FULL_SWEEP"):
     for K in (64, 256, 1024, 2048, 4096):
         run(1536, 1024, K, 2)
