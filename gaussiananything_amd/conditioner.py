@@ -3,7 +3,10 @@ constructor arguments, methods and outputs as /root/reference/sgm/modules/encode
 ViT (``torch.hub`` 'dinov2_vit{arch}14_reg' upstream) run on the MI355X kernels of the denoise half: ``ga_gemm_bf16`` (patch
 embedding as a GEMM over unfolded 14x14 patches, qkv with the transposed-V epilogue, GELU, LayerScale as the gate of the
 residual epilogue), ``ga_attention_bf16`` (1374 tokens: cls + 4 registers + 37 x 37 patches at 518 px) and
-``ga_layernorm_modulate``.  One image costs ~0.3 TFLOP, once per sample.
+``ga_layernorm_modulate``.  One image costs ~1 TFLOP, once per sample.  The release builds it from
+sgm/configs/img23d-clipl-compat-fm-lognorm-480-uniform-clay-dinoonly.yaml:43-52 (``arch: vitl, inp_size: 518, output_cls:
+True, ucg_rate: 0.1``; selected at nsr/lsgm/flow_matching_trainer.py:274-276) -- the native 37 x 37 grid, so no
+position-embedding interpolation is involved.
 
 ``DinoVisionTransformer`` below is a parameter container with the DINOv2 state-dict layout (``cls_token, pos_embed,
 register_tokens, mask_token, patch_embed.proj.*, blocks.{i}.{norm1,norm2}.*, blocks.{i}.attn.{qkv,proj}.*,
