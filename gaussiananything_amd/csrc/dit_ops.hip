@@ -10,6 +10,8 @@
 //                             xyz_projection of stage 2 (vit_triplane.py:187-229, utils/nerf_utils.py:16-66)
 //   final_layer_kernel      : T2IFinalLayer (dit_models_xformers.py:62-85): LayerNorm(no affine) + modulate + Linear
 // All are one-wave-per-row with 16-byte accesses where the layout allows.
+#include <stdlib.h>
+
 #include "dit_common.h"
 
 namespace gadit {
@@ -353,6 +355,14 @@ extern "C" size_t ga_dit_workspace_bytes(const GaDitModel *m, int32_t batch, int
 }
 
 #define GA_TRY(expr) do { const int rc_ = (expr); if (rc_ != GA_DIT_OK) return rc_; } while (0)
+// GA_DIT_ABLATE builds (tools/dit_ablate.sh) drop whole launch classes from the evaluation -- wrong results, wall-time shares only:
+// env GA_DIT_SKIP bit mask 1 self-attention, 2 cross-attention, 4 RMSNorm launches, 8 fc1 + fc2, 16 qkv + proj, 32 CA q + out
+#ifdef GA_DIT_ABLATE
+static int ga_skip_mask() { static const int v = [] { const char *e = getenv("GA_DIT_SKIP"); return e ? atoi(e) : 0; }(); return v; }
+#define GA_UNLESS(bit, expr) do { if (!(ga_skip_mask() & (bit))) GA_TRY(expr); } while (0)
+#else
+#define GA_UNLESS(bit, expr) GA_TRY(expr)
+#endif
 
 extern "C" int ga_dit_cache_context(const GaDitModel *m, int32_t batch, int32_t ctx_tokens, const ga_bf16 *ctx,
                                     ga_bf16 *ca_k, ga_bf16 *ca_vt, void *stream)
@@ -425,49 +435,49 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         const float *mod = w.mod + (size_t)i * B * 6 * D;  // [B][6][D]: shift_msa scale_msa gate_msa shift_mlp scale_mlp gate_mlp
         // cross-attention on the image tokens
         GaRmsNormArgs n0{Mca, D, L, w.xres, bw.prenorm_ca_w, nullptr, nullptr, 0, w.xn, nullptr, 0};
-        GA_TRY(ga_rmsnorm_modulate(&n0, stream));
+        GA_UNLESS(4, ga_rmsnorm_modulate(&n0, stream));
         GaGemmArgs gq{};
         gq.M = Mca; gq.N = D; gq.K = D; gq.epilogue = GA_GEMM_EPI_STORE_BF16; gq.A = w.xn; gq.lda = D; gq.W = bw.ca_q_w;
         gq.out = w.qkv; gq.ldo = D;
         gq.qk_w0 = bw.ca_q_norm_w; gq.qk_cols0 = D; gq.qk_cols1 = D;           // q_norm fused into the projection
-        GA_TRY(ga_gemm_bf16(&gq, stream));
+        GA_UNLESS(32, ga_gemm_bf16(&gq, stream));
         GaAttentionArgs ca{ca_batch, m->heads, L, a->ctx_tokens, w.qkv, a->ca_k + (size_t)i * kv_rows * D,
                            a->ca_vt + (size_t)i * B * D * Mp, D, D, Mp, nullptr, nullptr, w.att, D};
-        GA_TRY(ga_attention_bf16(&ca, stream));
+        GA_UNLESS(2, ga_attention_bf16(&ca, stream));
         GaGemmArgs go{};
         go.M = Mca; go.N = D; go.K = D; go.epilogue = GA_GEMM_EPI_RESIDUAL; go.A = w.att; go.lda = D; go.W = bw.ca_out_w;
         go.bias = bw.ca_out_b; go.out = w.xres; go.ldo = D; go.gate = nullptr; go.rows_per_batch = L;
-        GA_TRY(ga_gemm_bf16(&go, stream));
+        GA_UNLESS(32, ga_gemm_bf16(&go, stream));
         // self-attention
         // (rows of the items that skipped the cross-attention pick up its output bias here)
         GaRmsNormArgs n1{Mrows, D, L, w.xres, bw.norm1_w, mod + 1 * D, mod + 0 * D, 6 * (int64_t)D, w.xn,
                          Mca < Mrows ? bw.ca_out_b : nullptr, Mca};
-        GA_TRY(ga_rmsnorm_modulate(&n1, stream));
+        GA_UNLESS(4, ga_rmsnorm_modulate(&n1, stream));
         GaGemmArgs gqkv{};
         gqkv.M = Mrows; gqkv.N = 3 * D; gqkv.K = D; gqkv.epilogue = GA_GEMM_EPI_STORE_BF16; gqkv.A = w.xn; gqkv.lda = D;
         gqkv.W = bw.qkv_w; gqkv.bias = bw.qkv_b; gqkv.out = w.qkv; gqkv.ldo = 2 * D;   // q | k row-major ...
         gqkv.vt = w.vt; gqkv.vt_col0 = 2 * D; gqkv.vt_ld = Lp; gqkv.rows_per_batch = L;  // ... v transposed
         gqkv.qk_w0 = bw.q_norm_w; gqkv.qk_cols0 = D; gqkv.qk_w1 = bw.k_norm_w; gqkv.qk_cols1 = 2 * D;  // per-head q/k RMSNorm
-        GA_TRY(ga_gemm_bf16(&gqkv, stream));
+        GA_UNLESS(16, ga_gemm_bf16(&gqkv, stream));
         GaAttentionArgs sa{B, m->heads, L, L, w.qkv, w.qkv + D, w.vt, 2 * D, 2 * D, Lp, nullptr, nullptr, w.att, D};
-        GA_TRY(ga_attention_bf16(&sa, stream));
+        GA_UNLESS(1, ga_attention_bf16(&sa, stream));
         GaGemmArgs gp{};
         gp.M = Mrows; gp.N = D; gp.K = D; gp.epilogue = GA_GEMM_EPI_RESIDUAL; gp.A = w.att; gp.lda = D; gp.W = bw.proj_w;
         gp.bias = bw.proj_b; gp.out = w.xres; gp.ldo = D; gp.gate = mod + 2 * D; gp.gate_stride = 6 * (int64_t)D;
         gp.rows_per_batch = L;
-        GA_TRY(ga_gemm_bf16(&gp, stream));
+        GA_UNLESS(16, ga_gemm_bf16(&gp, stream));
         // FusedMLP
         GaRmsNormArgs n2{Mrows, D, L, w.xres, bw.norm2_w, mod + 4 * D, mod + 3 * D, 6 * (int64_t)D, w.xn, nullptr, 0};
-        GA_TRY(ga_rmsnorm_modulate(&n2, stream));
+        GA_UNLESS(4, ga_rmsnorm_modulate(&n2, stream));
         GaGemmArgs g1{};
         g1.M = Mrows; g1.N = 4 * D; g1.K = D; g1.epilogue = GA_GEMM_EPI_GELU_BF16; g1.A = w.xn; g1.lda = D; g1.W = bw.fc1_w;
         g1.bias = bw.fc1_b; g1.out = w.hmid; g1.ldo = 4 * D;
-        GA_TRY(ga_gemm_bf16(&g1, stream));
+        GA_UNLESS(8, ga_gemm_bf16(&g1, stream));
         GaGemmArgs g2{};
         g2.M = Mrows; g2.N = D; g2.K = 4 * D; g2.epilogue = GA_GEMM_EPI_RESIDUAL; g2.A = w.hmid; g2.lda = 4 * D;
         g2.W = bw.fc2_w; g2.bias = bw.fc2_b; g2.out = w.xres; g2.ldo = D; g2.gate = mod + 5 * D;
         g2.gate_stride = 6 * (int64_t)D; g2.rows_per_batch = L;
-        GA_TRY(ga_gemm_bf16(&g2, stream));
+        GA_UNLESS(8, ga_gemm_bf16(&g2, stream));
     }
     {
         FinalArgs f{Mrows, D, m->out_channels, L, w.xres, m->final_table, w.tvec, m->final_w, m->final_b, a->out};
