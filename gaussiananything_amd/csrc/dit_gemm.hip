@@ -43,6 +43,13 @@ struct GemmP {  // by-value kernel parameters (kept flat: no pointer into the ar
     long long vt_ld;
     const float *qk_w0, *qk_w1;  // optional per-head RMSNorm of the leading column groups
     int qk_cols0, qk_cols1;
+    // folded un-modulated RMSNorm (include/ga_dit.h): producer side (EPI_RESIDUAL) / consumer side (EPI_STORE_BF16)
+    uint16_t *emit_x;
+    float *emit_ss;
+    long long emit_ld;
+    const float *row_ss;
+    int row_ss_tiles;
+    float row_ss_inv_dim, row_ss_eps;
 };
 
 __device__ __forceinline__ void glds16(const uint16_t *gsrc, uint16_t *lds_wave_base)
@@ -109,9 +116,33 @@ __device__ __forceinline__ void residual_prefetch(const GemmP &p, ResidualPrefet
     }
 }
 
+// the consumer's row sums of squares (<= 16 partials per row), requested before the K loop like the residual rows
+template <int MT>
+struct RowSsPrefetch {
+    f32x4 part[MT][4];
+};
+
+template <int MT>
+__device__ __forceinline__ void rowss_prefetch(const GemmP &p, RowSsPrefetch<MT> &pf, int m0, int wm, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int m = min(m0 + wm * (MT * 16) + j * 16 + (lane & 15), p.M - 1);
+        const float *rp = p.row_ss + (size_t)m * p.row_ss_tiles;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            pf.part[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (4 * t < p.row_ss_tiles) {
+                const float4 v = *reinterpret_cast<const float4 *>(rp + 4 * t);
+                pf.part[j][t] = f32x4{v.x, v.y, v.z, v.w};
+            }
+        }
+    }
+}
+
 template <int EPI, int MT, bool PRE>
-__device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[4][MT], const ResidualPrefetch<MT> *pre, int m0, int n0,
-                                              int wn, int wm, int lane)
+__device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[4][MT], const ResidualPrefetch<MT> *pre,
+                                              const RowSsPrefetch<MT> *rss, int m0, int n0, int wn, int wm, int lane)
 {
     const int M = p.M, N = p.N;
     // epilogue: lane holds acc[i][j][r] = C[m = m0 + wm*MT*16 + j*16 + (lane&15)][n = n0 + wn*64 + i*16 + (lane>>4)*4 + r];
@@ -136,6 +167,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[4][MT
                 const float4 b = *reinterpret_cast<const float4 *>(p.bias + n);
                 v[i][0] += b.x; v[i][1] += b.y; v[i][2] += b.z; v[i][3] += b.w;
             }
+        }
+        if (EPI == GA_GEMM_EPI_STORE_BF16 && p.row_ss) {  // kernel-uniform: the RMSNorm row scale folded out of the A operand
+            float tot = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) tot += (rss->part[j][t][0] + rss->part[j][t][1]) + (rss->part[j][t][2] + rss->part[j][t][3]);
+            const float rs = rsqrtf(tot * p.row_ss_inv_dim + p.row_ss_eps);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i][0] *= rs; v[i][1] *= rs; v[i][2] *= rs; v[i][3] *= rs; }
         }
         if (EPI == GA_GEMM_EPI_STORE_BF16 && qkw) {  // wave-uniform
             float ss = 0.f;
@@ -170,6 +209,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[4][MT
             }
             continue;
         }
+        float emit_acc = 0.f;  // this lane's share of sum x_new^2 over the wave's 64 columns of row m
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             float w[8];
@@ -202,13 +242,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[4][MT
                             g0 = f32x4{b0.x, b0.y, b0.z, b0.w}; g1 = f32x4{b1.x, b1.y, b1.z, b1.w};
                         }
                     }
-                    dst[0] = make_float4(x0[0] + g0[0] * w[0], x0[1] + g0[1] * w[1], x0[2] + g0[2] * w[2], x0[3] + g0[3] * w[3]);
-                    if (hi) dst[1] = make_float4(x1[0] + g1[0] * w[4], x1[1] + g1[1] * w[5], x1[2] + g1[2] * w[6], x1[3] + g1[3] * w[7]);
+                    float xn[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        xn[e] = x0[e] + g0[e] * w[e];
+                        xn[4 + e] = hi ? x1[e] + g1[e] * w[4 + e] : 0.f;
+                    }
+                    dst[0] = make_float4(xn[0], xn[1], xn[2], xn[3]);
+                    if (hi) dst[1] = make_float4(xn[4], xn[5], xn[6], xn[7]);
+                    if (p.emit_x) {  // kernel-uniform; N % 64 == 0, so `hi` holds
+                        *reinterpret_cast<uint4 *>(p.emit_x + (size_t)m * p.emit_ld + n) =
+                            make_uint4(pack_bf16x2(xn[0], xn[1]), pack_bf16x2(xn[2], xn[3]), pack_bf16x2(xn[4], xn[5]),
+                                       pack_bf16x2(xn[6], xn[7]));
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) emit_acc += xn[e] * xn[e];
+                    }
                 } else {
                     dst[0] = make_float4(w[0], w[1], w[2], w[3]);
                     if (hi) dst[1] = make_float4(w[4], w[5], w[6], w[7]);
                 }
             }
+        }
+        if (EPI == GA_GEMM_EPI_RESIDUAL && p.emit_ss) {  // kernel-uniform: the four lanes of a row add up in a fixed order
+            emit_acc += __shfl_xor(emit_acc, 16, 64);
+            emit_acc += __shfl_xor(emit_acc, 32, 64);
+            if (g == 0 && m < M && nhead < N) p.emit_ss[(size_t)m * (N >> 6) + (nhead >> 6)] = emit_acc;
         }
     }
 }
@@ -252,6 +310,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
     constexpr bool PRE = EPI == GA_GEMM_EPI_RESIDUAL && NST >= 4;
     ResidualPrefetch<PRE ? MT : 1> pre;
     if (PRE) residual_prefetch<MT>(p, reinterpret_cast<ResidualPrefetch<MT> &>(pre), m0, n0, wn, wm, lane);
+    constexpr bool RSS = EPI == GA_GEMM_EPI_STORE_BF16;
+    RowSsPrefetch<RSS ? MT : 1> rss;
+    if (RSS && p.row_ss) rowss_prefetch<MT>(p, reinterpret_cast<RowSsPrefetch<MT> &>(rss), m0, wm, lane);
 
     const int frow = lane & 15, g = lane >> 4;
     const int nk = K / BK;
@@ -315,7 +376,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
 
     GA_STAGE(0, 0);
     if (GA_GEMM_ABLATE == 32) {  // launch + prologue + epilogue only
-        gemm_epilogue<EPI, MT, PRE>(p, acc, reinterpret_cast<const ResidualPrefetch<MT> *>(&pre), m0, n0, wn, wm, lane);
+        gemm_epilogue<EPI, MT, PRE>(p, acc, reinterpret_cast<const ResidualPrefetch<MT> *>(&pre),
+                                reinterpret_cast<const RowSsPrefetch<MT> *>(&rss), m0, n0, wn, wm, lane);
         return;
     }
     if (NST > 2 && nk > 1) GA_STAGE(1 % NST, 1);
@@ -337,7 +399,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
         if (t == 12345.f) static_cast<float *>(p.out)[tid] = t;
         return;
     }
-    gemm_epilogue<EPI, MT, PRE>(p, acc, reinterpret_cast<const ResidualPrefetch<MT> *>(&pre), m0, n0, wn, wm, lane);
+    gemm_epilogue<EPI, MT, PRE>(p, acc, reinterpret_cast<const ResidualPrefetch<MT> *>(&pre),
+                                reinterpret_cast<const RowSsPrefetch<MT> *>(&rss), m0, n0, wn, wm, lane);
 }
 
 // A register-FIFO variant of this kernel (global_load_dwordx4 into D = 4 / 8 K-tiles of VGPRs, ds_write into a double
@@ -364,9 +427,16 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
         (a->epilogue != GA_GEMM_EPI_STORE_BF16 || a->qk_cols0 % 64 || a->qk_cols1 % 64 || a->qk_cols1 < a->qk_cols0 ||
          a->qk_cols1 > a->N || (a->qk_cols0 && !a->qk_w0) || (a->qk_cols1 > a->qk_cols0 && !a->qk_w1)))
         return GA_DIT_ERR_BAD_SHAPE;
+    if ((a->emit_x || a->emit_ss) && (a->epilogue != GA_GEMM_EPI_RESIDUAL || !a->emit_x || !a->emit_ss || a->N % 64 != 0 ||
+                                      a->emit_ld % 8 != 0 || a->emit_ld < a->N))
+        return GA_DIT_ERR_BAD_SHAPE;
+    if (a->row_ss && (a->epilogue != GA_GEMM_EPI_STORE_BF16 || a->bias || a->row_ss_tiles <= 0 || a->row_ss_tiles > 16 ||
+                      a->row_ss_tiles % 4 != 0 || a->row_ss_dim <= 0))
+        return GA_DIT_ERR_BAD_SHAPE;
     const GemmP p{a->M, a->N, a->K, a->rows_per_batch, a->A, a->W, a->bias, a->gate, a->out, a->lda, a->ldo, a->gate_stride,
                   a->vt, a->vt_col0, a->vt ? (a->N - a->vt_col0) / 64 : 0, a->vt_ld, a->qk_w0, a->qk_w1, a->qk_cols0,
-                  a->qk_cols1};
+                  a->qk_cols1, a->emit_x, a->emit_ss, a->emit_ld, a->row_ss, a->row_ss_tiles,
+                  a->row_ss_dim > 0 ? 1.0f / (float)a->row_ss_dim : 0.f, a->row_ss_eps};
     // Tile / ring choice from the grid size (256 CUs):
     //   > 256 workgroups of 128x128          -> 128-row tiles, 2-slot ring (64 KiB): two workgroups share a CU
     //   <= 256 of them, but > 128             -> 128-row tiles, 4-slot ring (128 KiB): one workgroup per CU, deep look-ahead

@@ -303,7 +303,7 @@ extern "C" int ga_small_linear(const GaSmallLinearArgs *a, void *stream)
 namespace gadit {
 
 struct Ws {
-    float *xres, *tfreq, *t1, *pln, *pvec, *tvec, *t0, *mod;
+    float *xres, *tfreq, *t1, *pln, *pvec, *tvec, *t0, *mod, *rowss;
     uint16_t *xn, *qkv, *att, *hmid, *vt;
     size_t vt_bytes;
     size_t total;
@@ -325,6 +325,7 @@ static Ws carve(const GaDitModel *m, int B, int L, void *base)
     const size_t o_pln = take((size_t)B * m->context_dim * 4), o_pvec = take((size_t)B * D * 4);
     const size_t o_tvec = take((size_t)B * D * 4), o_t0 = take((size_t)B * 6 * D * 4);
     const size_t o_mod = take((size_t)m->depth * B * 6 * D * 4);
+    const size_t o_rowss = take(M * (D / 64) * 4);   // per-row partial sums of squares of the residual stream (folded pre-norm)
     w.total = off;
     w.xres = reinterpret_cast<float *>(p + o_xres); w.xn = reinterpret_cast<uint16_t *>(p + o_xn);
     w.qkv = reinterpret_cast<uint16_t *>(p + o_qkv); w.att = reinterpret_cast<uint16_t *>(p + o_att);
@@ -333,7 +334,14 @@ static Ws carve(const GaDitModel *m, int B, int L, void *base)
     w.t1 = reinterpret_cast<float *>(p + o_t1); w.pln = reinterpret_cast<float *>(p + o_pln);
     w.pvec = reinterpret_cast<float *>(p + o_pvec); w.tvec = reinterpret_cast<float *>(p + o_tvec);
     w.t0 = reinterpret_cast<float *>(p + o_t0); w.mod = reinterpret_cast<float *>(p + o_mod);
+    w.rowss = reinterpret_cast<float *>(p + o_rowss);
     return w;
+}
+
+// block i's cross-attention pre-norm can be folded into fc2 of block i-1 and its own q projection (include/ga_dit.h)
+static bool can_fold(const GaDitModel *m, int i)
+{
+    return m->blocks[i].ca_q_w_prenorm != nullptr && m->hidden % 256 == 0 && m->hidden <= 1024;
 }
 
 static bool model_ok(const GaDitModel *m)
@@ -433,12 +441,19 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     for (int i = 0; i < m->depth; ++i) {
         const GaDitBlockWeights &bw = m->blocks[i];
         const float *mod = w.mod + (size_t)i * B * 6 * D;  // [B][6][D]: shift_msa scale_msa gate_msa shift_mlp scale_mlp gate_mlp
-        // cross-attention on the image tokens
-        GaRmsNormArgs n0{Mca, D, L, w.xres, bw.prenorm_ca_w, nullptr, nullptr, 0, w.xn, nullptr, 0};
-        GA_UNLESS(4, ga_rmsnorm_modulate(&n0, stream));
+        // cross-attention on the image tokens.  Its pre-norm has no modulation, so from the second block on it can be folded
+        // into the neighbouring GEMMs: the previous block's fc2 epilogue left bf16(x) in xn and the rows' sums of squares in
+        // rowss (below); the q projection, with the norm weight folded into its columns, applies rsqrt(mean + eps) to its rows.
+        const bool folded = i > 0 && can_fold(m, i);
+        if (!folded) {
+            GaRmsNormArgs n0{Mca, D, L, w.xres, bw.prenorm_ca_w, nullptr, nullptr, 0, w.xn, nullptr, 0};
+            GA_UNLESS(4, ga_rmsnorm_modulate(&n0, stream));
+        }
         GaGemmArgs gq{};
-        gq.M = Mca; gq.N = D; gq.K = D; gq.epilogue = GA_GEMM_EPI_STORE_BF16; gq.A = w.xn; gq.lda = D; gq.W = bw.ca_q_w;
+        gq.M = Mca; gq.N = D; gq.K = D; gq.epilogue = GA_GEMM_EPI_STORE_BF16; gq.A = w.xn; gq.lda = D;
+        gq.W = folded ? bw.ca_q_w_prenorm : bw.ca_q_w;
         gq.out = w.qkv; gq.ldo = D;
+        if (folded) { gq.row_ss = w.rowss; gq.row_ss_tiles = D / 64; gq.row_ss_dim = D; gq.row_ss_eps = 1e-5f; }
         gq.qk_w0 = bw.ca_q_norm_w; gq.qk_cols0 = D; gq.qk_cols1 = D;           // q_norm fused into the projection
         GA_UNLESS(32, ga_gemm_bf16(&gq, stream));
         GaAttentionArgs ca{ca_batch, m->heads, L, a->ctx_tokens, w.qkv, a->ca_k + (size_t)i * kv_rows * D,
@@ -477,6 +492,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         g2.M = Mrows; g2.N = D; g2.K = 4 * D; g2.epilogue = GA_GEMM_EPI_RESIDUAL; g2.A = w.hmid; g2.lda = 4 * D;
         g2.W = bw.fc2_w; g2.bias = bw.fc2_b; g2.out = w.xres; g2.ldo = D; g2.gate = mod + 5 * D;
         g2.gate_stride = 6 * (int64_t)D; g2.rows_per_batch = L;
+        if (i + 1 < m->depth && can_fold(m, i + 1)) { g2.emit_x = w.xn; g2.emit_ld = D; g2.emit_ss = w.rowss; }
         GA_UNLESS(8, ga_gemm_bf16(&g2, stream));
     }
     {

@@ -14,6 +14,7 @@ names :1665-1697 -- on top of the hand-written HIP kernels behind include/ga_dit
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -167,7 +168,7 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
 
     # -- weight packing -------------------------------------------------------------------------------------------------
     def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + (bool(self.fold_prenorm),)
 
     def _prepare(self, device):
         sig = self._signature()
@@ -189,7 +190,9 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         for i, b in enumerate(self.blocks):
             ca = b.cross_attn_dino
             blocks[i] = ops.GaDitBlockWeights(
-                fp(b.prenorm_ca_dino.weight), bf(ca.to_q.weight), bf(torch.cat([ca.to_k.weight, ca.to_v.weight], 0)),
+                fp(b.prenorm_ca_dino.weight), bf(ca.to_q.weight),
+                bf(ca.to_q.weight.detach().float() * b.prenorm_ca_dino.weight.detach().float()[None, :]) if self.fold_prenorm else None,
+                bf(torch.cat([ca.to_k.weight, ca.to_v.weight], 0)),
                 fp(ca.q_norm.weight), fp(ca.k_norm.weight), bf(ca.to_out[0].weight), fp(ca.to_out[0].bias),
                 fp(b.norm1.weight), bf(b.attn.qkv.weight), fp(b.attn.qkv.bias), fp(b.attn.q_norm.weight),
                 fp(b.attn.k_norm.weight), bf(b.attn.proj.weight), fp(b.attn.proj.bias), fp(b.norm2.weight),
@@ -213,6 +216,8 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         return self._pack
 
     ca_skip = True  # skip the cross-attention of batch items whose image tokens are all zero (exact; tests switch it off)
+    # fold the (un-modulated) cross-attention pre-norm into the neighbouring GEMMs (include/ga_dit.h); GA_DIT_FOLD=0: A/B aid
+    fold_prenorm = os.environ.get("GA_DIT_FOLD", "1") != "0"
 
     def _context_kv(self, pack, ctx_tokens: torch.Tensor):
         key = (ctx_tokens.data_ptr(), ctx_tokens._version, tuple(ctx_tokens.shape), ctx_tokens.dtype)

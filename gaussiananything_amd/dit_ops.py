@@ -18,7 +18,8 @@ class GaGemmArgs(ctypes.Structure):
     _fields_ = [("M", i32), ("N", i32), ("K", i32), ("epilogue", i32), ("A", c_p), ("lda", i64), ("W", c_p),
                 ("bias", c_p), ("out", c_p), ("ldo", i64), ("gate", c_p), ("gate_stride", i64), ("rows_per_batch", i32),
                 ("vt", c_p), ("vt_col0", i32), ("vt_ld", i64), ("qk_w0", c_p), ("qk_w1", c_p), ("qk_cols0", i32),
-                ("qk_cols1", i32)]
+                ("qk_cols1", i32), ("emit_x", c_p), ("emit_ss", c_p), ("emit_ld", i64), ("row_ss", c_p),
+                ("row_ss_tiles", i32), ("row_ss_dim", i32), ("row_ss_eps", ctypes.c_float)]
 
 
 class GaAttentionArgs(ctypes.Structure):
@@ -39,7 +40,7 @@ class GaSmallLinearArgs(ctypes.Structure):
 
 class GaDitBlockWeights(ctypes.Structure):
     _fields_ = [(n, c_p) for n in (
-        "prenorm_ca_w", "ca_q_w", "ca_kv_w", "ca_q_norm_w", "ca_k_norm_w", "ca_out_w", "ca_out_b", "norm1_w", "qkv_w",
+        "prenorm_ca_w", "ca_q_w", "ca_q_w_prenorm", "ca_kv_w", "ca_q_norm_w", "ca_k_norm_w", "ca_out_w", "ca_out_b", "norm1_w", "qkv_w",
         "qkv_b", "q_norm_w", "k_norm_w", "proj_w", "proj_b", "norm2_w", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
         "scale_shift_table")]
 
@@ -104,10 +105,12 @@ def _need_cuda(*ts):
 
 
 def gemm(A, W, bias=None, epilogue=EPI_STORE_BF16, out=None, gate=None, rows_per_batch=1, vt=None, vt_col0=0,
-         qk_w0=None, qk_cols0=0, qk_w1=None, qk_cols1=0):
+         qk_w0=None, qk_cols0=0, qk_w1=None, qk_cols1=0, emit_x=None, emit_ss=None, row_ss=None, row_ss_dim=0,
+         row_ss_eps=1e-5):
     """A [M,K] bf16, W [N,K] bf16 -> see ga_dit.h.  EPI_RESIDUAL accumulates into ``out`` (fp32 [M,N]).
     ``vt`` [B*heads*64, Lpad] bf16 (zero-initialised): columns >= vt_col0 are stored transposed there (V projection).
-    ``qk_w0/qk_w1``: per-head RMSNorm weights for the column groups [0, qk_cols0) / [qk_cols0, qk_cols1)."""
+    ``qk_w0/qk_w1``: per-head RMSNorm weights for the column groups [0, qk_cols0) / [qk_cols0, qk_cols1).
+    ``emit_*`` (EPI_RESIDUAL) / ``row_ss`` (EPI_STORE_BF16): the folded un-modulated RMSNorm of ga_dit.h."""
     _need_cuda(A, W, bias, out, gate, vt)
     assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and A.stride(-1) == 1 and W.is_contiguous()
     M, K = A.shape
@@ -117,7 +120,9 @@ def gemm(A, W, bias=None, epilogue=EPI_STORE_BF16, out=None, gate=None, rows_per
                           dtype=torch.bfloat16 if epilogue in (EPI_STORE_BF16, EPI_GELU_BF16) else torch.float32)
     a = GaGemmArgs(M, N, K, epilogue, A.data_ptr(), A.stride(0), W.data_ptr(), _ptr(bias), out.data_ptr(), out.stride(0),
                    _ptr(gate), gate.stride(0) if gate is not None else 0, rows_per_batch, _ptr(vt), vt_col0,
-                   vt.stride(0) if vt is not None else 0, _ptr(qk_w0), _ptr(qk_w1), qk_cols0, max(qk_cols1, qk_cols0))
+                   vt.stride(0) if vt is not None else 0, _ptr(qk_w0), _ptr(qk_w1), qk_cols0, max(qk_cols1, qk_cols0),
+                   _ptr(emit_x), _ptr(emit_ss), emit_x.stride(0) if emit_x is not None else 0,
+                   _ptr(row_ss), row_ss.shape[1] if row_ss is not None else 0, row_ss_dim, row_ss_eps)
     check(lib().ga_gemm_bf16(ctypes.byref(a), _stream(A)), "ga_gemm_bf16")
     return out
 

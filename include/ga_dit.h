@@ -65,6 +65,21 @@ typedef struct GaGemmArgs {
      * applied where the projection is produced instead of where it is consumed. */
     const float *qk_w0, *qk_w1;
     int32_t qk_cols0, qk_cols1;
+    /* Folding an UN-modulated RMSNorm (y = x * rsqrt(mean(x^2) + eps) * weight, dit/norm.py:29-43) that sits between a
+     * residual GEMM and the next projection into the two GEMMs (one launch and one pass over the stream less); the norm
+     * weight is folded into the consumer's W offline (W'[n][k] = W[n][k] * weight[k]):
+     *   producer, EPI 2 only, optional (N % 64 == 0): besides x += ..., write emit_x[m][n] = bf16(x_new[m][n]) and
+     *     emit_ss[m][n / 64] = sum of x_new[m][.]^2 over that 64-column group (fixed order: deterministic);
+     *   consumer, EPI 0 only, optional: with A = emit_x and W', every output row is scaled by
+     *     rsqrt(sum_t row_ss[m][t] / row_ss_dim + row_ss_eps) (t < row_ss_tiles <= 16, row_ss_tiles % 4 == 0) before the
+     *     per-head qk-norm and the store.
+     * The activations are rounded to bf16 before instead of after the row scale and weight: the same relative rounding. */
+    ga_bf16 *emit_x;
+    float *emit_ss;
+    int64_t emit_ld;          /* elements per row of emit_x, multiple of 8                           */
+    const float *row_ss;
+    int32_t row_ss_tiles, row_ss_dim;
+    float row_ss_eps;
 } GaGemmArgs;
 
 int ga_gemm_bf16(const GaGemmArgs *args, void *stream);
@@ -122,6 +137,9 @@ typedef struct GaDitBlockWeights {
     /* cross-attention on the image tokens (cross_attn_dino, prenorm_ca_dino) */
     const float *prenorm_ca_w;           /* [D]                                         */
     const ga_bf16 *ca_q_w;               /* [D, D]      to_q (no bias)                  */
+    const ga_bf16 *ca_q_w_prenorm;       /* [D, D] or NULL: to_q with prenorm_ca_w folded into its columns (to_q[n][k] *
+                                          * prenorm_ca_w[k]); when given, blocks after the first run the pre-norm folded
+                                          * into the previous fc2 and this projection (see GaGemmArgs) */
     const ga_bf16 *ca_kv_w;              /* [2D, ctx]   to_k rows then to_v rows        */
     const float *ca_q_norm_w, *ca_k_norm_w; /* [64]                                     */
     const ga_bf16 *ca_out_w;             /* [D, D]      to_out.0                        */

@@ -153,6 +153,44 @@ def test_rmsnorm_modulate(gpu_device, M, D):
     assert rel_l2(out.float(), ref2) < 5e-3
 
 
+def test_folded_prenorm_pair_matches_the_unfused_sequence(gpu_device):
+    """ga_dit.h 'folded un-modulated RMSNorm': residual GEMM with the emit_* side product + projection (norm weight folded
+    into its columns) with row_ss must equal residual GEMM -> rmsnorm -> projection (bf16 rounding moved across the row
+    scale: the tolerance of any bf16 op), with and without the per-head q-norm, in the 32- / 64- / 128-row tile
+    configurations; the sums of squares are exact and deterministic."""
+    from gaussiananything_amd import dit_ops as ops
+    g = torch.Generator(device="cpu").manual_seed(21)
+    for (M, D, K) in ((200, 256, 128), (1536, 1024, 256), (4500, 768, 64)):
+        A = torch.randn(M, K, generator=g).to(gpu_device).bfloat16()
+        W1 = (torch.randn(D, K, generator=g) / K ** 0.5).to(gpu_device).bfloat16()
+        b1 = torch.randn(D, generator=g).to(gpu_device)
+        gate = torch.randn(3, D, generator=g).to(gpu_device)
+        rpb = (M + 2) // 3
+        x0 = torch.randn(M, D, generator=g).to(gpu_device)
+        nw = (1 + 0.2 * torch.randn(D, generator=g)).to(gpu_device)
+        W2f = torch.randn(D, D, generator=g) / D ** 0.5
+        W2 = W2f.to(gpu_device).bfloat16()
+        W2n = (W2.float() * nw[None, :]).bfloat16()
+        qw = (1 + 0.2 * torch.randn(64, generator=g)).to(gpu_device)
+        x_ref = x0.clone()
+        ops.gemm(A, W1, b1, ops.EPI_RESIDUAL, out=x_ref, gate=gate, rows_per_batch=rpb)
+        h = ops.rmsnorm_modulate(x_ref, nw)
+        x = x0.clone()
+        xb = torch.empty(M, D, device=gpu_device, dtype=torch.bfloat16)
+        ss = torch.full((M, D // 64), float("nan"), device=gpu_device)
+        ops.gemm(A, W1, b1, ops.EPI_RESIDUAL, out=x, gate=gate, rows_per_batch=rpb, emit_x=xb, emit_ss=ss)
+        assert torch.equal(x, x_ref) and torch.equal(xb, x.bfloat16())
+        assert torch.allclose(ss.sum(1), x.pow(2).sum(1), rtol=1e-5)
+        ss2 = torch.empty_like(ss)
+        ops.gemm(A, W1, b1, ops.EPI_RESIDUAL, out=x0.clone(), gate=gate, rows_per_batch=rpb, emit_x=xb, emit_ss=ss2)
+        assert torch.equal(ss, ss2)
+        for qk in (False, True):
+            kw = dict(qk_w0=qw, qk_cols0=D, qk_cols1=D) if qk else {}
+            y_ref = ops.gemm(h, W2, None, ops.EPI_STORE_BF16, **kw)
+            y = ops.gemm(xb, W2n, None, ops.EPI_STORE_BF16, row_ss=ss, row_ss_dim=D, **kw)
+            assert rel_l2(y.float(), y_ref.float()) < 8e-3, (M, qk)
+
+
 def test_small_linear(gpu_device):
     from gaussiananything_amd import dit_ops as ops
     g = torch.Generator(device="cpu").manual_seed(3)
