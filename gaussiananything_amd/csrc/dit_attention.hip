@@ -83,14 +83,17 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
 {
     constexpr int QB = NW * 16, GT = NW * 64, CPT = (512 + GT - 1) / GT;  // 16-byte chunks per thread per staged tile
     constexpr int DPW = 16 / NW;                                          // DMA instructions per wave per tile (K + V^T)
+    // tiles per barrier interval ("stage"): two when the ring still fits (3 slots x 2 tiles x 16 KiB = 96 KiB) -- in-situ
+    // ablation put the per-tile barrier at ~20 % of the kernel
+    constexpr int TPS = (!KNORM && KS == 1) ? 2 : 1;
     static_assert(16 % NW == 0, "a tile is 16 one-KiB DMA pieces");
-    __shared__ __attribute__((aligned(16))) uint16_t smem[KS * 6 * TILE];  // per key group: K[3][key][d], V^T[3][d][key]
+    __shared__ __attribute__((aligned(16))) uint16_t smem[KS * 6 * TPS * TILE];  // per key group: K[3][TPS][key][d], V^T[3][TPS][d][key]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: uniform branches
     const int ks = wave / NW, wq = wave - ks * NW, tg = tid - ks * GT;
     const int g = lane >> 4, c16 = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB + wq * 16;
     const int Lq = a.Lq, Lk = a.Lk;
-    uint16_t *sK = smem + ks * 6 * TILE, *sV = sK + 3 * TILE;
+    uint16_t *sK = smem + ks * 6 * TPS * TILE, *sV = sK + 3 * TPS * TILE;
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + c16][kk*32 + g*8 .. +7], normalised, scaled
     bf16x8 qf[2];
@@ -151,6 +154,11 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
             }
         }
     };
+    // a stage = TPS consecutive tiles in TPS consecutive tile buffers of ring slot `slot`
+    auto dma_stage = [&](int stage, int slot) {
+#pragma unroll
+        for (int u = 0; u < TPS; ++u) dma_tile(stage * TPS + u, slot * TPS + u);
+    };
     // ---- staging, register form (KNORM): 512 16-byte chunks per tile and operand; chunk c -> row c>>3, part c&7
     uint4 rk[CPT], rv[CPT];
     auto issue = [&](int tile_raw) {
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
     // harmless in fp32 sums and in the relative precision of the bf16 P) the reference is kept: no max update, no
     // exp2(m_old - m_new), no rescale of the 16 O accumulators.  m_run is always the true maximum at the time it was
     // set, so the largest P of a row lies in [1, 256] and the row sum is >= 1.  The decision is wave-uniform.
-    auto tile_math = [&](int tile, bool first, int slot, int dma_slot, auto tail_c) {
+    auto tile_math = [&](int tile, bool first, int slot, int dma_stage_idx, int dma_slot, auto tail_c) {
         constexpr bool TAIL = decltype(tail_c)::value;
         const uint16_t *bk = sK + slot * TILE, *bv = sV + slot * TILE;
         // The fragment reads are issued in two batches into their own registers (the compiler, left alone, funnels them
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
         STAMP(3);
         // the next-but-one tile's DMA is requested here, behind the head of the step's dependency chain (K fragments ->
         // S MFMAs) rather than in front of it
-        if (!KNORM && GA_ATTN_ABLATE != 5) dma_tile(tile + 2 * KS, dma_slot);
+        if (!KNORM && GA_ATTN_ABLATE != 5 && dma_stage_idx >= 0) dma_stage(dma_stage_idx, dma_slot);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int df = 0; df < 4; ++df)
@@ -292,36 +300,42 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
         STAMP(6);
     };
 
-    // ---- the walk: step t works on tile t*KS + ks in ring slot t % 3 while tile t+2 (DMA) / t+1 (registers) is staged.
-    // DMA form: counted wait for this wave's pieces of tile t, then a RAW s_barrier (everyone's pieces have landed and
-    // everyone has left tile t-1, whose slot the next DMA overwrites) -- __syncthreads() would drain vmcnt to 0.
+    // ---- the walk: step t works on stage t*KS + ks (TPS tiles) in ring slot t % 3 while stage t+2 (DMA) / tile t+1 (registers)
+    // is staged.  DMA form: counted wait for this wave's pieces of stage t, then a RAW s_barrier (everyone's pieces have
+    // landed and everyone has left stage t-1, whose slot the next DMA overwrites) -- __syncthreads() would drain vmcnt to 0.
     if (KNORM) {
         issue(ks);
         write_lds(0);
         issue(KS + ks);
     } else {
-        dma_tile(ks, 0);
-        dma_tile(KS + ks, 1);
+        dma_stage(ks, 0);
+        dma_stage(KS + ks, 1);
     }
-    const int steps = (ntiles + KS - 1) / KS;
+    const int nstages = (ntiles + TPS - 1) / TPS, steps = (nstages + KS - 1) / KS;
     int s0 = 0, s1 = 1, s2 = 2;
     for (int t = 0; t < steps; ++t) {
-        const int tile = t * KS + ks;
+        const int stage = t * KS + ks;
         t_stamp = t;
         STAMP(0);
         if (KNORM) {
             __syncthreads();
             write_lds(s1);                        // tile t+1 into the slot tile t-2 left two barriers ago
-            issue(tile + 2 * KS);
+            issue(stage + 2 * KS);
         } else {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA_ATTN_ABLATE == 5 ? 0 : DPW) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA_ATTN_ABLATE == 5 ? 0 : DPW * TPS) : "memory");
             if (GA_ATTN_ABLATE != 6) __builtin_amdgcn_s_barrier();
         }
         __builtin_amdgcn_sched_barrier(0);
         STAMP(1);
-        if (tile < nfull) tile_math(tile, t == 0, s0, s2, std::false_type{});      // DMA of tile t+2 into the slot of tile t-1
-        else if (tile < ntiles) tile_math(tile, t == 0, s0, s2, std::true_type{});
-        else if (!KNORM && GA_ATTN_ABLATE != 5) dma_tile(tile + 2 * KS, s2);       // keeps the vmcnt arithmetic exact
+        bool dma_done = false;
+#pragma unroll
+        for (int u = 0; u < TPS; ++u) {
+            const int tile = stage * TPS + u;
+            const int dma_idx = dma_done ? -1 : stage + 2 * KS;   // the stage after next goes out behind the first S MFMAs
+            if (tile < nfull) { tile_math(tile, t == 0 && u == 0, s0 * TPS + u, dma_idx, s2, std::false_type{}); dma_done = true; }
+            else if (tile < ntiles) { tile_math(tile, t == 0 && u == 0, s0 * TPS + u, dma_idx, s2, std::true_type{}); dma_done = true; }
+        }
+        if (!KNORM && GA_ATTN_ABLATE != 5 && !dma_done) dma_stage(stage + 2 * KS, s2);   // keeps the vmcnt arithmetic exact
         STAMP(7);
         const int r = s0; s0 = s1; s1 = s2; s2 = r;
     }
