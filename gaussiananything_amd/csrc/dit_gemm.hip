@@ -140,7 +140,7 @@ __device__ __forceinline__ void rowss_prefetch(const GemmP &p, RowSsPrefetch<MT>
     }
 }
 
-template <int EPI, int MT, bool PRE>
+template <int EPI, int MT, bool PRE, bool RSSPRE>
 __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[4][MT], const ResidualPrefetch<MT> *pre,
                                               const RowSsPrefetch<MT> *rss, int m0, int n0, int wn, int wm, int lane)
 {
@@ -170,8 +170,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[4][MT
         }
         if (EPI == GA_GEMM_EPI_STORE_BF16 && p.row_ss) {  // kernel-uniform: the RMSNorm row scale folded out of the A operand
             float tot = 0.f;
+            if (RSSPRE) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) tot += (rss->part[j][t][0] + rss->part[j][t][1]) + (rss->part[j][t][2] + rss->part[j][t][3]);
+                for (int t = 0; t < 4; ++t) tot += (rss->part[j][t][0] + rss->part[j][t][1]) + (rss->part[j][t][2] + rss->part[j][t][3]);
+            } else {  // two-workgroups-per-CU configuration: no registers to spare for a prefetch, same summation order
+                const float *rp = p.row_ss + (size_t)min(m, M - 1) * p.row_ss_tiles;
+                for (int t = 0; t < p.row_ss_tiles; t += 4) {
+                    const float4 q4 = *reinterpret_cast<const float4 *>(rp + t);
+                    tot += (q4.x + q4.y) + (q4.z + q4.w);
+                }
+            }
             const float rs = rsqrtf(tot * p.row_ss_inv_dim + p.row_ss_eps);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { v[i][0] *= rs; v[i][1] *= rs; v[i][2] *= rs; v[i][3] *= rs; }
@@ -196,7 +204,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[4][MT
                 for (int r = 0; r < 4; ++r) v[i][r] = gelu_erf(v[i][r]);
         }
         if (to_vt) {
-            // V projection: write V^T[(b*heads + h)*64 + d][token]; 16 consecutive lanes hold 16 consecutive tokens
+            // V projection: write V^T[(b*heads + h)*64 + d][token]; 16 consecutive lanes hold 16 consecutive tokens.  (A 4x4
+            // transpose inside lane quads -- three DPP moves, 8-byte stores of 4 tokens -- was measured: 24.4 vs 22.8 us for the
+            // qkv GEMM; the 2-byte stores of 16 consecutive tokens coalesce well enough and cost no extra VALU.)
             if (m >= M) continue;
             const int b = m / p.rows_per_batch, tok = m - b * p.rows_per_batch;
 #pragma unroll
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
     constexpr bool PRE = EPI == GA_GEMM_EPI_RESIDUAL && NST >= 4;
     ResidualPrefetch<PRE ? MT : 1> pre;
     if (PRE) residual_prefetch<MT>(p, reinterpret_cast<ResidualPrefetch<MT> &>(pre), m0, n0, wn, wm, lane);
-    constexpr bool RSS = EPI == GA_GEMM_EPI_STORE_BF16;
+    constexpr bool RSS = EPI == GA_GEMM_EPI_STORE_BF16 && NST >= 4;   // not in the 2-workgroups-per-CU configuration (VGPR budget 256)
     RowSsPrefetch<RSS ? MT : 1> rss;
     if (RSS && p.row_ss) rowss_prefetch<MT>(p, reinterpret_cast<RowSsPrefetch<MT> &>(rss), m0, wm, lane);
 
@@ -376,7 +386,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
 
     GA_STAGE(0, 0);
     if (GA_GEMM_ABLATE == 32) {  // launch + prologue + epilogue only
-        gemm_epilogue<EPI, MT, PRE>(p, acc, reinterpret_cast<const ResidualPrefetch<MT> *>(&pre),
+        gemm_epilogue<EPI, MT, PRE, RSS>(p, acc, reinterpret_cast<const ResidualPrefetch<MT> *>(&pre),
                                 reinterpret_cast<const RowSsPrefetch<MT> *>(&rss), m0, n0, wn, wm, lane);
         return;
     }
@@ -399,7 +409,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
         if (t == 12345.f) static_cast<float *>(p.out)[tid] = t;
         return;
     }
-    gemm_epilogue<EPI, MT, PRE>(p, acc, reinterpret_cast<const ResidualPrefetch<MT> *>(&pre),
+    gemm_epilogue<EPI, MT, PRE, RSS>(p, acc, reinterpret_cast<const ResidualPrefetch<MT> *>(&pre),
                                 reinterpret_cast<const RowSsPrefetch<MT> *>(&rss), m0, n0, wn, wm, lane);
 }
 
