@@ -405,3 +405,27 @@ def test_conditioner_oracle_and_host_surface():
     assert tok.shape == (2, 4, 128) and cls.shape == (2, 128)
     with pytest.raises(RuntimeError):
         e(img)                                                                    # no CPU fallback
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r1*_bench.json (the last full `python bench.py` line of the round) carries every field of the driver's
+    contract with the right types, and the derived numbers are consistent with each other."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r1*_bench.json")))
+    assert files
+    d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                 ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[k], t), k
+    assert d["vs_baseline"] is None and d["unit"] == "Msplats/s" and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    cfg = d["config"]
+    assert abs(d["value"] - cfg["points"] * cfg["views"] * d["n_gpus"] / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"] * 0.5
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
