@@ -18,7 +18,10 @@
  * (test_surfel_oracle_against_the_published_method) renders a fronto-parallel, a tilted and three overlapping surfels with an
  * independent float64 ray-splat solve written from the 2DGS paper's equations (no homography trick, no tiles) and this file
  * agrees with it to 5e-5 on colour, alpha, normals, expected / median depth and distortion.  That pins the method, not
- * upstream's implementation choices (cut-offs, tile culling, tie order), which remain as recalled in SURVEY.md A.1.
+ * upstream's implementation choices (cut-offs, tile culling, tie order), which remain as recalled in SURVEY.md A.1.  One
+ * such choice is visible against the paper: the screen-space low-pass filter is centred on the centre of the splat's
+ * bounding box (A.1 step 5), not on the projection of its 3D centre -- 0.02 in alpha at the centre pixel of a strongly
+ * tilted splat (oracle/surfel_autograd.py, the differentiable restatement kept as the backward oracle, follows it).
  *
  * Floating point contract of this oracle (it DEFINES the bit patterns the HIP path must reproduce for the
  * integer artefacts): IEEE-754 binary32, one rounding per written operation, evaluated left to right,

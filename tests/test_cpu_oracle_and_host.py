@@ -175,6 +175,44 @@ def test_surfel_oracle_against_the_published_method():
             assert out["allmap"][6].max() > 1e-7
 
 
+def test_surfel_backward_oracle_forward_and_gradcheck():
+    """oracle/surfel_autograd.py (the backward oracle of section 8(f)-4): its forward equals the C oracle, and its
+    autograd gradients w.r.t. means, opacity, colour, scales and rotations equal finite differences of that forward."""
+    from oracle import surfel as osurf
+    from oracle import surfel_autograd as oag
+    cams = synthetic.eval_cameras(2)
+    H = W = 48
+    g = torch.Generator().manual_seed(5)
+    n = 6
+    means = ((torch.rand(n, 3, generator=g) - 0.5) * 0.3).double()
+    opac = (0.1 + 0.2 * torch.rand(n, generator=g)).double()           # < 0.35: nothing outside the 3-sigma box reaches 1/255
+    rgb = torch.rand(n, 3, generator=g).double()
+    scales = (0.04 + 0.08 * torch.rand(n, 2, generator=g)).double()
+    quats = torch.nn.functional.normalize(torch.randn(n, 4, generator=g), dim=-1).double()
+    cv, cvp = cams["cam_view"][1].double(), cams["cam_view_proj"][1].double()
+    bg = torch.tensor([0.3, 0.6, 0.1], dtype=torch.float64)
+    color, am = oag.render(means, opac, rgb, scales, quats, cv, cvp, bg, H, W)
+    ref = osurf.rasterize(means.float().numpy(), opac.float().numpy(), rgb.float().numpy(), scales.float().numpy(),
+                          quats.float().numpy(), cv.float().numpy(), cvp.float().numpy(), bg.float().numpy(), H, W)
+    assert float(am[1].max()) > 0.2
+    assert np.abs(ref["color"] - color.numpy()).max() < 5e-5
+    for ch in range(7):
+        assert np.abs(ref["allmap"][ch] - am[ch].numpy()).max() < (5e-4 if ch in (0, 5) else 5e-5), ch
+
+    # gradients: a scalar functional of every differentiable output (random fixed weights), checked by finite differences
+    wc = torch.rand(3, H, W, generator=g).double()
+    wa = torch.rand(7, H, W, generator=g).double()
+    wa[5] = 0                                                           # the median depth is piecewise constant
+
+    def f(m_, o_, c_, s_, q_):
+        col, a_ = oag.render(m_, o_, c_, s_, q_, cv, cvp, bg, H, W)
+        return (col * wc).sum() + (a_ * wa).sum()
+    inputs = [t.clone().requires_grad_(True) for t in (means, opac, rgb, scales, quats)]
+    assert torch.autograd.gradcheck(f, inputs, eps=1e-6, atol=2e-5, rtol=2e-4, nondet_tol=0.0)
+    grads = torch.autograd.grad(f(*inputs), inputs)
+    assert all(torch.isfinite(gr).all() and float(gr.abs().max()) > 0 for gr in grads)
+
+
 # ---- DiT oracle: pinned against the reference's own model code ----------------------------------------------------
 @pytest.mark.parametrize("stage", [1, 2])
 def test_dit_oracle_matches_reference_golden(stage):
