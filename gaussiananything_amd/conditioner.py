@@ -12,6 +12,7 @@ position-embedding interpolation is involved.
 register_tokens, mask_token, patch_embed.proj.*, blocks.{i}.{norm1,norm2}.*, blocks.{i}.attn.{qkv,proj}.*,
 blocks.{i}.{ls1,ls2}.gamma, blocks.{i}.mlp.{fc1,fc2}.*, norm.*``), so ``embedder.model.load_state_dict(hub_model.state_dict())``
 is a strict load; there is no network here, so construction does not download anything and the weights start random.
+Other input sizes than the stored 37 x 37 grid resample the position embeddings as DINOv2 does.
 The resize of ``preprocess`` is a handful of torch ops on the device (plumbing, once per sample), not a kernel of ours.
 
 Parity is UNPINNED for this row (the arithmetic is third-party code absent from /root/reference): oracle/dinov2.py restates
@@ -111,6 +112,19 @@ class DinoVisionTransformer(nn.Module):
         self._pack = (ver, pk)
         return pk
 
+    def interpolate_pos_encoding(self, h0, w0):
+        """dinov2 DinoVisionTransformer.interpolate_pos_encoding as the register models are built by the hub
+        (interpolate_antialias=True, interpolate_offset=0.0) [UPSTREAM-RECALLED]: the stored M x M grid of patch position
+        embeddings is resampled bicubically to h0 x w0; the class position is kept.  Host-side plumbing on a parameter."""
+        pos = self.pos_embed.detach().float()
+        N = pos.shape[1] - 1
+        if h0 * w0 == N and h0 == w0:
+            return pos
+        M = int(round(N ** 0.5))
+        grid = pos[:, 1:].reshape(1, M, M, -1).permute(0, 3, 1, 2)
+        grid = F.interpolate(grid, size=(h0, w0), mode="bicubic", antialias=True)
+        return torch.cat([pos[:, :1], grid.permute(0, 2, 3, 1).reshape(1, h0 * w0, -1)], dim=1)
+
     @torch.no_grad()
     def forward_features(self, x, masks=None):
         if masks is not None:
@@ -121,15 +135,14 @@ class DinoVisionTransformer(nn.Module):
         B, _, Hh, Ww = x.shape
         D, H, P, R = self.embed_dim, self.num_heads, self.patch_size, self.num_register_tokens
         n = (Hh // P) * (Ww // P)
-        if Hh % P or Ww % P or self.pos_embed.shape[1] != n + 1:
-            raise NotImplementedError("position-embedding interpolation is not built: run at the stored patch grid "
-                                      f"({int((self.pos_embed.shape[1] - 1) ** 0.5) * P} px for this model)")
+        if Hh % P or Ww % P:
+            raise ValueError(f"image size {Hh}x{Ww} is not a multiple of the patch size {P}")
         # patch embedding: Conv2d(k = s = P) == GEMM over the unfolded patches ([B*n, 3*P*P], channel-major like the conv weight)
         cols = F.unfold(x.float(), kernel_size=P, stride=P).transpose(1, 2).reshape(B * n, 3 * P * P)
         a = torch.zeros((B * n, pk["Kp"]), dtype=torch.bfloat16, device=x.device)
         a[:, :cols.shape[1]] = cols.to(torch.bfloat16)
         tok = ops.gemm(a, pk["wpe"], pk["bpe"], ops.EPI_STORE_F32).reshape(B, n, D)
-        pos = self.pos_embed.detach().float()
+        pos = self.interpolate_pos_encoding(Hh // P, Ww // P)
         T = 1 + R + n
         xs = torch.empty((B, T, D), dtype=torch.float32, device=x.device)      # fp32 residual stream, updated in place
         xs[:, 0] = self.cls_token.detach().float()[0, 0] + pos[0, 0]

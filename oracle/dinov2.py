@@ -16,7 +16,7 @@ ref unpinned; the comments at :841 and :895 cite commit e1277af2ba9496fbadf7aec6
 (requirements.txt, unpinned).  What is restated below, from the published DINOv2 code [UPSTREAM-RECALLED]:
   dinov2/models/vision_transformer.py  DinoVisionTransformer.prepare_tokens_with_masks / forward_features:
       x = patch_embed(img) (Conv2d k = s = 14, flattened row-major);  x = cat(cls_token, x) + pos_embed  (no interpolation
-      when the patch grid equals the stored one);  x = cat(x[:, :1], register_tokens, x[:, 1:]);  blocks;  x_norm = norm(x);
+      when the patch grid equals the stored one, else bicubic + antialias resampling of the patch grid, offset 0);  x = cat(x[:, :1], register_tokens, x[:, 1:]);  blocks;  x_norm = norm(x);
       x_norm_clstoken = x_norm[:, 0], x_norm_regtokens = x_norm[:, 1:1+R], x_norm_patchtokens = x_norm[:, 1+R:]
   dinov2/layers/block.py               x = x + ls1(attn(norm1(x)));  x = x + ls2(mlp(norm2(x)))   (LayerNorm eps 1e-6)
   dinov2/layers/attention.py           qkv Linear(bias) -> heads -> softmax(q k^T / sqrt(d)) v -> proj Linear
@@ -75,9 +75,13 @@ def vit_forward(sd, img):
     heads = D // 64
     x = F.conv2d(img.float(), w, sd["patch_embed.proj.bias"], stride=P).flatten(2).transpose(1, 2)      # [B, n, D]
     B, n, _ = x.shape
-    if sd["pos_embed"].shape[1] != n + 1:
-        raise NotImplementedError("position-embedding interpolation is not restated (the release runs at the native 518 px grid)")
-    x = torch.cat([sd["cls_token"].expand(B, -1, -1), x], dim=1) + sd["pos_embed"]
+    pos = sd["pos_embed"]
+    if pos.shape[1] != n + 1:   # interpolate_pos_encoding of the register models (antialias=True, offset 0) [UPSTREAM-RECALLED]
+        Mg, g0 = int(round((pos.shape[1] - 1) ** 0.5)), img.shape[-1] // P
+        grid = F.interpolate(pos[:, 1:].reshape(1, Mg, Mg, D).permute(0, 3, 1, 2), size=(img.shape[-2] // P, g0), mode="bicubic",
+                             antialias=True)
+        pos = torch.cat([pos[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, D)], dim=1)
+    x = torch.cat([sd["cls_token"].expand(B, -1, -1), x], dim=1) + pos
     R = sd["register_tokens"].shape[1]
     x = torch.cat([x[:, :1], sd["register_tokens"].expand(B, -1, -1), x[:, 1:]], dim=1)
     depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))

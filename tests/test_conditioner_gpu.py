@@ -86,8 +86,18 @@ def test_release_size_vitl_518(gpu_device):
         assert torch.equal(v.cpu(), sd[k]), k
 
 
-def test_wrong_grid_is_refused(gpu_device):
+def test_other_input_sizes_resample_the_position_embeddings(gpu_device):
+    """A model stored at a 5 x 5 grid run at 4 x 4 and 7 x 7 (DINOv2's interpolate_pos_encoding), against the oracle."""
     from gaussiananything_amd.conditioner import FrozenDinov2ImageEmbedder
-    e = FrozenDinov2ImageEmbedder(arch="vitl", inp_size=56, _vit_kwargs=dict(embed_dim=128, depth=1, num_heads=2, img_size=70)).to(gpu_device)
-    with pytest.raises(NotImplementedError):
-        e(torch.zeros(1, 3, 56, 56, device=gpu_device))
+    for S in (56, 98):
+        e = FrozenDinov2ImageEmbedder(arch="vitl", output_cls=True, inp_size=S,
+                                      _vit_kwargs=dict(embed_dim=128, depth=2, num_heads=2, img_size=70))
+        randomize(e.model, S)
+        sd = {k: v.clone() for k, v in e.model.state_dict().items()}
+        img = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(S)) * 2 - 1
+        tok_ref, cls_ref = od.embed(sd, img, S)
+        tok, cls = e.to(gpu_device)(img.to(gpu_device))
+        assert tok.shape == (2, (S // 14) ** 2, 128)
+        assert rel_l2(tok.cpu(), tok_ref) < 1.5e-2 and rel_l2(cls.cpu(), cls_ref) < 1.5e-2
+    with pytest.raises(ValueError):
+        e.model(torch.zeros(1, 3, 60, 60, device=gpu_device), is_training=True)
