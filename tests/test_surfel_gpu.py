@@ -123,6 +123,27 @@ def test_segmented_blend_of_transparent_long_lists(gpu_device):
             assert 0.2 < float(alpha.max()) < 0.9999, "scene should stay short of the stop rule"
 
 
+def test_segmented_blend_of_very_long_lists_beside_short_ones(gpu_device):
+    """Tiles with > 4096, with 1-2 k and with a handful of pairs in one launch (the schedule puts the long ones first, four
+    quadrant workgroups each), transparent so that every segment seam is crossed; one and several views; repeated calls
+    are bit-identical."""
+    cams = synthetic.eval_cameras(8)
+    gen = torch.Generator().manual_seed(17)
+    dense = synthetic.random_surfels(9000, seed=21)[0].clone()
+    dense[:, 0:3] *= 0.04                      # a few tiles with thousands of entries
+    mid = synthetic.random_surfels(3000, seed=22)[0].clone()
+    mid[:, 0:3] = mid[:, 0:3] * 0.08 + torch.tensor([0.25, 0.2, 0.0])   # a neighbouring clump with ~1-2 k per tile
+    sparse = synthetic.random_surfels(1500, seed=23)[0].clone()
+    g = torch.cat([dense, mid, sparse], 0)
+    g[:, 3] = 0.004 + 0.02 * torch.rand(g.shape[0], generator=gen)
+    for views in ([0], [0, 3, 6]):
+        art = _run_case(g, cams, views, 96, 96, gpu_device)
+        assert art["max_tile"] >= 4096
+    a1 = _util.hip_views(g, cams, [0, 3], 96, 96, gpu_device)
+    a2 = _util.hip_views(g, cams, [0, 3], 96, 96, gpu_device)
+    assert torch.equal(a1[0], a2[0]) and torch.equal(a1[2], a2[2])
+
+
 def test_degenerate_inputs(gpu_device):
     """behind-camera, zero-scale, zero / tiny opacity, duplicate depths (tie-break by index), edge-on splats."""
     cams = synthetic.eval_cameras(8)
