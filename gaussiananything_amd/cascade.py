@@ -17,19 +17,26 @@ import torch
 from .transport import Sampler, create_transport
 
 XYZ_STD = 0.164  # flow_matching_trainer.py:987
+PCD_SCALING_FACTOR = 0.45  # sgm/configs/stage2-i23d.yaml:55-57 -> PCD_Scaler (sgm/modules/encoders/modules.py:1746-1768)
 
 
 @torch.no_grad()
 def sample(model, cond, uc, shape, batch_size=1, cfg_scale=4.0, seed=42, num_steps=250, sampling_method="dopri5",
-           transport_sampler=None, **ode_kwargs):
+           transport_sampler=None, noise_dtype=torch.bfloat16, **ode_kwargs):
     """``FlowMatchingEngine.sample`` (flow_matching_trainer.py:700-744): CPU-seeded noise, CFG batch = [cond | uncond],
-    ``sample_ode(num_steps=250, cfg=True)`` (dopri5 by default, as upstream), last state, conditional half."""
+    ``sample_ode(num_steps=250, cfg=True)`` (dopri5 by default, as upstream), last state, conditional half.
+
+    ``noise_dtype``: the reference draws fp32 noise on the CPU and rounds it to the engine dtype before sampling
+    (``.to(self.dtype)``, :720; the release runs bf16 AMP), so the initial state is a bf16-representable tensor; the ODE
+    state is fp32 from the first update on.  ``None`` keeps the un-rounded fp32 draw."""
     if transport_sampler is None:
         transport_sampler = Sampler(create_transport("GVP", "velocity", None, None, None, snr_type="uniform"))
     sample_fn = transport_sampler.sample_ode(sampling_method=sampling_method, num_steps=num_steps, cfg=True, **ode_kwargs)
     dev = next(model.parameters()).device
     torch.manual_seed(seed)
     zs = torch.randn(batch_size, *shape).to(dev)
+    if noise_dtype is not None:
+        zs = zs.to(noise_dtype).float()
     c_out = {k: torch.cat((cond[k], uc[k]), 0) for k in cond}
     zs = torch.cat([zs, zs], 0)
     samples = sample_fn(zs, model.forward_with_cfg, context=c_out, cfg_scale=cfg_scale)[-1]
@@ -43,22 +50,37 @@ def condition_on_image(embedder, image):
     ``output_cls=True``, configs: sgm/modules/encoders/modules.py:791-931): cond = {'img_crossattn': patch tokens
     [S,1369,1024], 'img_vector': cls token [S,1024]}; the unconditional half of CFG is all zeros
     (flow_matching_trainer.py:1148-1153 ``get_unconditional_conditioning`` with ucg force-zero)."""
-    tokens, cls = embedder(image)
+    tokens, cls = embedder(image, no_dropout=True)  # get_unconditional_conditioning forces ucg_rate = 0 (modules.py:185-194)
     cond = {"img_crossattn": tokens.contiguous(), "img_vector": cls.contiguous()}
     return cond, {k: torch.zeros_like(v) for k, v in cond.items()}
 
 
 @torch.no_grad()
+def stage2_conditioning(cond, uc, fps_xyz, zero_image_uc=False):
+    """Stage-2 conditioning dicts from the stage-1 cloud, as the release's conditioner builds them
+    (sgm/configs/stage2-i23d.yaml): the ``fps-xyz`` embedder is ``PCD_Scaler`` -- the denoiser's XYZPosEmbed sees
+    ``xyz / 0.45`` (only the decoder gets the raw cloud).  Stage 2 runs with ``cond_key = 'img-xyz'``, so
+    ``ucg_keys = ['img-xyz']`` matches no embedder input key ('img', 'fps-xyz') and ``get_unconditional_conditioning``
+    returns uc == c (flow_matching_trainer.py:1039,1148-1155): classifier-free guidance is a no-op there.
+    ``zero_image_uc=True`` is the non-reference variant that guides against the zero-image branch."""
+    scaled = fps_xyz / PCD_SCALING_FACTOR
+    cond2 = dict(cond)
+    cond2["fps-xyz"] = scaled
+    uc2 = dict(uc) if zero_image_uc else dict(cond)
+    uc2["fps-xyz"] = scaled
+    return cond2, uc2
+
+
+@torch.no_grad()
 def cascade(stage1, stage2, decoder, cond, uc, cameras=None, cfg_scale=4.0, seed=42, num_steps=250,
-            sampling_method="dopri5", render_all_scale=True, **ode_kwargs):
+            sampling_method="dopri5", render_all_scale=True, stage2_zero_image_uc=False, **ode_kwargs):
     """Stage 1 -> stage 2 -> surfel decode (-> renders when ``cameras`` = {cam_view, cam_view_proj [B,V,4,4], cam_pos
     [B,V,3], tanfov} is given).  ``cond`` / ``uc``: {'img_crossattn' [S,1369,1024], 'img_vector' [S,1024]}."""
     S = cond["img_crossattn"].shape[0]
     L = decoder.vit_decoder.pos_embed.shape[1]  # 768 latent tokens in the release (z_shape, flow_matching_trainer.py:1158)
     xyz = sample(stage1, cond, uc, (L, stage1.in_channels), S, cfg_scale, seed, num_steps, sampling_method, **ode_kwargs)
     fps_xyz = (xyz * XYZ_STD).clip(-0.45, 0.45)
-    cond2, uc2 = dict(cond), dict(uc)
-    cond2["fps-xyz"] = uc2["fps-xyz"] = fps_xyz
+    cond2, uc2 = stage2_conditioning(cond, uc, fps_xyz, zero_image_uc=stage2_zero_image_uc)
     latent = sample(stage2, cond2, uc2, (L, stage2.in_channels), S, cfg_scale, seed, num_steps, sampling_method,
                     **ode_kwargs)
     ret = decoder.decode(latent, fps_xyz)

@@ -420,7 +420,11 @@ extern "C" int ga_attention_bf16(const GaAttentionArgs *a, void *stream)
     // 128-query workgroups when they fill the chip; otherwise (the conditional half of a CFG pair alone in the image
     // cross-attention: 6 x 16 x 1 = 96 workgroups for 256 CUs) 64-query workgroups with two key groups -- measured on
     // MI355X, B = 1, 16 heads, 768 x 1369: 20.7 -> 15.0 us; B = 2: 22.3 us (<8,1>) vs 28.5 us (<4,2>).
-    static const int cfg = [] { const char *e = getenv("GA_ATTN_CFG"); return e ? atoi(e) : 0; }();  // NW*10 + KS
+#ifdef GA_TUNING  // tuning builds only: NW*10 + KS from the environment
+    static const int cfg = [] { const char *e = getenv("GA_ATTN_CFG"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int cfg = 0;
+#endif
     const int64_t wgs128 = (int64_t)((a->Lq + 127) / 128) * a->heads * a->batch;
     const bool split = cfg ? cfg == 42 : wgs128 <= 128;
     if (split) launch_attention<4, 2>(*a, s);

@@ -454,7 +454,9 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
     //   <= 64  (the same at M = 768: one CFG half alone in the cross-attention) -> 32-row tiles: four times
     const long long wg128 = (long long)((a->N + BN - 1) / BN) * ((a->M + 127) / 128);
     int cfg = wg128 > 256 ? 0 : (wg128 > 128 ? 1 : (wg128 > 64 ? 2 : 3));
-    if (const char *e = getenv("GA_GEMM_CFG")) cfg = atoi(e) % 4;  // tuning aid
+#ifdef GA_TUNING  // tuning builds only
+    if (const char *e = getenv("GA_GEMM_CFG")) cfg = atoi(e) % 4;
+#endif
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KiB of dynamic LDS has to be opted into once per kernel
 #define GA_ATTR(E)                                                                                                  \

@@ -27,12 +27,16 @@ bool make_dims(int32_t N, int32_t V, int32_t H, int32_t W, ga::Dims *d)
 namespace ga {
 int long_list()
 {
+#ifdef GA_TUNING  // tuning builds only (tools/): the product library reads no environment variables
     static const int v = [] {
         const char *e = getenv("GA_LONG_LOG2");
         const int l = e ? atoi(e) : 0;
         return (l >= 6 && l <= 30) ? (1 << l) : kLongList;
     }();
     return v;
+#else
+    return kLongList;
+#endif
 }
 }  // namespace ga
 

@@ -46,8 +46,10 @@ __device__ __forceinline__ bool preprocess_one(
     const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
     if (vz <= 0.2f) return false;
 
+    // A.1 step 2: the quaternion is re-normalised first (upstream quat_to_rotmat); same operation order as the oracle
     const float4 q = *reinterpret_cast<const float4 *>(rotations + 4 * i);
-    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    const float qs = 1.0f / sqrtf(((q.w * q.w + q.x * q.x) + q.y * q.y) + q.z * q.z);
+    const float r = q.x * qs, x = q.y * qs, y = q.z * qs, z = q.w * qs;
     const float tu[3] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y + r * z), 2.f * (x * z - r * y)};
     const float tv[3] = {2.f * (x * y - r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + r * x)};
     const float nn[3] = {2.f * (x * z + r * y), 2.f * (y * z - r * x), 1.f - 2.f * (x * x + y * y)};

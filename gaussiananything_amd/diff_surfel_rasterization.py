@@ -11,6 +11,7 @@ launch sequence); the per-view ``GaussianRasterizer`` call is a V=1 special case
 from __future__ import annotations
 
 import ctypes
+from collections import OrderedDict
 import warnings
 from typing import NamedTuple, Optional
 
@@ -63,16 +64,19 @@ class SurfelWorkspace:
         return self.section("status", torch.int64, _lib.GA_STATUS_WORDS)
 
 
-_ws_cache = {}
+_WS_CACHE_SLOTS = 8          # most recently used (device, N, V, H, W) workspaces kept alive; older ones are released
+_ws_cache = OrderedDict()
 
 
 def _get_workspace(device, n, v, h, w, min_capacity=0):
     key = (str(device), n, v, h, w)
-    ws = _ws_cache.get(key)
+    ws = _ws_cache.pop(key, None)
     if ws is None or ws.capacity < min_capacity:
         cap = max(int(min_capacity), 4 * n * v, 1 << 16)
         ws = SurfelWorkspace(device, n, v, h, w, cap)
-        _ws_cache[key] = ws
+    _ws_cache[key] = ws          # most recently used last
+    while len(_ws_cache) > _WS_CACHE_SLOTS:
+        _ws_cache.popitem(last=False)
     return ws
 
 

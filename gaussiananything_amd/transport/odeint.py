@@ -135,7 +135,7 @@ def _interp_coeffs(y0, y1, ymid, f0, f1, dt):
     return a, b, c, d, y0
 
 
-def odeint(func, y0, t, method="dopri5", atol=1e-6, rtol=1e-3, stats=None):
+def odeint(func, y0, t, method="dopri5", atol=1e-6, rtol=1e-3, stats=None, max_steps=1 << 20):
     """``func(t_scalar_tensor, y) -> dy/dt``.  ``t``: 1-D increasing tensor.  ``stats``: optional dict, receives nfe / steps."""
     if isinstance(atol, (list, tuple)):
         atol = atol[0]
@@ -195,6 +195,14 @@ def odeint(func, y0, t, method="dopri5", atol=1e-6, rtol=1e-3, stats=None):
             tol = atol + rtol * torch.maximum(y.abs(), y1.abs())
             ratio = _rms(err / tol)
             steps += 1
+            # torchdiffeq asserts on a non-finite or underflowing step; without this a NaN model output would make
+            # `ratio <= 1` False forever while _optimal_step keeps growing dt
+            if not math.isfinite(ratio):
+                raise FloatingPointError(f"dopri5: non-finite error ratio at t = {t0} (dt = {dt}): the model returned NaN/inf")
+            if not math.isfinite(dt) or t0 + dt == t0:
+                raise FloatingPointError(f"dopri5: step size underflow at t = {t0} (dt = {dt})")
+            if steps > max_steps:
+                raise RuntimeError(f"dopri5: more than {max_steps} attempted steps")
             if ratio <= 1:
                 ymid = y + sum((dt * c) * kk for c, kk in zip(_C_MID, k) if c != 0)
                 interp = (t0, t0 + dt, _interp_coeffs(y, y1, ymid, k[0], k[6], dt))

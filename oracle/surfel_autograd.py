@@ -23,8 +23,8 @@ NEAR, FAR = 0.2, 100.0
 
 
 def quat_to_rot(q):
-    """Rotation matrix of a (w, x, y, z) quaternion WITHOUT renormalisation (as the rasterizer uses it)."""
-    w, x, y, z = q.unbind(-1)
+    """Rotation matrix of a (w, x, y, z) quaternion, re-normalised first (as the rasterizer does)."""
+    w, x, y, z = (q / q.norm(dim=-1, keepdim=True)).unbind(-1)
     return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
                         2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
                         2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(q.shape[:-1] + (3, 3))

@@ -108,8 +108,12 @@ void oracle_preprocess(int N, int H, int W, const float *means3D, const float *o
         const float vy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
         const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
         if (vz <= 0.2f) continue;
-        /* quat (r,x,y,z) -> rotation; columns tu, tv, n (the kernel does NOT renormalise the quaternion) */
-        const float r = rotations[4 * i], x = rotations[4 * i + 1], y = rotations[4 * i + 2], z = rotations[4 * i + 3];
+        /* quat (r,x,y,z) -> rotation; columns tu, tv, n.  SURVEY.md A.1 step 2: the quaternion is re-normalised by
+         * 1/sqrt(|q|^2) first (upstream auxiliary.h quat_to_rotmat; its glm vec4 holds (r,x,y,z) in (.x,.y,.z,.w) and
+         * sums .w^2 + .x^2 + .y^2 + .z^2 left to right).  IEEE 1.0f / sqrtf here and in the kernel. */
+        const float q0 = rotations[4 * i], q1 = rotations[4 * i + 1], q2 = rotations[4 * i + 2], q3 = rotations[4 * i + 3];
+        const float qs = 1.0f / sqrtf(((q3 * q3 + q0 * q0) + q1 * q1) + q2 * q2);
+        const float r = q0 * qs, x = q1 * qs, y = q2 * qs, z = q3 * qs;
         const float tu[3] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y + r * z), 2.f * (x * z - r * y)};
         const float tv[3] = {2.f * (x * y - r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + r * x)};
         const float nn[3] = {2.f * (x * z + r * y), 2.f * (y * z - r * x), 1.f - 2.f * (x * x + y * y)};

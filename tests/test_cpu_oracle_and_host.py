@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from gaussiananything_amd import synthetic
+from tests import _util
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -467,3 +468,68 @@ def test_committed_bench_line_follows_the_contract():
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+
+
+def test_dopri5_refuses_non_finite_models_and_step_underflow():
+    """torchdiffeq asserts on a non-finite / underflowing step; our loop must not spin forever on a NaN model output."""
+    from gaussiananything_amd.transport.odeint import odeint
+    with pytest.raises(FloatingPointError):
+        odeint(lambda t, y: y * float("nan"), torch.ones(2, 2), torch.linspace(0, 1, 5))
+    with pytest.raises(RuntimeError):
+        odeint(lambda t, y: -y, torch.ones(2, 2), torch.linspace(0, 1, 5), max_steps=1)
+
+
+def test_surfel_oracle_renormalises_quaternions():
+    """scaled quaternions give the same splats (integer artefacts equal, pixels to rounding)."""
+    cams = synthetic.eval_cameras(1)
+    g = synthetic.random_surfels(800, seed=4)[0].clone()
+    g2 = g.clone()
+    g2[:, 6:10] *= torch.exp(2.0 * torch.randn(800, 1, generator=torch.Generator().manual_seed(1)))
+    a, b = _util.oracle_view(g, cams, 0, 96, 96), _util.oracle_view(g2, cams, 0, 96, 96)
+    assert float(np.mean(a["radii"] != b["radii"])) < 0.01 and abs(int(a["D"]) - int(b["D"])) <= 8
+    assert float(np.mean((a["color"] - b["color"]) ** 2)) < 1e-8
+
+
+def test_stage2_conditioning_follows_the_release_config():
+    """sgm/configs/stage2-i23d.yaml: the 'fps-xyz' embedder is PCD_Scaler(0.45) -> the stage-2 denoiser sees xyz / 0.45;
+    cond_key 'img-xyz' matches no embedder input key, so uc == c (guidance is a no-op); the decoder gets the raw cloud.
+    Checked on the orchestration itself with recording stand-ins for the two denoisers and the decoder."""
+    from gaussiananything_amd import cascade
+
+    class Den(torch.nn.Module):
+        def __init__(self, C):
+            super().__init__()
+            self.in_channels = C
+            self.w = torch.nn.Parameter(torch.zeros(1))
+            self.seen = []
+
+        def forward_with_cfg(self, x, t, context=None, cfg_scale=1.0):
+            self.seen.append({k: v.clone() for k, v in context.items()} | {"x0": x.clone()})
+            return -x
+
+    class Dec(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.vit_decoder = torch.nn.Module()
+            self.vit_decoder.pos_embed = torch.nn.Parameter(torch.zeros(1, 16, 4))
+
+        def decode(self, latent, xyz):
+            return {"latent": latent, "query_pcd_xyz": xyz}
+
+    s1, s2, dec = Den(3), Den(10), Dec()
+    cond = {"img_crossattn": torch.randn(1, 5, 8), "img_vector": torch.randn(1, 8)}
+    uc = {k: torch.zeros_like(v) for k, v in cond.items()}
+    out = cascade.cascade(s1, s2, dec, cond, uc, num_steps=4, sampling_method="euler", seed=7)
+    first1, first2 = s1.seen[0], s2.seen[0]
+    # stage 1: [cond | zero uncond]; initial state = CPU-seeded noise rounded to bf16 (flow_matching_trainer.py:720)
+    assert torch.equal(first1["img_crossattn"][1], torch.zeros(5, 8)) and torch.equal(first1["img_crossattn"][0], cond["img_crossattn"][0])
+    torch.manual_seed(7)
+    z = torch.randn(1, 16, 3)
+    assert torch.equal(first1["x0"][0], z[0].bfloat16().float()) and torch.equal(first1["x0"][0], first1["x0"][1])
+    # stage 2: scaled cloud for the denoiser, both CFG halves conditional, raw cloud for the decoder
+    raw = out["query_pcd_xyz"]
+    assert float(raw.abs().max()) <= 0.45
+    assert torch.allclose(first2["fps-xyz"][0], raw[0] / 0.45) and torch.equal(first2["fps-xyz"][0], first2["fps-xyz"][1])
+    assert torch.equal(first2["img_crossattn"][0], first2["img_crossattn"][1]) and torch.equal(first2["img_crossattn"][0], cond["img_crossattn"][0])
+    out0 = cascade.cascade(s1, s2, dec, cond, uc, num_steps=4, sampling_method="euler", seed=7, stage2_zero_image_uc=True)
+    assert torch.equal(s2.seen[-1]["img_crossattn"][1], torch.zeros(5, 8)) and out0["latent"].shape == (1, 16, 10)

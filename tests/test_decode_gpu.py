@@ -178,7 +178,10 @@ def test_cascade_equals_its_parts(gpu_device):
     L = cfg["tokens"]
     xyz = cascade.sample(m1, cond, uc, (L, 3), 1, 4.0, 3, 6, "euler")
     fps = (xyz * 0.164).clip(-0.45, 0.45)
-    lat = cascade.sample(m2, dict(cond, **{"fps-xyz": fps}), dict(uc, **{"fps-xyz": fps}), (L, 10), 1, 4.0, 3, 6, "euler")
+    # stage-2 conditioning of the release (sgm/configs/stage2-i23d.yaml): PCD_Scaler feeds the denoiser xyz / 0.45, and
+    # with cond_key 'img-xyz' the unconditional branch equals the conditional one; the decoder gets the raw cloud
+    c2 = dict(cond, **{"fps-xyz": fps / 0.45})
+    lat = cascade.sample(m2, c2, dict(c2), (L, 10), 1, 4.0, 3, 6, "euler")
     ref = dec.decode(lat, fps)
     assert torch.equal(out["query_pcd_xyz"], fps) and torch.equal(out["gaussians_upsampled_3"], ref["gaussians_upsampled_3"])
     assert out["gaussians_upsampled_3"].shape == (1, L * 96, 13)
