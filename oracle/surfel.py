@@ -63,7 +63,7 @@ def rasterize(means3D, opacities, colors, scales, rotations, viewmatrix, projmat
 
     Returns a dict: color[3,H,W], allmap[7,H,W], radii[N] i32, rect[N,4] u32, tiles_touched[N] u32,
     depths/xy/trans/normal_opacity (f32), point_list[D] u32, keys[D] u64, ranges[tiles,2] u32,
-    final_T[H,W], n_contrib[H,W], D, pairs.
+    final_T[H,W], n_contrib[H,W], n_walked[H,W] (list entries each pixel visited), D, pairs.
     """
     L = lib()
     means3D = _f32(means3D, (-1, 3)); N = means3D.shape[0]
@@ -89,11 +89,12 @@ def rasterize(means3D, opacities, colors, scales, rotations, viewmatrix, projmat
                  _p(keys), _p(vals), _p(ktmp), _p(vtmp), _p(ranges))
     color = np.zeros((3, H, W), np.float32); allmap = np.zeros((7, H, W), np.float32)
     final_T = np.zeros((H, W), np.float32); n_contrib = np.zeros((H, W), np.uint32)
+    n_walked = np.zeros((H, W), np.uint32)
     pairs = ctypes.c_int64(0)
     if threads is not None:
         L.oracle_set_threads(ctypes.c_int(int(threads)))
     L.oracle_blend(ctypes.c_int(N), ctypes.c_int(H), ctypes.c_int(W), ctypes.byref(pre), _p(colors), _p(bg),
-                   _p(vals), _p(ranges), _p(color), _p(allmap), _p(final_T), _p(n_contrib), ctypes.byref(pairs))
+                   _p(vals), _p(ranges), _p(color), _p(allmap), _p(final_T), _p(n_contrib), _p(n_walked), ctypes.byref(pairs))
     out.update(color=color, allmap=allmap, point_list=vals[:D], keys=keys[:D], ranges=ranges,
-               final_T=final_T, n_contrib=n_contrib, D=D, pairs=int(pairs.value))
+               final_T=final_T, n_contrib=n_contrib, n_walked=n_walked, D=D, pairs=int(pairs.value))
     return out

@@ -224,7 +224,7 @@ void oracle_bin(int N, int H, int W, const OraclePre *o, int64_t D, uint64_t *ke
  * pair_count (optional): number of (pixel, list entry) evaluations actually started, i.e. the real K. */
 void oracle_blend(int N, int H, int W, const OraclePre *o, const float *colors, const float *bg,
                   const uint32_t *point_list, const uint32_t *ranges, float *out_color, float *out_others,
-                  float *final_T, uint32_t *n_contrib, int64_t *pair_count)
+                  float *final_T, uint32_t *n_contrib, uint32_t *n_walked, int64_t *pair_count)
 {
     (void)N;
     const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
@@ -279,6 +279,7 @@ void oracle_blend(int N, int H, int W, const OraclePre *o, const float *colors, 
                 const size_t pid = (size_t)pyi * W + pxi, HW = (size_t)H * W;
                 if (final_T) final_T[pid] = T;
                 if (n_contrib) n_contrib[pid] = last_contributor;
+                if (n_walked) n_walked[pid] = contributor; /* list entries visited, the stopping one included */
                 for (int ch = 0; ch < 3; ++ch) out_color[ch * HW + pid] = C[ch] + T * bg[ch];
                 out_others[DEPTH_OFFSET * HW + pid] = Dp;
                 out_others[ALPHA_OFFSET * HW + pid] = 1 - T;

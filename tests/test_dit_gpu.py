@@ -328,30 +328,48 @@ def test_release_models_full_depth_against_oracle(gpu_device, arch, C):
 def test_dopri5_on_the_golden_model_against_the_ode_oracle(gpu_device):
     """The reference's default sampler -- sample_ode(num_steps=N) = dopri5, rtol 1e-3, atol 1e-6
     (/root/reference/transport/transport.py:384-431, integrators.py:111-118) -- on the HIP denoiser, against oracle/ode.py
-    (float64 state, torchdiffeq semantics of SURVEY.md A.3) integrating the fp32 DiT oracle on the same golden weights:
-    the step controller must take the same decisions (function evaluations, accepted and rejected steps) and the
-    saved states must agree."""
+    (float64 state, torchdiffeq semantics of SURVEY.md A.3):
+      (i)  integrator parity: the oracle integrating the SAME function (the HIP forward_with_cfg) must take the same
+           decisions -- function evaluations, accepted and rejected steps -- and give the same saved states;
+      (ii) end-to-end: the saved states against the oracle integrating the fp32 DiT oracle on the same golden weights.
+           The step sequences differ there by construction: the bf16 rounding noise of the HIP model enters the embedded
+           error estimate (the reference under bf16 autocast has the same property), so only the states are compared."""
     from gaussiananything_amd.transport import Sampler, create_transport
     from oracle import dit as od, ode as oo
     z, model, ctx = _load_golden(1, gpu_device)
     x = z["x"]
+    n_out = 9
+    tgrid = np.linspace(0.0, 1.0, n_out)
+    sampler = Sampler(create_transport("GVP", "velocity", None, None, None, snr_type="uniform"))
+    fn = sampler.sample_ode(sampling_method="dopri5", num_steps=n_out, atol=1e-6, rtol=1e-3)
+    with torch.no_grad():
+        out = fn(x.to(gpu_device), model.forward_with_cfg, context=ctx, cfg_scale=z["cfg_scale"])
+    s_hip = dict(sampler.last_ode.last_stats)
+    assert out.shape == (n_out,) + tuple(x.shape)
+
+    def f_hip(ts, yy):
+        with torch.no_grad():
+            tt = torch.ones(x.shape[0], device=gpu_device) * torch.tensor(ts, dtype=torch.float32, device=gpu_device)
+            return model.forward_with_cfg(torch.from_numpy(yy).float().to(gpu_device), tt, context=ctx,
+                                          cfg_scale=z["cfg_scale"]).double().cpu().numpy()
+
+    s_same = {}
+    same = oo.odeint(f_hip, x.double().numpy(), tgrid, method="dopri5", atol=1e-6, rtol=1e-3, stats=s_same)
+    assert (s_hip["nfe"], s_hip["steps"], s_hip["rejected"]) == (s_same["nfe"], s_same["steps"], s_same["rejected"]), (s_hip, s_same)
+    # same decisions; the states differ by more than fp32-vs-fp64 rounding because the function itself is bf16: an ulp of
+    # the fp32 state can round a bf16 operand the other way (measured 7e-4)
+    assert rel_l2(out.cpu().double(), torch.from_numpy(same)) < 3e-3
+
     sd = {k: v.float() for k, v in z["state_dict"].items()}
     cctx = {k: v.float() for k, v in z["context"].items()}
-    n_out = 9
-    s_ref = {}
 
     def f_ref(ts, yy):
         tt = torch.full((x.shape[0],), float(ts))
         return od.forward_with_cfg(sd, torch.from_numpy(yy).float(), tt, cctx, z["cfg_scale"]).double().numpy()
 
-    ref = oo.odeint(f_ref, x.double().numpy(), np.linspace(0.0, 1.0, n_out), method="dopri5", atol=1e-6, rtol=1e-3, stats=s_ref)
-    sampler = Sampler(create_transport("GVP", "velocity", None, None, None, snr_type="uniform"))
-    fn = sampler.sample_ode(sampling_method="dopri5", num_steps=n_out, atol=1e-6, rtol=1e-3)
-    with torch.no_grad():
-        out = fn(x.to(gpu_device), model.forward_with_cfg, context=ctx, cfg_scale=z["cfg_scale"])
-    s_hip = sampler.last_ode.last_stats
-    assert out.shape == (n_out,) + tuple(x.shape)
-    assert s_hip["nfe"] == s_ref["nfe"] and s_hip["steps"] == s_ref["steps"] and s_hip["rejected"] == s_ref["rejected"], (s_hip, s_ref)
+    s_ref = {}
+    ref = oo.odeint(f_ref, x.double().numpy(), tgrid, method="dopri5", atol=1e-6, rtol=1e-3, stats=s_ref)
+    assert s_ref["rejected"] <= s_ref["steps"] and s_hip["nfe"] >= s_ref["nfe"]
     assert rel_l2(out.cpu().double(), torch.from_numpy(ref)) < 3e-2
 
 
