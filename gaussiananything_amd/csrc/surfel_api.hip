@@ -24,22 +24,6 @@ bool make_dims(int32_t N, int32_t V, int32_t H, int32_t W, ga::Dims *d)
 
 }  // namespace
 
-namespace ga {
-int long_list()
-{
-#ifdef GA_TUNING  // tuning builds only (tools/): the product library reads no environment variables
-    static const int v = [] {
-        const char *e = getenv("GA_LONG_LOG2");
-        const int l = e ? atoi(e) : 0;
-        return (l >= 6 && l <= 30) ? (1 << l) : kLongList;
-    }();
-    return v;
-#else
-    return kLongList;
-#endif
-}
-}  // namespace ga
-
 extern "C" {
 
 const char *ga_surfel_version(void) { return "ga_mi355 surfel gfx950 r1"; }
@@ -55,6 +39,7 @@ int ga_surfel_workspace_layout(int32_t num_points, int32_t num_views, int32_t im
     const size_t nv = (size_t)d.N * d.V, nt = (size_t)d.V * d.tiles, cap = (size_t)capacity;
     size_t off = 0;
     out->status = off;      off += align256(GA_STATUS_WORDS * sizeof(int64_t));
+    out->seg_sync = off;    off += align256((4 * (cap / 256 + 1) + 4 * (cap / 1024 + 1)) * 4);
     out->tile_count = off;  off += align256(nt * 4);
     out->tile_start = off;  off += align256((nt + 1) * 4);
     out->tile_cursor = off; off += align256(nt * 4);
@@ -65,6 +50,8 @@ int ga_surfel_workspace_layout(int32_t num_points, int32_t num_views, int32_t im
     out->record = off;      off += align256(nv * ga::kRec * 4);
     out->keys = off;        off += align256(cap * 8);
     out->point_list = off;  off += align256(cap * 4);
+    out->seg_table = off;   off += align256(2 * 40 * 4);
+    out->seg_scratch = off; off += align256((cap / 256 + 1) * (size_t)ga::kSegFloats * 4);
     out->total_bytes = off;
     return GA_OK;
 }
@@ -88,6 +75,9 @@ int ga_surfel_forward(const GaSurfelForwardArgs *a, void *stream_v)
     unsigned char *w = static_cast<unsigned char *>(a->workspace);
     ga::Workspace ws;
     ws.status = reinterpret_cast<int64_t *>(w + L.status);
+    ws.seg_sync = reinterpret_cast<uint32_t *>(w + L.seg_sync);
+    ws.seg_table = reinterpret_cast<uint32_t *>(w + L.seg_table);
+    ws.seg_scratch = reinterpret_cast<float *>(w + L.seg_scratch);
     ws.tile_count = reinterpret_cast<uint32_t *>(w + L.tile_count);
     ws.tile_start = reinterpret_cast<uint32_t *>(w + L.tile_start);
     ws.tile_cursor = reinterpret_cast<uint32_t *>(w + L.tile_cursor);
@@ -101,7 +91,8 @@ int ga_surfel_forward(const GaSurfelForwardArgs *a, void *stream_v)
 
     (void)hipGetLastError();
     // (event 0 is recorded after this memset so that it brackets kernels only)
-    // status + tile counters are contiguous at the head of the workspace: one memset node clears both
+    // status words, segment flags / counters and tile counters are contiguous at the head of the workspace: one memset
+    // node clears them all
     if (hipMemsetAsync(w + L.status, 0, L.tile_start - L.status, s) != hipSuccess) return GA_ERR_LAUNCH;
     auto mark = [&](int k) {
         if (a->stage_events && a->stage_events[k]) (void)hipEventRecord(static_cast<hipEvent_t>(a->stage_events[k]), s);

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(const uint32_t *
                                                                 uint32_t *__restrict__ tile_cursor,
                                                                 uint4 *__restrict__ tile_order,
                                                                 uint4 *__restrict__ run_table, int n,
-                                                                int64_t capacity, int long_bucket, int64_t *__restrict__ status)
+                                                                int64_t capacity, uint32_t *__restrict__ seg_table,
+                                                                int64_t *__restrict__ status)
 {
     __shared__ uint32_t wt[kScanPer * 16], wt_ex[kScanPer * 16];
     __shared__ uint32_t hist[16][kClasses];       // wave-private class counts, later wave-private rank counters
@@ -131,11 +132,27 @@ __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(const uint32_t *
         }
         if (lane < kClasses) {
             class_start[b] = sx - pop;
-            // every list longer than one sort run lives in a class >= kBigBucket; lists >= the long-list bound (a power
-            // of two) in a class >= long_bucket: remember where those classes end
+            // every list longer than one sort run lives in a class >= kBigBucket: remember where those classes end
             constexpr int kBigBucket = 32 - __builtin_clz((unsigned)kSortCap + 1u);
             if (b == kBigBucket) nbig_s = sx;
-            if (b == long_bucket) status[GA_STATUS_LONG_TILES] = (int64_t)sx;
+        }
+        {   // segmented blend: a tile of class b >= kSegClass becomes seg_count(b) work items; the classes are laid out
+            // longest first, so lane order is work order.  seg_table[b] = (first tile_order slot, first work item)
+            const uint32_t segs = (lane < kClasses && b >= kSegClass) ? pop * (uint32_t)seg_count(b) : 0u;
+            uint32_t wx = segs;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_up(wx, o, 64);
+                if (lane >= o) wx += y;
+            }
+            if (lane < kClasses) {
+                seg_table[2 * b] = sx - pop;
+                seg_table[2 * b + 1] = wx - segs;
+                if (b == kSegClass) {
+                    status[GA_STATUS_LONG_TILES] = (int64_t)sx;
+                    status[GA_STATUS_SEG_WORK] = (int64_t)wx;
+                }
+            }
         }
         uint64_t total = lane < 16 ? wide_tot[lane] : 0ull;
         uint32_t mx = lane < 16 ? wave_max[lane] : 0u;
@@ -555,8 +572,7 @@ void launch_binning(const GaSurfelForwardArgs &a, const Dims &d, const Workspace
 {
     const int nt = d.V * d.tiles;
     hipLaunchKernelGGL(surfel_tile_scan_kernel, dim3(1), dim3(1024), 0, s, ws.tile_count, ws.tile_start,
-                       ws.tile_cursor, ws.tile_order, ws.run_table, nt, a.capacity,
-                       32 - __builtin_clz((unsigned)long_list()), ws.status);  // classes >= this hold the long lists
+                       ws.tile_cursor, ws.tile_order, ws.run_table, nt, a.capacity, ws.seg_table, ws.status);
     const dim3 grid((unsigned)((d.N + 256 * kBinSplats - 1) / (256 * kBinSplats)), (unsigned)d.V);
     if (d.tiles <= kLdsTiles)
         hipLaunchKernelGGL(surfel_fill_kernel<true>, grid, dim3(256), 2 * d.tiles * sizeof(uint32_t), s, ws.rect,

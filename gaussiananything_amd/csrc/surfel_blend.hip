@@ -3,29 +3,38 @@
 // /root/reference/nsr/gs_surfel.py:100-114; consumer of the 7 allmap channels :121-142); arithmetic per
 // SURVEY.md Appendix A.1 "Blend".
 //
-// MI355X-first formulation ("wave-autonomous" blend), not the CUDA block-cooperative one.  What the measurements on
-// MI355X showed (profiles/r1a_*): the kernel is bound by the SERIAL CHAIN of the longest tile lists and by VALU issue,
-// never by HBM; so the design minimises latency on the chain and instructions per (pixel, splat) pair:
-//   * a 256-thread workgroup still owns one 16x16 tile (that granularity is part of the semantics: the tile rect
-//     decides which pixels a splat may touch), but each of its four 64-lane wavefronts owns one 8x8 quadrant and runs
-//     completely on its own -- no workgroup barrier, independent early termination; workgroups are scheduled longest
-//     list first (tile_order);
-//   * the tile's depth-ordered list is consumed 64 entries at a time with LANES = ENTRIES: every lane fetches one
-//     entry's conservative {alpha >= 1/255} pixel box and its 96-byte record (vector loads, all 64 in flight at
-//     once, issued one chunk AHEAD of use), tests the box against the quadrant, rebases the record's plane
-//     coefficients to the quadrant origin and parks it in a wave-private LDS slot.  A 64-bit ballot of the box test
-//     is the list of entries that can contribute (about half are culled for the sub-pixel splats of real scenes,
-//     which also halves the serial chain);
-//   * LANES = PIXELS with per-lane survivor lists: from 16 ballots per chunk (does my entry's box cover pixel column c /
-//     row r of the quadrant?) every lane ANDs the masks of its own column and row and walks only those entries --
-//     the trip count of a wave drops from "survivors of the quadrant" to "survivors of its busiest pixel"; records are
-//     gathered from LDS four at a time, their alphas evaluated back to back (no cross-entry dependence), then
-//     composited in order;
-//   * the ray/splat intersection uses the plane form p = C' + dx*A + dy*B (6 FMAs) instead of two 3-vector affine
-//     maps and a cross product (18 ops); A, B, C come from the preprocess kernel;
-//   * upstream's chain of `continue` filters is evaluated branch-free into one predicate, so a pair costs ~25 VALU
-//     instructions and one EXEC-masked region (~25 more) when it contributes; a wave leaves the list as soon as its
-//     64 pixels are saturated.
+// MI355X-first formulation, not the CUDA block-cooperative one.  The kernel is bound by VALU issue and LDS bandwidth
+// (profiles/r1f_pmc.txt: 75 M wave instructions per launch, LDS 83 % busy, HBM far from its roof), so everything here is
+// about instructions and LDS bytes per useful (pixel, splat) pair:
+//   * WORK ITEM = one 16x16 tile, or one SEGMENT (256..512 list entries) of a tile whose list has >= 1024 entries; the
+//     16x16 granularity is part of the semantics (the tile rect decides which pixels a splat may touch).
+//   * WORKGROUP = 5 wavefronts: four CONSUMERS, one per 8x8 pixel quadrant, and one PRODUCER.
+//   * STAGING (lanes = entries, 64 list entries = one chunk): gather the 96-byte records, test every entry's conservative
+//     {alpha >= 1/255} pixel box against the 16 pixel columns and 16 pixel rows of the tile (32 ballots), rebase the plane
+//     coefficients to the tile origin, leave records and masks in LDS.  Each record is fetched and prepared ONCE per tile
+//     (round 1 did it once per quadrant: 2.3x the algorithmic HBM/L2 traffic and four times the staging instructions) and
+//     once for BOTH passes of a segment.  The first four chunks of an item are staged by the four consumer waves in
+//     parallel (they would otherwise sit out the load latencies of the first chunk), the rest by the producer with its
+//     loads one chunk ahead (ids two ahead).  Up to kItemChunks chunks stay resident; a longer unsegmented list
+//     (513..1023 entries) wraps around.
+//   * Consumers run with LANES = PIXELS and per-lane survivor lists: a lane ANDs the mask of its column with the mask of
+//     its row and walks only those entries, kU per trip (the LDS gathers and alpha evaluations of a trip are
+//     independent, the composites follow in order).  A two-chunk window lets a lane that has finished the older chunk
+//     run ahead into the newer one.  The only synchronisation is one LDS word per chunk (DS operations of a wave execute
+//     in order, so stamp-after-data is enough): no workgroup barrier in the list walk, the quadrants are independent of
+//     each other, a saturated quadrant leaves.
+//   * SEGMENTS make the serial chain of a long list short (round 1: one workgroup, the hottest quadrant of the 5 127-entry
+//     list, spanned the whole launch).  Pass 1: every segment multiplies (1 - alpha) over its pairs and publishes the
+//     per-pixel product; pass 2: a segment enters the UNCHANGED sequential blend with the product of its predecessors, so
+//     weights, the `T > 0.5` median test and the `T (1 - alpha) < 1e-4` stop rule see the global transmittance; the last
+//     segment to finish a quadrant adds the partial sums in order, with the cross terms of the depth distortion
+//     (M2_before * W_k - 2 M1_before * M1_k).  Segments of a tile are different workgroups (4, 8, 16 ... by list length);
+//     they find each other through a scratch area and per-(segment, quadrant) flags in the workspace.  A segment only
+//     ever waits for LOWER-numbered segments and segment work items are handed out by an atomic ticket, so whatever it
+//     waits for has already started: no deadlock, whatever the dispatch order.  The only numerical difference to the
+//     sequential order is the rounding of the prefix product.
+//   * the ray/splat intersection uses the plane form p = C' + dx*A + dy*B (6 FMAs) instead of two 3-vector affine maps
+//     and a cross product (18 ops); upstream's chain of `continue` filters is one branch-free predicate.
 // Pixel results are compared with the oracle by MSE (<= 1e-5, tests/), so this TU may contract to FMA and uses
 // v_rcp_f32 / v_exp_f32 instead of IEEE division and libm expf.
 #include <hip/hip_fp16.h>
@@ -38,6 +47,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));  // one packed-fp32 operan
 
 __device__ __forceinline__ f2 lo2(const float4 &q) { return f2{q.x, q.y}; }
 __device__ __forceinline__ f2 hi2(const float4 &q) { return f2{q.z, q.w}; }
+
+constexpr int kSlots = kItemChunks * 64;   // list entries of a work item that fit the LDS image
+constexpr uint32_t kGone = 0xFFFFFFFFu;    // done[q]: this quadrant needs nothing any more
 
 struct PixelAcc {  // pairs are updated by one v_pk_fma_f32
     float T, Dp, dist, median;
@@ -52,21 +64,45 @@ __device__ __forceinline__ PixelAcc fresh_pixel(float T)
     return PixelAcc{T, 0.0f, 0.0f, 0.0f, f2{0.0f, 0.0f}, f2{0.0f, 0.0f}, f2{0.0f, 0.0f}, f2{0.0f, 0.0f}};
 }
 
-struct Rec {  // one staged record (quadrant-relative, see the staging step) in registers; layout: surfel_common.h
+struct Rec {  // one staged record (tile-relative, see stage_chunk) in registers; layout: surfel_common.h
     float4 q0, q1, q2, q3, q4;
     f2 q5;
 };
 
-// LDS image of a wave's staged chunks: six planes of 128 float4 (plane q holds quad q of every slot), so that the
-// staging writes are contiguous and a gather of 16 different slots spreads over all 64 banks.
-__device__ __forceinline__ Rec lds_read_rec(const float4 (*planes)[128], int j)
+// LDS image of a work item: six planes of kSlots entries (plane q holds quad q of every entry), so that the stager's writes
+// are contiguous and a consumer's gather of 16 different entries spreads over all 64 banks; per chunk the 32 survivor masks
+// (entries covering pixel column c / pixel row c - 16 of the tile) and a stamp.
+struct __attribute__((aligned(16))) Ring {
+    float4 planes[5][kSlots];
+    f2 plane5[kSlots];
+    unsigned long long masks[kItemChunks][32];
+    uint32_t stamp[kItemChunks];   // k + 1 once chunk k of the item is in slot k % kItemChunks
+    uint32_t done[4];              // unsegmented lists of more than kItemChunks chunks only: chunks finished by consumer q
+    uint32_t work;                 // work item of this workgroup (ticket broadcast)
+};
+
+__device__ __forceinline__ uint32_t lds_load(const uint32_t *p)
 {
-    return Rec{planes[0][j], planes[1][j], planes[2][j], planes[3][j], planes[4][j],
-               *reinterpret_cast<const f2 *>(&planes[5][j])};
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+__device__ __forceinline__ void lds_store(uint32_t *p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// Cross-workgroup exchange of the segmented blend.  The L2 of an XCD is not coherent with the other seven, and an
+// agent-scope release / acquire FENCE is a write-back / invalidate of that whole L2 (measured: 0.7 ms per launch for
+// 1 340 segments).  So the exchanged words themselves are written and read with agent-scope accesses (sc1: they bypass the
+// L2), and ordering is "my stores have been acknowledged (vmcnt = 0), then the flag".
+__device__ __forceinline__ void xwg_store(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float xwg_load(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xwg_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+
+// compiler fence: LDS operations of one wave reach the LDS in program order, so ordering data and flag accesses in the
+// instruction stream is all the protocol needs
+#define GA_LDS_ORDER() asm volatile("" ::: "memory")
 
 // One (pixel, splat) evaluation -- SURVEY.md A.1 "Blend" -- in two parts.  dxy: this lane's pixel relative to the
-// quadrant origin.  eval_alpha is free of cross-entry dependences (several entries are evaluated back to back);
+// tile origin.  eval_alpha is free of cross-entry dependences (several entries are evaluated back to back);
 // composite is the short sequential part.  Upstream's chain of `continue` filters is evaluated branch-free into one
 // predicate (the filters commute: each one only decides whether the pair is skipped).
 struct Alpha {
@@ -126,58 +162,135 @@ __device__ __forceinline__ void composite(const Rec &r, const Alpha &e, PixelAcc
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Walk the list range [sbeg, send) for one wave = one 8x8 pixel quadrant.  FULL: the complete per-pixel blend;
-// !FULL: only the transmittance product of the range (every contributing pair multiplies T by 1 - alpha; no stop
-// rule), which the segment-parallel kernel needs to give each segment its true starting transmittance.
-struct WaveCtx {
-    int lane;
-    f2 dxy;
-    float qxlo, qylo;
-    uint32_t safe;  // a valid list position: out-of-range lanes re-read it
-    const uint32_t *__restrict__ point_list;
-    const float4 *__restrict__ rec4;
-    float4 (*planes)[128];
+struct Stats {
+    unsigned iters, chunks, useful;
 };
 
-template <bool FULL>
-__device__ __forceinline__ void walk_list(const WaveCtx &c, uint32_t sbeg, uint32_t send, PixelAcc &a, bool &done,
-                                          unsigned &stat_iters, unsigned &stat_chunks, int flags, unsigned &stat_useful)
-{
-    if (sbeg >= send) return;
-    const int lane = c.lane;
-    float4(*planes)[128] = c.planes;
-    // ---- software pipeline over 64-entry chunks (lanes = entries) ------------------------------------------------
-    //   iteration k consumes {bb, g0..g5} of chunk k (issued during k-1), issues them for chunk k+1 (whose ids were
-    //   issued during k-1) and issues the ids of chunk k+2.  Loads are unconditional (out-of-range lanes re-read a
-    //   valid entry) so the loop body is straight-line code and the loaded registers stay untouched until consumed.
+// ---------------------------------------------------------------------------------------------------------------
+// STAGING.  One chunk: the records of 64 consecutive list entries (lanes = entries) are already in registers.
+struct ChunkRegs {
     float4 g0, g1, g2, g3, g4;
     f2 g5;
-    uint32_t id_next;
-    {
-        const uint32_t e0 = sbeg + lane < send ? sbeg + lane : c.safe;
-        const uint32_t e1 = sbeg + 64 + lane < send ? sbeg + 64 + lane : c.safe;
-        const uint32_t id0 = c.point_list[e0];
-        id_next = c.point_list[e1];
-        const float4 *r = c.rec4 + (size_t)id0 * 6;
-        g0 = r[0]; g1 = r[1]; g2 = r[2]; g3 = r[3]; g4 = r[4]; g5 = *reinterpret_cast<const f2 *>(r + 5);
-    }
-    // loop-invariant lane predicates "my column / row is c" as wave masks (SGPR pairs)
-    unsigned long long colsel[8], rowsel[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        colsel[k] = __builtin_amdgcn_ballot_w64((lane & 7) == k);
-        rowsel[k] = __builtin_amdgcn_ballot_w64((lane >> 3) == k);
-    }
+};
 
-    // Per-lane survivor masks of a TWO-chunk window: `cur` = what is left of the previous chunk (LDS buffer oldb), `nxt` =
-    // the chunk staged in this step (buffer newb).  A lane that has finished `cur` runs ahead into `nxt` while slower
-    // lanes still work on `cur`; the step ends when no lane has anything left in `cur`, which frees that buffer for the
-    // chunk after next.  With one-chunk windows only 36 % of the lane slots did work (lists per chunk are short and
-    // Poisson-like: mean 3.4, max over 64 lanes ~9); the run-ahead evens that out (measured: see DESIGN.md).
+__device__ __forceinline__ ChunkRegs load_chunk(const float4 *__restrict__ rec4, uint32_t id)
+{
+    const float4 *r = rec4 + (size_t)id * 6;
+    return ChunkRegs{r[0], r[1], r[2], r[3], r[4], *reinterpret_cast<const f2 *>(r + 5)};
+}
+
+// masks, rebase, LDS image of chunk k (slot k % kItemChunks), stamp.  `valid`: my entry lies inside the list range.
+__device__ __forceinline__ void stage_chunk(Ring &ring, int lane, uint32_t k, const ChunkRegs &g, bool valid, float tx0, float ty0)
+{
+    // centre relative to the tile origin and the cull half-extents (fp16 pair, +inf = unbounded, < 0 = never)
+    const float ex0 = g.g2.x - tx0, ey0 = g.g2.y - ty0;
+    const uint32_t cull = __float_as_uint(g.g3.w);
+    const float rx = valid ? __half2float(__ushort_as_half((unsigned short)(cull & 0xffffu))) : -1.0f;
+    const float ry = __half2float(__ushort_as_half((unsigned short)(cull >> 16)));
+    // the 32 masks leave through lanes 0..31: lane c takes column mask c, lane 16 + c row mask c
+    uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const unsigned long long xm = __builtin_amdgcn_ballot_w64(fabsf((float)c - ex0) <= rx);
+        const unsigned long long ym = __builtin_amdgcn_ballot_w64(fabsf((float)c - ey0) <= ry);
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(mlo) : "s"((uint32_t)xm), "n"(c));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(mhi) : "s"((uint32_t)(xm >> 32)), "n"(c));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(mlo) : "s"((uint32_t)ym), "n"(16 + c));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(mhi) : "s"((uint32_t)(ym >> 32)), "n"(16 + c));
+    }
+    // rebase to the tile origin: C' = C + (t0.x - ox)*A + (t0.y - oy)*B with o = rint(centre); centre -= t0
+    const float ux = tx0 - rintf(g.g2.x), uy = ty0 - rintf(g.g2.y);
+    const int slot = (int)(k % kItemChunks), j = slot * 64 + lane;
+    ring.planes[0][j] = g.g0;
+    ring.planes[1][j] = make_float4(fmaf(uy, g.g0.z, fmaf(ux, g.g0.x, g.g1.x)), fmaf(uy, g.g0.w, fmaf(ux, g.g0.y, g.g1.y)), g.g1.z, g.g1.w);
+    ring.planes[2][j] = make_float4(ex0, ey0, fmaf(uy, g.g1.w, fmaf(ux, g.g1.z, g.g2.z)), g.g2.w);
+    ring.planes[3][j] = g.g3;
+    ring.planes[4][j] = g.g4;
+    ring.plane5[j] = g.g5;
+    if (lane < 32) ring.masks[slot][lane] = ((unsigned long long)mhi << 32) | mlo;
+    GA_LDS_ORDER();
+    if (lane == 0) lds_store(&ring.stamp[slot], k + 1);
+    GA_LDS_ORDER();
+}
+
+constexpr uint32_t kHelpChunks = 4;   // chunks 0..3 of an item are staged by the four consumer waves, one each
+
+// a consumer wave's share of the staging: chunk `k` of [sbeg, send), dependent loads (ids, then records) and all
+__device__ __forceinline__ void stage_one(Ring &ring, int lane, uint32_t k, uint32_t sbeg, uint32_t send,
+                                          const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec4,
+                                          float tx0, float ty0)
+{
+    const uint32_t e = sbeg + k * 64 + lane;
+    const bool valid = e < send;
+    const ChunkRegs g = load_chunk(rec4, point_list[valid ? e : sbeg]);
+    stage_chunk(ring, lane, k, g, valid, tx0, ty0);
+}
+
+// PRODUCER wave: chunks kHelpChunks.. of [sbeg, send), loads one chunk ahead (ids two ahead).  Up to kItemChunks chunks
+// stay resident; beyond that (an unsegmented list of 513..1023 entries) a chunk's slot is reused once every consumer has
+// finished the chunk kItemChunks before it.
+__device__ __forceinline__ void produce(Ring &ring, int lane, uint32_t sbeg, uint32_t send,
+                                        const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec4,
+                                        float tx0, float ty0)
+{
+    const uint32_t nch = (send - sbeg + 63) / 64;
+    if (nch <= kHelpChunks) return;
+    auto entry = [&](uint32_t k) {   // list position of this lane's entry in chunk k (clamped: out-of-range lanes re-read a valid one)
+        const uint32_t e = sbeg + k * 64 + lane;
+        return e < send ? e : sbeg;
+    };
+    uint32_t id_next;
+    ChunkRegs g;
+    {
+        const uint32_t id0 = point_list[entry(kHelpChunks)];
+        id_next = point_list[entry(kHelpChunks + 1)];
+        g = load_chunk(rec4, id0);
+    }
+    for (uint32_t k = kHelpChunks; k < nch; ++k) {
+        const ChunkRegs cur = g;
+        const bool valid = sbeg + k * 64 + lane < send;
+        {   // issue the next chunk's loads (its ids arrived during the previous iteration) and the ids after that
+            const uint32_t idn = id_next;
+            id_next = point_list[entry(k + 2)];
+            g = load_chunk(rec4, idn);
+        }
+        if (k >= (uint32_t)kItemChunks) {   // wrap: wait until every consumer has finished chunk k - kItemChunks
+            for (;;) {
+                const uint32_t d0 = lds_load(&ring.done[0]), d1 = lds_load(&ring.done[1]);
+                const uint32_t d2 = lds_load(&ring.done[2]), d3 = lds_load(&ring.done[3]);
+                const uint32_t dmin = min(min(d0, d1), min(d2, d3));
+                if (dmin == kGone) return;
+                if (dmin + kItemChunks > k) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            GA_LDS_ORDER();
+        }
+        stage_chunk(ring, lane, k, cur, valid, tx0, ty0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// CONSUMER: walk the `nch` chunks of the item for one 8x8 pixel quadrant.  FULL: the complete per-pixel blend;
+// !FULL: only the transmittance product of the range (every contributing pair multiplies T by 1 - alpha; no stop rule
+// except "the product alone is below the stop threshold").
+struct Consumer {
+    int lane, quad;
+    f2 dxy;          // my pixel relative to the tile origin
+    int col, row;    // my pixel column / row inside the tile
+};
+
+#ifndef GA_BLEND_KU
+#define GA_BLEND_KU 4
+#endif
+
+template <bool FULL>
+__device__ __forceinline__ void consume(Ring &ring, const Consumer &c, uint32_t nch, PixelAcc &a, bool &done, Stats &st, int flags)
+{
+    // Per-lane survivor masks of a TWO-chunk window: `cur` = what is left of the previous chunk, `nxt` = the chunk fetched
+    // in this step.  A lane that has finished `cur` runs ahead into `nxt` while slower lanes still work on `cur`; the step
+    // ends when no lane has anything left in `cur`.
     unsigned long long cur = 0, nxt = 0;
-    int step = 0;
-    constexpr int kU = 4;
+    constexpr int kU = GA_BLEND_KU;
     auto trips = [&](int oldb, int newb) {
         // Lanes walk their own lists independently (compositing order only matters per pixel), kU entries per trip: the
         // kU gathers and alpha evaluations are mutually independent, then the contributing ones are composited in
@@ -185,7 +298,7 @@ __device__ __forceinline__ void walk_list(const WaveCtx &c, uint32_t sbeg, uint3
         while (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
             int j[kU];
             bool live[kU];
-            int last = lane;
+            int last = oldb;
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 const bool has = cur != 0;
@@ -197,12 +310,13 @@ __device__ __forceinline__ void walk_list(const WaveCtx &c, uint32_t sbeg, uint3
                 cur = has ? rest : 0ull;
                 nxt = has ? nxt : rest;
             }
-            stat_iters += kU;
+            st.iters += kU;
             Rec r[kU];
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
-                if (FULL) r[u] = lds_read_rec(planes, j[u]);
-                else { r[u].q0 = planes[0][j[u]]; r[u].q1 = planes[1][j[u]]; r[u].q2 = planes[2][j[u]]; r[u].q3 = planes[3][j[u]]; }
+                r[u].q0 = ring.planes[0][j[u]]; r[u].q1 = ring.planes[1][j[u]];
+                r[u].q2 = ring.planes[2][j[u]]; r[u].q3 = ring.planes[3][j[u]];
+                if (FULL) { r[u].q4 = ring.planes[4][j[u]]; r[u].q5 = ring.plane5[j[u]]; }
             }
             Alpha e[kU];
 #pragma unroll
@@ -226,69 +340,34 @@ __device__ __forceinline__ void walk_list(const WaveCtx &c, uint32_t sbeg, uint3
         }
     };
 
-    for (uint32_t base = sbeg; base < send; base += 64, ++step) {
+    const bool wraps = nch > (uint32_t)kItemChunks;
+    uint32_t i = 0;
+    for (; i < nch; ++i) {
         if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
-        const int newb = (step & 1) * 64, oldb = 64 - newb;
-        // ---- lanes = entries: which pixel columns / rows of the quadrant does my entry's cull box cover? ----------
-        const bool valid = base + lane < send;
-        // centre relative to the quadrant origin and the cull half-extents (fp16 pair, +inf = unbounded, < 0 = never)
-        const float ex0 = g2.x - c.qxlo, ey0 = g2.y - c.qylo;
-        const uint32_t cull = __float_as_uint(g3.w);
-        const float rx = __half2float(__ushort_as_half((unsigned short)(cull & 0xffffu)));
-        const float ry = __half2float(__ushort_as_half((unsigned short)(cull >> 16)));
-        unsigned long long xm[8], ym[8], xany = 0, yany = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            xm[k] = __builtin_amdgcn_ballot_w64(valid && fabsf((float)k - ex0) <= rx);
-            ym[k] = __builtin_amdgcn_ballot_w64(valid && fabsf((float)k - ey0) <= ry);
-            xany |= xm[k];
-            yany |= ym[k];
-        }
-        const unsigned long long hitmask = xany & yany;
-        if ((hitmask >> lane) & 1ull) {
-            // rebase to the quadrant origin: C' = C + (q0.x - ox)*A + (q0.y - oy)*B with o = rint(centre); centre -= q0
-            const float ux = c.qxlo - rintf(g2.x), uy = c.qylo - rintf(g2.y);
-            const float Cx = fmaf(uy, g0.z, fmaf(ux, g0.x, g1.x));
-            const float Cy = fmaf(uy, g0.w, fmaf(ux, g0.y, g1.y));
-            const float Cz = fmaf(uy, g1.w, fmaf(ux, g1.z, g2.z));
-            const int slot = newb + lane;
-            planes[0][slot] = g0;
-            planes[1][slot] = make_float4(Cx, Cy, g1.z, g1.w);
-            planes[2][slot] = make_float4(ex0, ey0, Cz, g2.w);
-            planes[3][slot] = make_float4(g3.x, g3.y, g3.z, g3.w);
-            if (FULL) {
-                planes[4][slot] = g4;
-                *reinterpret_cast<f2 *>(&planes[5][slot]) = g5;
-            }
-        }
-        {   // issue the next chunk's loads (ids arrived during the previous iteration) and the ids after that
-            const uint32_t idn = id_next;
-            const uint32_t e2 = base + 128 + lane < send ? base + 128 + lane : c.safe;
-            id_next = c.point_list[e2];
-            const float4 *r = c.rec4 + (size_t)idn * 6;
-            g0 = r[0]; g1 = r[1]; g2 = r[2]; g3 = r[3];
-            if (FULL) { g4 = r[4]; g5 = *reinterpret_cast<const f2 *>(r + 5); }
-        }
-        ++stat_chunks;
-        if (flags & 2) continue;  // flag 2: staging only (measurement aid, not in the public header)
-        // ---- lanes = pixels: my own survivor list = entries whose box covers MY column and MY row ---------------
-        unsigned long long mx = xm[0], my = ym[0];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) {
-            mx = ((colsel[k] >> lane) & 1ull) ? xm[k] : mx;
-            my = ((rowsel[k] >> lane) & 1ull) ? ym[k] : my;
-        }
+        const int slot = (int)(i % kItemChunks);
+        while (lds_load(&ring.stamp[slot]) != i + 1) __builtin_amdgcn_s_sleep(1);
+        GA_LDS_ORDER();
+        const unsigned long long mx = ring.masks[slot][c.col], my = ring.masks[slot][16 + c.row];
         nxt = done ? 0ull : (mx & my);
         if (flags & GA_SURFEL_FLAG_STATS) {
             unsigned pc = __builtin_popcountll(nxt);
             for (int o = 32; o > 0; o >>= 1) pc += __shfl_xor(pc, o, 64);
-            stat_useful += pc;
+            st.useful += pc;
         }
-        trips(oldb, newb);   // until every lane has finished the previous chunk
+        ++st.chunks;
+        trips((int)((i + kItemChunks - 1) % kItemChunks) * 64, slot * 64);   // until every lane has finished the previous chunk
         cur = nxt;           // what is left of this chunk becomes the "previous chunk" of the next step
         nxt = 0;
+        if (wraps) {         // chunks < i are finished: their slots may be reused
+            GA_LDS_ORDER();
+            if (c.lane == 0) lds_store(&ring.done[c.quad], i);
+        }
     }
-    trips(64 - (step & 1) * 64, 0);  // drain: `cur` is the last staged chunk (buffer of step-1), `nxt` is empty
+    trips((int)((i + kItemChunks - 1) % kItemChunks) * 64, 0);  // drain: `cur` is the last fetched chunk, `nxt` is empty
+    if (wraps) {
+        GA_LDS_ORDER();
+        if (c.lane == 0) lds_store(&ring.done[c.quad], kGone);
+    }
 }
 
 __device__ __forceinline__ void write_pixel(const PixelAcc &a, const float *__restrict__ bg, const Dims &dm, int v, int pxi,
@@ -310,138 +389,172 @@ __device__ __forceinline__ void write_pixel(const PixelAcc &a, const float *__re
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Blend kernel.  The serial per-pixel chain of the longest lists was the critical path of the whole rasterizer (PMC:
-// ~1 resident wave per SIMD, VALU 20 % busy), so lists are handled in two shapes:
-//   * short list (< kLongList pairs): one workgroup per 16x16 tile, each wave blends one 8x8 quadrant over the whole list;
-//   * long list: one workgroup per 8x8 QUADRANT whose four waves take contiguous quarters of the list (SEGMENTS):
-//       pass 1  every wave multiplies (1 - alpha) over the contributing pairs of its segment -> seg_T[w][pixel];
-//               P_w = prod_{j<w} seg_T[j] is the transmittance the sequential algorithm has on entering segment w;
-//       pass 2  every wave runs the UNCHANGED sequential blend over its segment starting from T = P_w: weights, the
-//               `T > 0.5` median test and the `T (1-alpha) < 1e-4` stop rule therefore see the global transmittance;
-//       merge   wave 0 adds the segments in order; the depth-distortion prefix sums M1, M2 are segment-local, their
-//               cross terms  M2_before * W_k - 2 M1_before * M1_k  (W_k = the segment's summed weights = P_k - T_end,k)
-//               are added here; a segment after one that hit the stop rule contributes nothing, exactly as the
-//               sequential loop would have left it.
-//     The only numerical difference to the sequential order is the rounding of P_w (a product of segment products).
-// The tile scan leaves the long tiles at the front of tile_order and their number in status[GA_STATUS_LONG_TILES]; the
-// grid is [4 x long tiles rounded up to 8 | remaining tiles], sized on the host from the capacity bound.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void surfel_blend_kernel(const uint4 *__restrict__ tile_order,
-                                                               const uint32_t *__restrict__ point_list,
-                                                               const float *__restrict__ record,
-                                                               const float *__restrict__ bg, Dims dm, int ntiles,
-                                                               float *__restrict__ out_color,
-                                                               float *__restrict__ out_others,
-                                                               int64_t *__restrict__ status, int flags)
+// Grid: [ segment region: capacity / 256 workgroups | one workgroup per (view, tile) ].  Workgroups of the segment region
+// take a ticket (status[GA_STATUS_SEG_TICKET]) and leave when the region is beyond status[GA_STATUS_SEG_WORK]; the
+// segmented tiles are the first status[GA_STATUS_LONG_TILES] slots of tile_order, which the tile region skips.
+#ifndef GA_BLEND_WAVES
+#define GA_BLEND_WAVES 4
+#endif
+__global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WAVES, GA_BLEND_WAVES))) void surfel_blend_kernel(const uint4 *__restrict__ tile_order,
+                                                           const uint32_t *__restrict__ point_list,
+                                                           const float *__restrict__ record,
+                                                           const float *__restrict__ bg, Dims dm, int ntiles,
+                                                           uint32_t seg_region, uint32_t nseg_cap,
+                                                           const uint32_t *__restrict__ seg_table,
+                                                           uint32_t *__restrict__ seg_sync,
+                                                           float *__restrict__ seg_scratch,
+                                                           float *__restrict__ out_color,
+                                                           float *__restrict__ out_others,
+                                                           int64_t *__restrict__ status, int flags)
 {
-    __shared__ __attribute__((aligned(16))) float4 stage[4][6][128];  // wave-private record planes, 24 KiB; after pass 2
-                                                                      // the same 6 KiB hold the wave's segment results
-    __shared__ float seg_T[4][64];                                    // pass-1 transmittance of each segment
-    const int64_t overflow = status[GA_STATUS_OVERFLOW], nlong64 = status[GA_STATUS_LONG_TILES];  // one latency
+    __shared__ Ring ring;
+    const int64_t overflow = status[GA_STATUS_OVERFLOW], nlong64 = status[GA_STATUS_LONG_TILES];
+    const int64_t segwork64 = status[GA_STATUS_SEG_WORK];
     if (overflow) return;
-    const uint32_t nlong = (uint32_t)nlong64, nlong8 = (nlong + 7u) & ~7u;
+    const uint32_t nlong = (uint32_t)nlong64, segwork = (uint32_t)segwork64;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t pos, quad;
-    bool split;
-    if (blockIdx.x < 4 * nlong8) {
-        // blocks b, b+8, b+16, b+24 (same XCD under round-robin dispatch) are the four quadrants of one long tile
-        const uint32_t grp = blockIdx.x >> 5, xcd = blockIdx.x & 7;
-        quad = (blockIdx.x >> 3) & 3;
-        pos = grp * 8 + xcd;
-        if (pos >= nlong) return;
-        split = true;
+
+    uint32_t pos, seg = 0, nsegs = 1, work = 0;
+    if (blockIdx.x < seg_region) {
+        if (blockIdx.x >= segwork) return;   // every workgroup sees the same bound: whole workgroups leave
+        if (threadIdx.x == 0)
+            ring.work = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_SEG_TICKET), 1ull);
     } else {
-        pos = nlong + (blockIdx.x - 4 * nlong8);
+        pos = nlong + (blockIdx.x - seg_region);
         if (pos >= (uint32_t)ntiles) return;
-        quad = (uint32_t)wave;
-        split = false;
+    }
+    if (threadIdx.x < kItemChunks) ring.stamp[threadIdx.x] = 0;
+    if (threadIdx.x < 4) ring.done[threadIdx.x] = 0;
+    __syncthreads();
+    if (blockIdx.x < seg_region) {
+        work = ring.work;
+        // length class of the work item: classes are laid out longest first, seg_table[b] = (first slot, first work item)
+        // (non-increasing in b; class b owns [first(b), first(b - 1)); classes above the longest populated one start at 0)
+        int b = kSegClass;
+        while (b < 32 && seg_table[2 * b + 1] > work) ++b;
+        nsegs = seg_count(b);
+        const uint32_t rel = work - seg_table[2 * b + 1];
+        pos = seg_table[2 * b] + rel / nsegs;
+        seg = rel % nsegs;
     }
     const uint4 sched = tile_order[pos];  // longest lists first: (tile, list begin, list length)
     const uint32_t vt = sched.x;
     const int v = (int)(vt / (uint32_t)dm.tiles), tile = (int)(vt - (uint32_t)v * dm.tiles);
     const int tx = tile % dm.gx, ty = tile / dm.gx;
-    const int qx0 = tx * kTile + (int)(quad & 1) * 8, qy0 = ty * kTile + (int)(quad >> 1) * 8;
-    if (qx0 >= dm.W || qy0 >= dm.H) return;  // uniform per wave (short) or per workgroup (long): barriers stay safe
-    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
-    const bool inside = pxi < dm.W && pyi < dm.H;
+    const uint32_t beg = sched.y, n = sched.z;
+    // my segment: chunks [seg * chunks / nsegs, (seg + 1) * chunks / nsegs) (at most kItemChunks of them when segmented)
+    const uint32_t chunks = (n + 63) / 64;
+    const uint32_t c0 = (uint32_t)((uint64_t)seg * chunks / nsegs), c1 = (uint32_t)((uint64_t)(seg + 1) * chunks / nsegs);
+    const uint32_t sbeg = beg + c0 * 64, send = min(beg + n, beg + c1 * 64), nch = c1 - c0;
+    const bool last_seg = seg + 1 == nsegs;
+    const float4 *rec4 = reinterpret_cast<const float4 *>(record) + (size_t)v * dm.N * (kRec / 4);
+    const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
 
-    const uint32_t beg = sched.y, end = sched.y + sched.z;
-    const size_t vbase = (size_t)v * dm.N;
-    WaveCtx c;
-    c.lane = lane; c.dxy = f2{(float)(lane & 7), (float)(lane >> 3)}; c.qxlo = (float)qx0; c.qylo = (float)qy0;
-    c.safe = beg; c.point_list = point_list;
-    c.rec4 = reinterpret_cast<const float4 *>(record) + vbase * (kRec / 4);
-    c.planes = stage[wave];
-    unsigned stat_iters = 0, stat_chunks = 0, stat_useful = 0;
+    if (wave == 4) {
+        produce(ring, lane, sbeg, send, point_list, rec4, tx0, ty0);
+        return;
+    }
+    // my share of the staging: chunk `wave` (the others wait for it, so even a quadrant outside the image does it)
+    if ((uint32_t)wave < nch) stage_one(ring, lane, (uint32_t)wave, sbeg, send, point_list, rec4, tx0, ty0);
+
+    Consumer c;
+    c.lane = lane; c.quad = wave;
+    c.col = (wave & 1) * 8 + (lane & 7); c.row = (wave >> 1) * 8 + (lane >> 3);
+    c.dxy = f2{(float)c.col, (float)c.row};
+    const int pxi = tx * kTile + c.col, pyi = ty * kTile + c.row;
+    const bool inside = pxi < dm.W && pyi < dm.H;
+    Stats st{};
     PixelAcc a = fresh_pixel(1.0f);
     bool done = !inside;
+    if (tx * kTile + (wave & 1) * 8 >= dm.W || ty * kTile + (wave >> 1) * 8 >= dm.H) {  // quadrant outside the image
+        if (lane == 0) lds_store(&ring.done[wave], kGone);
+        return;
+    }
 
-    if (!split) {
-        walk_list<true>(c, beg, end, a, done, stat_iters, stat_chunks, flags, stat_useful);
+    if (nsegs == 1) {
+        consume<true>(ring, c, nch, a, done, st, flags);
         if (inside) write_pixel(a, bg, dm, v, pxi, pyi, out_color, out_others);
     } else {
-        constexpr int kSeg = 4;
-        const uint32_t n = end - beg, chunks = (n + 63) / 64, cps = (chunks + kSeg - 1) / kSeg;
-        const uint32_t sbeg = min(end, beg + (uint32_t)wave * cps * 64), send = min(end, sbeg + cps * 64);
-        {   // pass 1: transmittance of my segment
+        const uint32_t work0 = work - seg;                      // work item of segment 0 of this tile
+        const int px = wave * 64 + lane;                        // pixel index inside the scratch records
+        uint32_t *flag = seg_sync + 4 * (size_t)work0 + wave;   // + 4 * segment
+        uint32_t *arrive = seg_sync + 4 * (size_t)nseg_cap + 4 * (size_t)pos + wave;
+        float *mine = seg_scratch + (size_t)work * kSegFloats;
+        if (!last_seg) {   // pass 1: transmittance of my segment (nobody needs that of the last one)
             bool d1 = !inside;
-            walk_list<false>(c, sbeg, send, a, d1, stat_iters, stat_chunks, flags, stat_useful);
+            consume<false>(ring, c, nch, a, d1, st, flags);
+            xwg_store(mine + px, a.T);
+            xwg_stores_done();
+            if (lane == 0) __hip_atomic_store(flag + 4 * seg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        seg_T[wave][lane] = a.T;
-        __syncthreads();
+        // transmittance on entering my segment: product over the lower segments (they started before me: tickets).
+        // lanes = segments for the flags: one load looks at 64 of them
+        for (uint32_t k0 = 0; k0 < seg; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            for (;;) {
+                const uint32_t f = k < seg ? __hip_atomic_load(flag + 4 * (size_t)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+                if (__builtin_amdgcn_ballot_w64(f == 0u) == 0) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
         float P = 1.0f;
-        for (int k = 0; k < wave; ++k) P *= seg_T[k][lane];
+        for (uint32_t k = 0; k < seg; ++k) P *= xwg_load(seg_scratch + (size_t)(work0 + k) * kSegFloats + px);
         // pass 2: the sequential blend of my segment, entered with the global transmittance
         a = fresh_pixel(P);
         done = done || P < 0.0001f;  // T never falls below 1e-4 in the sequential loop: it stopped before this segment
-        a.median = -1.0f;  // depths are >= near > 0: a negative median means "not set inside this segment"
-        walk_list<true>(c, sbeg, send, a, done, stat_iters, stat_chunks, flags, stat_useful);
-        float *o = reinterpret_cast<float *>(stage[wave]) + lane;
-        o[0 * 64] = a.N2C0.y; o[1 * 64] = a.C12.x; o[2 * 64] = a.C12.y; o[3 * 64] = a.N01.x; o[4 * 64] = a.N01.y;
-        o[5 * 64] = a.N2C0.x; o[6 * 64] = a.Dp; o[7 * 64] = a.M.x; o[8 * 64] = a.M.y; o[9 * 64] = a.dist;
-        o[10 * 64] = a.median;
-        o[11 * 64] = a.T; o[12 * 64] = done ? 1.0f : 0.0f; o[13 * 64] = P;
-        __syncthreads();
-        if (wave == 0 && inside) {
+        a.median = -1.0f;            // depths are >= near > 0: a negative median means "not set inside this segment"
+        consume<true>(ring, c, nch, a, done, st, flags);
+        float *o = mine + 256 + px;
+        const float part[14] = {a.N2C0.y, a.C12.x, a.C12.y, a.N01.x, a.N01.y, a.N2C0.x, a.Dp, a.M.x, a.M.y, a.dist,
+                                a.median, a.T, done ? 1.0f : 0.0f, P};
+#pragma unroll
+        for (int f = 0; f < 14; ++f) xwg_store(o + f * 256, part[f]);
+        xwg_stores_done();
+        uint32_t arrived = 0;
+        if (lane == 0) arrived = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        arrived = __builtin_amdgcn_readfirstlane(arrived);
+        if (arrived == nsegs - 1) {   // the last segment to finish this quadrant adds the partial sums in list order
             PixelAcc r = fresh_pixel(1.0f);
             bool dead = false;
+            for (uint32_t k = 0; k < nsegs; ++k) {
+                const float *q = seg_scratch + (size_t)(work0 + k) * kSegFloats + 256 + px;
+                float tt[14];
 #pragma unroll
-            for (int k = 0; k < kSeg; ++k) {
-                const float *q = reinterpret_cast<const float *>(stage[k]) + lane;
+                for (int f = 0; f < 14; ++f) tt[f] = xwg_load(q + f * 256);
                 if (!dead) {
-                    const float Wk = q[13 * 64] - q[11 * 64];
-                    r.N2C0.y += q[0 * 64]; r.C12.x += q[1 * 64]; r.C12.y += q[2 * 64];
-                    r.N01.x += q[3 * 64]; r.N01.y += q[4 * 64]; r.N2C0.x += q[5 * 64];
-                    r.Dp += q[6 * 64];
-                    r.dist += q[9 * 64] + r.M.y * Wk - 2.0f * r.M.x * q[7 * 64];
-                    r.M.x += q[7 * 64];
-                    r.M.y += q[8 * 64];
-                    if (q[10 * 64] >= 0.0f) r.median = q[10 * 64];
-                    r.T = q[11 * 64];
-                    dead = q[12 * 64] != 0.0f;
+                    const float Wk = tt[13] - tt[11];
+                    r.N2C0.y += tt[0]; r.C12.x += tt[1]; r.C12.y += tt[2];
+                    r.N01.x += tt[3]; r.N01.y += tt[4]; r.N2C0.x += tt[5];
+                    r.Dp += tt[6];
+                    r.dist += tt[9] + r.M.y * Wk - 2.0f * r.M.x * tt[7];
+                    r.M.x += tt[7];
+                    r.M.y += tt[8];
+                    if (tt[10] >= 0.0f) r.median = tt[10];
+                    r.T = tt[11];
+                    dead = tt[12] != 0.0f;
                 }
             }
-            write_pixel(r, bg, dm, v, pxi, pyi, out_color, out_others);
+            if (inside) write_pixel(r, bg, dm, v, pxi, pyi, out_color, out_others);
         }
     }
     if ((flags & GA_SURFEL_FLAG_STATS) && lane == 0) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_ITERS), (unsigned long long)stat_iters);
-        atomicMax(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_MAX_ITERS), (unsigned long long)stat_iters);
-        atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_LANE_SLOTS), (unsigned long long)stat_useful);
-        atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_CHUNKS), (unsigned long long)stat_chunks);
+        atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_ITERS), (unsigned long long)st.iters);
+        atomicMax(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_MAX_ITERS), (unsigned long long)st.iters);
+        atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_LANE_SLOTS), (unsigned long long)st.useful);
+        atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_CHUNKS), (unsigned long long)st.chunks);
     }
 }
-
 
 void launch_blend(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &ws, hipStream_t s)
 {
     const int nt = d.V * d.tiles;
-    // long tiles hold >= long_list() pairs each, so there are at most capacity / long_list() of them
-    const int64_t max_long = std::min<int64_t>(nt, a.capacity / long_list());
-    const unsigned grid = (unsigned)(4 * ((max_long + 7) / 8 * 8) + nt);
-    hipLaunchKernelGGL(surfel_blend_kernel, dim3(grid), dim3(256), 0, s,
-                       ws.tile_order, ws.point_list, ws.record, a.bg, d, nt, a.out_color, a.out_others, ws.status,
-                       a.flags);
+    // a segmented tile of class b holds >= 2^(b-1) entries and takes seg_count(b) = 2^(b-9) = 2^(b-1) / 256 work items
+    const uint32_t nseg_cap = (uint32_t)(a.capacity / 256 + 1);
+    const uint32_t seg_region = (uint32_t)(a.capacity / 256);
+    hipLaunchKernelGGL(surfel_blend_kernel, dim3(seg_region + (unsigned)nt), dim3(320), 0, s,
+                       ws.tile_order, ws.point_list, ws.record, a.bg, d, nt, seg_region, nseg_cap, ws.seg_table,
+                       ws.seg_sync, ws.seg_scratch, a.out_color, a.out_others, ws.status, a.flags);
 }
 
 }  // namespace ga

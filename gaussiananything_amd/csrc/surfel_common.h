@@ -35,8 +35,17 @@ constexpr int kBinSplats = GA_BIN_SPLATS;           // splats per thread in the 
 #endif
 constexpr int kPreSplats = GA_PRE_SPLATS;  // splats per thread in the preprocess kernel
 constexpr int kLdsTiles = 8192;         // per-view tile counters aggregated in LDS up to this many tiles (32 KiB)
-constexpr int kLongList = 1024;          // lists of >= this many pairs (a power of two) are blended four segments at a time
-int long_list();                         // kLongList, or 2^GA_LONG_LOG2 from the environment (tuning aid)
+// Segmented blend: lists of >= kLongList entries (length class >= kSegClass; class b holds 2^(b-1) <= n < 2^b) are cut into
+// seg_count(b) segments of 256..512 entries, each blended by its own workgroup; a segment (<= kItemChunks chunks of 64)
+// stays resident in LDS for both of its passes, a shorter unsegmented list streams through the same LDS as a ring.
+constexpr int kItemChunks = 8;
+constexpr int kLongList = 1024;
+#ifndef GA_SEG_CLASS
+#define GA_SEG_CLASS 11
+#endif
+constexpr int kSegClass = GA_SEG_CLASS;
+__host__ __device__ constexpr uint32_t seg_count(int b) { return b < kSegClass ? 1u : (1u << (b - 9)); }
+constexpr int kSegFloats = 15 * 256;     // scratch floats per segment: transmittance + 14 partial sums for 256 pixels
 constexpr int kSortCap = GA_SURFEL_SORT_RUN;         // per-tile entries sorted in one LDS pass (16 KiB of u64 keys: 8+ workgroups per CU)
 
 struct Dims {
@@ -45,6 +54,9 @@ struct Dims {
 
 struct Workspace {
     int64_t *status;
+    uint32_t *seg_sync;   // [4 * nseg_cap] pass-1 flags per (segment, quadrant), then [4 * ntile_cap] arrival counters
+    uint32_t *seg_table;  // [2 * 40] per class b: (first tile_order slot, first segment work item)
+    float *seg_scratch;
     uint32_t *tile_count, *tile_start, *tile_cursor;
     uint4 *tile_order;   // schedule of the per-tile kernels, longest lists first: (tile, list begin, list length, 0)
     uint4 *run_table;    // runs 1.. of the lists longer than one sort run: (tile, run, list begin, list length)

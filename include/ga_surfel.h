@@ -42,8 +42,10 @@ extern "C" {
 #define GA_STATUS_BLEND_ITERS 4   /* with GA_SURFEL_FLAG_STATS: total inner-loop iterations of the blend (all waves) */
 #define GA_STATUS_BLEND_MAX_ITERS 5 /* with GA_SURFEL_FLAG_STATS: most iterations executed by one wave              */
 #define GA_STATUS_BLEND_CHUNKS 6  /* with GA_SURFEL_FLAG_STATS: total 64-entry chunks consumed                          */
-#define GA_STATUS_LONG_TILES 7    /* tiles whose list is blended in segments (internal)                                */
+#define GA_STATUS_LONG_TILES 7    /* tiles whose list is blended in segments (internal): they lead tile_order          */
 #define GA_STATUS_BLEND_LANE_SLOTS 8 /* with GA_SURFEL_FLAG_STATS: (pixel, pair) evaluations that had work (of 64 x BLEND_ITERS) */
+#define GA_STATUS_SEG_WORK 9      /* (tile, segment) work items of the segmented tiles (internal)                      */
+#define GA_STATUS_SEG_TICKET 10   /* next segment work item to hand out (internal)                                     */
 #define GA_STATUS_WORDS 16
 
 typedef struct GaSurfelForwardArgs {
@@ -81,6 +83,8 @@ typedef struct GaSurfelForwardArgs {
  * (rect, tile ranges, sorted point list) straight out of the workspace through these offsets. */
 typedef struct GaSurfelWorkspaceLayout {
     size_t status;      /* int64[GA_STATUS_WORDS]                                                  */
+    size_t seg_sync;    /* uint32[4*(capacity/256+1) + 4*(capacity/1024+1)] per (segment, quadrant) flags and per (tile,
+                           quadrant) arrival counters of the segmented blend; cleared with the status words */
     size_t tile_count;  /* uint32[V*tiles]   entries per (view, tile)                             */
     size_t tile_start;  /* uint32[V*tiles+1] exclusive scan of tile_count                         */
     size_t tile_cursor; /* uint32[V*tiles]   scratch of the fill pass                             */
@@ -91,6 +95,8 @@ typedef struct GaSurfelWorkspaceLayout {
     size_t record;      /* float[V*N*GA_SURFEL_RECORD_FLOATS] blend-ready splat records           */
     size_t keys;        /* uint64[capacity]  (depth bits << 32 | gaussian index), binned per tile */
     size_t point_list;  /* uint32[capacity]  gaussian indices, per tile in (depth, index) order   */
+    size_t seg_table;   /* uint32[2*40]      per length class: first tile_order slot, first segment work item */
+    size_t seg_scratch; /* float[(capacity/256+1) * 15 * 256] per segment: transmittance + 14 partial sums per pixel */
     size_t total_bytes;
 } GaSurfelWorkspaceLayout;
 

@@ -14,6 +14,7 @@ typedef struct {
     double waves;          /* waves that did anything */
     double max_wave_cost;  /* instruction-model cost of the most expensive wave */
     double total_cost;
+    double coupled_cost;   /* sum over work items of 4 x the most expensive quadrant (quadrants in lock step) */
 } SimOut;
 
 #define MAXCH 512
@@ -134,6 +135,7 @@ void blend_sim(int H, int W_img, int ntiles_x, int ntiles_y, const uint32_t *ran
                     }
                 }
                 const int passes = segs > 1 ? 2 : 1;   /* segmented lists are walked twice (transmittance pre-pass) */
+                double tile_max_w = 0, tile_max_i = 0;
                 for (int w = 0; w < 4; ++w) {
                     long chunks = 0;
                     const long tr = sim_window((const uint16_t (*)[MAXCH])cnt[w], lastc[w], nch, window, kU, &chunks);
@@ -143,9 +145,12 @@ void blend_sim(int H, int W_img, int ntiles_x, int ntiles_y, const uint32_t *ran
                     const double ci = passes * (chunks * c_stage + ti * (c_trip + kU * c_entry));
                     win->trips += passes * tr; win->slots += passes * tr * kU * 64.0; win->chunks += passes * chunks; win->waves += 1;
                     win->total_cost += cw; if (cw > win->max_wave_cost) win->max_wave_cost = cw;
+                    if (cw > tile_max_w) tile_max_w = cw;
+                    if (ci > tile_max_i) tile_max_i = ci;
                     ideal->trips += passes * ti; ideal->slots += passes * ti * kU * 64.0; ideal->chunks += passes * chunks; ideal->waves += 1;
                     ideal->total_cost += ci; if (ci > ideal->max_wave_cost) ideal->max_wave_cost = ci;
                 }
+                win->coupled_cost += 4 * tile_max_w; ideal->coupled_cost += 4 * tile_max_i;
                 win->pairs += passes * pairs; ideal->pairs += passes * pairs;
             }
         }

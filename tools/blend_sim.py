@@ -13,7 +13,7 @@ from tests import _util  # noqa: E402
 
 
 class SimOut(ctypes.Structure):
-    _fields_ = [(k, ctypes.c_double) for k in ("pairs", "slots", "trips", "chunks", "waves", "max_wave_cost", "total_cost")]
+    _fields_ = [(k, ctypes.c_double) for k in ("pairs", "slots", "trips", "chunks", "waves", "max_wave_cost", "total_cost", "coupled_cost")]
 
 
 def cull_extents(o, c2_rel=1.02, c2_abs=0.05, e_rel=1.01, e_abs=0.5):
@@ -96,7 +96,7 @@ def main():
         sc = 8.0 / nviews
         print(f"{name:70s} util {acc['pairs'] / acc['slots']:.3f} (ideal {acci['pairs'] / acci['slots']:.3f})  "
               f"pairs {acc['pairs'] * sc / 1e6:6.2f}M  slots/64 {acc['slots'] * sc / 64e6:6.3f}M  chunks {acc['chunks'] * sc / 1e3:6.1f}K  "
-              f"cost {acc['total_cost'] * sc / 1e6:6.1f}M (ideal {acci['total_cost'] * sc / 1e6:6.1f}M)  max wave {acc['max_wave_cost'] / 1e3:6.1f}K")
+              f"cost {acc['total_cost'] * sc / 1e6:6.1f}M (ideal {acci['total_cost'] * sc / 1e6:6.1f}M)  max wave {acc['max_wave_cost'] / 1e3:6.1f}K  quadrants in lock step {acc['coupled_cost'] * sc / 1e6:6.1f}M")
 
 
 if __name__ == "__main__":
