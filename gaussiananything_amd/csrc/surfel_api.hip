@@ -39,7 +39,7 @@ int ga_surfel_workspace_layout(int32_t num_points, int32_t num_views, int32_t im
     const size_t nv = (size_t)d.N * d.V, nt = (size_t)d.V * d.tiles, cap = (size_t)capacity;
     size_t off = 0;
     out->status = off;      off += align256(GA_STATUS_WORDS * sizeof(int64_t));
-    out->seg_sync = off;    off += align256((4 * (cap / 256 + 1) + 4 * (cap / 1024 + 1)) * 4);
+    out->seg_sync = off;    off += align256(4 * (cap / 1024 + 1) * 4);
     out->tile_count = off;  off += align256(nt * 4);
     out->tile_start = off;  off += align256((nt + 1) * 4);
     out->tile_cursor = off; off += align256(nt * 4);
@@ -51,7 +51,7 @@ int ga_surfel_workspace_layout(int32_t num_points, int32_t num_views, int32_t im
     out->keys = off;        off += align256(cap * 8);
     out->point_list = off;  off += align256(cap * 4);
     out->seg_table = off;   off += align256(2 * 40 * 4);
-    out->seg_scratch = off; off += align256((cap / 256 + 1) * (size_t)ga::kSegFloats * 4);
+    out->seg_scratch = off; off += align256((cap / 256 + 1) * (size_t)ga::kSegFloats * 8);
     out->total_bytes = off;
     return GA_OK;
 }
@@ -77,7 +77,7 @@ int ga_surfel_forward(const GaSurfelForwardArgs *a, void *stream_v)
     ws.status = reinterpret_cast<int64_t *>(w + L.status);
     ws.seg_sync = reinterpret_cast<uint32_t *>(w + L.seg_sync);
     ws.seg_table = reinterpret_cast<uint32_t *>(w + L.seg_table);
-    ws.seg_scratch = reinterpret_cast<float *>(w + L.seg_scratch);
+    ws.seg_scratch = reinterpret_cast<unsigned long long *>(w + L.seg_scratch);
     ws.tile_count = reinterpret_cast<uint32_t *>(w + L.tile_count);
     ws.tile_start = reinterpret_cast<uint32_t *>(w + L.tile_start);
     ws.tile_cursor = reinterpret_cast<uint32_t *>(w + L.tile_cursor);

@@ -39,6 +39,8 @@
 // v_rcp_f32 / v_exp_f32 instead of IEEE division and libm expf.
 #include <hip/hip_fp16.h>
 
+#include <atomic>
+
 #include "surfel_common.h"
 
 namespace ga {
@@ -91,11 +93,24 @@ __device__ __forceinline__ void lds_store(uint32_t *p, uint32_t v)
 }
 // Cross-workgroup exchange of the segmented blend.  The L2 of an XCD is not coherent with the other seven, and an
 // agent-scope release / acquire FENCE is a write-back / invalidate of that whole L2 (measured: 0.7 ms per launch for
-// 1 340 segments).  So the exchanged words themselves are written and read with agent-scope accesses (sc1: they bypass the
-// L2), and ordering is "my stores have been acknowledged (vmcnt = 0), then the flag".
-__device__ __forceinline__ void xwg_store(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float xwg_load(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void xwg_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+// 1 340 segments), while plain agent-scope stores to different addresses are not ordered with respect to each other on
+// their way to memory.  So every exchanged value is SELF-VALIDATING: one 64-bit agent-scope store (sc1: bypasses the L2)
+// of (value, epoch of this launch), which the reader polls until the epoch matches -- no fence, no flag, no ordering
+// assumption.  The epoch is a per-launch number from the host, so words left by earlier launches never match.
+__device__ __forceinline__ void xwg_store(unsigned long long *p, float v, uint32_t epoch)
+{
+    __hip_atomic_store(p, ((unsigned long long)epoch << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float xwg_load(const unsigned long long *p, uint32_t epoch)
+{
+    unsigned long long w;
+    for (;;) {
+        w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__builtin_amdgcn_ballot_w64((uint32_t)(w >> 32) != epoch) == 0) break;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return __uint_as_float((uint32_t)w);
+}
 
 // compiler fence: LDS operations of one wave reach the LDS in program order, so ordering data and flag accesses in the
 // instruction stream is all the protocol needs
@@ -188,15 +203,13 @@ __device__ __forceinline__ void stage_chunk(Ring &ring, int lane, uint32_t k, co
     const float rx = valid ? __half2float(__ushort_as_half((unsigned short)(cull & 0xffffu))) : -1.0f;
     const float ry = __half2float(__ushort_as_half((unsigned short)(cull >> 16)));
     // the 32 masks leave through lanes 0..31: lane c takes column mask c, lane 16 + c row mask c
-    uint32_t mlo = 0, mhi = 0;
+    unsigned long long m = 0;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         const unsigned long long xm = __builtin_amdgcn_ballot_w64(fabsf((float)c - ex0) <= rx);
         const unsigned long long ym = __builtin_amdgcn_ballot_w64(fabsf((float)c - ey0) <= ry);
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(mlo) : "s"((uint32_t)xm), "n"(c));
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(mhi) : "s"((uint32_t)(xm >> 32)), "n"(c));
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(mlo) : "s"((uint32_t)ym), "n"(16 + c));
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(mhi) : "s"((uint32_t)(ym >> 32)), "n"(16 + c));
+        m = lane == c ? xm : m;
+        m = lane == 16 + c ? ym : m;
     }
     // rebase to the tile origin: C' = C + (t0.x - ox)*A + (t0.y - oy)*B with o = rint(centre); centre -= t0
     const float ux = tx0 - rintf(g.g2.x), uy = ty0 - rintf(g.g2.y);
@@ -207,7 +220,7 @@ __device__ __forceinline__ void stage_chunk(Ring &ring, int lane, uint32_t k, co
     ring.planes[3][j] = g.g3;
     ring.planes[4][j] = g.g4;
     ring.plane5[j] = g.g5;
-    if (lane < 32) ring.masks[slot][lane] = ((unsigned long long)mhi << 32) | mlo;
+    if (lane < 32) ring.masks[slot][lane] = m;
     GA_LDS_ORDER();
     if (lane == 0) lds_store(&ring.stamp[slot], k + 1);
     GA_LDS_ORDER();
@@ -399,10 +412,10 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
                                                            const uint32_t *__restrict__ point_list,
                                                            const float *__restrict__ record,
                                                            const float *__restrict__ bg, Dims dm, int ntiles,
-                                                           uint32_t seg_region, uint32_t nseg_cap,
+                                                           uint32_t seg_region,
                                                            const uint32_t *__restrict__ seg_table,
                                                            uint32_t *__restrict__ seg_sync,
-                                                           float *__restrict__ seg_scratch,
+                                                           unsigned long long *__restrict__ seg_scratch, uint32_t epoch,
                                                            float *__restrict__ out_color,
                                                            float *__restrict__ out_others,
                                                            int64_t *__restrict__ status, int flags)
@@ -478,39 +491,26 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
     } else {
         const uint32_t work0 = work - seg;                      // work item of segment 0 of this tile
         const int px = wave * 64 + lane;                        // pixel index inside the scratch records
-        uint32_t *flag = seg_sync + 4 * (size_t)work0 + wave;   // + 4 * segment
-        uint32_t *arrive = seg_sync + 4 * (size_t)nseg_cap + 4 * (size_t)pos + wave;
-        float *mine = seg_scratch + (size_t)work * kSegFloats;
+        uint32_t *arrive = seg_sync + 4 * (size_t)pos + wave;
+        unsigned long long *mine = seg_scratch + (size_t)work * kSegFloats;
         if (!last_seg) {   // pass 1: transmittance of my segment (nobody needs that of the last one)
             bool d1 = !inside;
             consume<false>(ring, c, nch, a, d1, st, flags);
-            xwg_store(mine + px, a.T);
-            xwg_stores_done();
-            if (lane == 0) __hip_atomic_store(flag + 4 * seg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            xwg_store(mine + px, a.T, epoch);
         }
-        // transmittance on entering my segment: product over the lower segments (they started before me: tickets).
-        // lanes = segments for the flags: one load looks at 64 of them
-        for (uint32_t k0 = 0; k0 < seg; k0 += 64) {
-            const uint32_t k = k0 + lane;
-            for (;;) {
-                const uint32_t f = k < seg ? __hip_atomic_load(flag + 4 * (size_t)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
-                if (__builtin_amdgcn_ballot_w64(f == 0u) == 0) break;
-                __builtin_amdgcn_s_sleep(4);
-            }
-        }
+        // transmittance on entering my segment: product over the lower segments (they started before me: tickets)
         float P = 1.0f;
-        for (uint32_t k = 0; k < seg; ++k) P *= xwg_load(seg_scratch + (size_t)(work0 + k) * kSegFloats + px);
+        for (uint32_t k = 0; k < seg; ++k) P *= xwg_load(seg_scratch + (size_t)(work0 + k) * kSegFloats + px, epoch);
         // pass 2: the sequential blend of my segment, entered with the global transmittance
         a = fresh_pixel(P);
         done = done || P < 0.0001f;  // T never falls below 1e-4 in the sequential loop: it stopped before this segment
         a.median = -1.0f;            // depths are >= near > 0: a negative median means "not set inside this segment"
         consume<true>(ring, c, nch, a, done, st, flags);
-        float *o = mine + 256 + px;
+        unsigned long long *o = mine + 256 + px;
         const float part[14] = {a.N2C0.y, a.C12.x, a.C12.y, a.N01.x, a.N01.y, a.N2C0.x, a.Dp, a.M.x, a.M.y, a.dist,
                                 a.median, a.T, done ? 1.0f : 0.0f, P};
 #pragma unroll
-        for (int f = 0; f < 14; ++f) xwg_store(o + f * 256, part[f]);
-        xwg_stores_done();
+        for (int f = 0; f < 14; ++f) xwg_store(o + f * 256, part[f], epoch);
         uint32_t arrived = 0;
         if (lane == 0) arrived = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         arrived = __builtin_amdgcn_readfirstlane(arrived);
@@ -518,10 +518,10 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
             PixelAcc r = fresh_pixel(1.0f);
             bool dead = false;
             for (uint32_t k = 0; k < nsegs; ++k) {
-                const float *q = seg_scratch + (size_t)(work0 + k) * kSegFloats + 256 + px;
+                const unsigned long long *q = seg_scratch + (size_t)(work0 + k) * kSegFloats + 256 + px;
                 float tt[14];
 #pragma unroll
-                for (int f = 0; f < 14; ++f) tt[f] = xwg_load(q + f * 256);
+                for (int f = 0; f < 14; ++f) tt[f] = xwg_load(q + f * 256, epoch);
                 if (!dead) {
                     const float Wk = tt[13] - tt[11];
                     r.N2C0.y += tt[0]; r.C12.x += tt[1]; r.C12.y += tt[2];
@@ -550,11 +550,13 @@ void launch_blend(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &
 {
     const int nt = d.V * d.tiles;
     // a segmented tile of class b holds >= 2^(b-1) entries and takes seg_count(b) = 2^(b-9) = 2^(b-1) / 256 work items
-    const uint32_t nseg_cap = (uint32_t)(a.capacity / 256 + 1);
     const uint32_t seg_region = (uint32_t)(a.capacity / 256);
+    static std::atomic<uint32_t> launches{0};
+    uint32_t epoch = ++launches;
+    if (epoch == 0) epoch = ++launches;   // 0 is what a fresh workspace may hold
     hipLaunchKernelGGL(surfel_blend_kernel, dim3(seg_region + (unsigned)nt), dim3(320), 0, s,
-                       ws.tile_order, ws.point_list, ws.record, a.bg, d, nt, seg_region, nseg_cap, ws.seg_table,
-                       ws.seg_sync, ws.seg_scratch, a.out_color, a.out_others, ws.status, a.flags);
+                       ws.tile_order, ws.point_list, ws.record, a.bg, d, nt, seg_region, ws.seg_table,
+                       ws.seg_sync, ws.seg_scratch, epoch, a.out_color, a.out_others, ws.status, a.flags);
 }
 
 }  // namespace ga

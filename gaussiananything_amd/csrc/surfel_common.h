@@ -45,7 +45,7 @@ constexpr int kLongList = 1024;
 #endif
 constexpr int kSegClass = GA_SEG_CLASS;
 __host__ __device__ constexpr uint32_t seg_count(int b) { return b < kSegClass ? 1u : (1u << (b - 9)); }
-constexpr int kSegFloats = 15 * 256;     // scratch floats per segment: transmittance + 14 partial sums for 256 pixels
+constexpr int kSegFloats = 15 * 256;     // scratch words per segment: transmittance + 14 partial sums for 256 pixels
 constexpr int kSortCap = GA_SURFEL_SORT_RUN;         // per-tile entries sorted in one LDS pass (16 KiB of u64 keys: 8+ workgroups per CU)
 
 struct Dims {
@@ -54,9 +54,9 @@ struct Dims {
 
 struct Workspace {
     int64_t *status;
-    uint32_t *seg_sync;   // [4 * nseg_cap] pass-1 flags per (segment, quadrant), then [4 * ntile_cap] arrival counters
+    uint32_t *seg_sync;   // [4 * ntile_cap] arrival counters per (segmented tile, quadrant)
     uint32_t *seg_table;  // [2 * 40] per class b: (first tile_order slot, first segment work item)
-    float *seg_scratch;
+    unsigned long long *seg_scratch;   // (value, launch epoch) words, see surfel_blend.hip
     uint32_t *tile_count, *tile_start, *tile_cursor;
     uint4 *tile_order;   // schedule of the per-tile kernels, longest lists first: (tile, list begin, list length, 0)
     uint4 *run_table;    // runs 1.. of the lists longer than one sort run: (tile, run, list begin, list length)

@@ -83,8 +83,8 @@ typedef struct GaSurfelForwardArgs {
  * (rect, tile ranges, sorted point list) straight out of the workspace through these offsets. */
 typedef struct GaSurfelWorkspaceLayout {
     size_t status;      /* int64[GA_STATUS_WORDS]                                                  */
-    size_t seg_sync;    /* uint32[4*(capacity/256+1) + 4*(capacity/1024+1)] per (segment, quadrant) flags and per (tile,
-                           quadrant) arrival counters of the segmented blend; cleared with the status words */
+    size_t seg_sync;    /* uint32[4*(capacity/1024+1)] per (segmented tile, quadrant) arrival counters of the segmented
+                           blend; cleared with the status words */
     size_t tile_count;  /* uint32[V*tiles]   entries per (view, tile)                             */
     size_t tile_start;  /* uint32[V*tiles+1] exclusive scan of tile_count                         */
     size_t tile_cursor; /* uint32[V*tiles]   scratch of the fill pass                             */
@@ -96,7 +96,8 @@ typedef struct GaSurfelWorkspaceLayout {
     size_t keys;        /* uint64[capacity]  (depth bits << 32 | gaussian index), binned per tile */
     size_t point_list;  /* uint32[capacity]  gaussian indices, per tile in (depth, index) order   */
     size_t seg_table;   /* uint32[2*40]      per length class: first tile_order slot, first segment work item */
-    size_t seg_scratch; /* float[(capacity/256+1) * 15 * 256] per segment: transmittance + 14 partial sums per pixel */
+    size_t seg_scratch; /* uint64[(capacity/256+1) * 15 * 256] per segment: transmittance + 14 partial sums per pixel,
+                           each word (value, launch epoch) */
     size_t total_bytes;
 } GaSurfelWorkspaceLayout;
 
