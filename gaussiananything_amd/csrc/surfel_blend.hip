@@ -226,60 +226,67 @@ __device__ __forceinline__ void stage_chunk(Ring &ring, int lane, uint32_t k, co
     GA_LDS_ORDER();
 }
 
-constexpr uint32_t kHelpChunks = 4;   // chunks 0..3 of an item are staged by the four consumer waves, one each
+// Staging duty: chunk k of an item is staged by wave k % 4.  The first kItemChunks chunks (two per wave) are staged before
+// the walk starts -- for a segment and for most tiles that is everything.  In a longer unsegmented list wave w stages chunk
+// i + 4 when it reaches its own chunk i (i % 4 == w), into the slot of chunk i - 4, once every wave has finished that one;
+// its records were requested one duty earlier (ids two duties earlier).
+struct Duty {
+    uint32_t next, sbeg, send;   // my next chunk to stage; the list range
+    uint32_t id1, id2;           // list entries of chunk `next` (arrived) and `next + 4` (in flight)
+    ChunkRegs g;                 // records of chunk `next` (in flight)
+    const uint32_t *__restrict__ point_list;
+    const float4 *__restrict__ rec4;
+    float tx0, ty0;
+};
 
-// a consumer wave's share of the staging: chunk `k` of [sbeg, send), dependent loads (ids, then records) and all
-__device__ __forceinline__ void stage_one(Ring &ring, int lane, uint32_t k, uint32_t sbeg, uint32_t send,
-                                          const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec4,
-                                          float tx0, float ty0)
+__device__ __forceinline__ uint32_t duty_entry(const Duty &d, uint32_t k, int lane)
 {
-    const uint32_t e = sbeg + k * 64 + lane;
-    const bool valid = e < send;
-    const ChunkRegs g = load_chunk(rec4, point_list[valid ? e : sbeg]);
-    stage_chunk(ring, lane, k, g, valid, tx0, ty0);
+    const uint32_t e = d.sbeg + k * 64 + lane;   // (clamped: out-of-range lanes re-read a valid entry)
+    return e < d.send ? e : d.sbeg;
 }
 
-// PRODUCER wave: chunks kHelpChunks.. of [sbeg, send), loads one chunk ahead (ids two ahead).  Up to kItemChunks chunks
-// stay resident; beyond that (an unsegmented list of 513..1023 entries) a chunk's slot is reused once every consumer has
-// finished the chunk kItemChunks before it.
-__device__ __forceinline__ void produce(Ring &ring, int lane, uint32_t sbeg, uint32_t send,
-                                        const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec4,
-                                        float tx0, float ty0)
+// stage chunks `quad` and `quad + 4`, then (longer lists) start the pipeline for `quad + 8`
+__device__ __forceinline__ void duty_prologue(Ring &ring, Duty &d, int lane, int quad, uint32_t nch)
 {
-    const uint32_t nch = (send - sbeg + 63) / 64;
-    if (nch <= kHelpChunks) return;
-    auto entry = [&](uint32_t k) {   // list position of this lane's entry in chunk k (clamped: out-of-range lanes re-read a valid one)
-        const uint32_t e = sbeg + k * 64 + lane;
-        return e < send ? e : sbeg;
-    };
-    uint32_t id_next;
-    ChunkRegs g;
-    {
-        const uint32_t id0 = point_list[entry(kHelpChunks)];
-        id_next = point_list[entry(kHelpChunks + 1)];
-        g = load_chunk(rec4, id0);
+    const uint32_t k0 = (uint32_t)quad, k1 = (uint32_t)quad + 4;
+    if (k0 >= nch) { d.next = nch; return; }
+    const uint32_t ida = d.point_list[duty_entry(d, k0, lane)];
+    const uint32_t idb = d.point_list[duty_entry(d, k1 < nch ? k1 : k0, lane)];
+    const ChunkRegs ga = load_chunk(d.rec4, ida);
+    ChunkRegs gb = ga;
+    if (k1 < nch) gb = load_chunk(d.rec4, idb);
+    d.next = k1 + 4;
+    if (d.next < nch) {   // wrapping list: ids of my next two duties
+        d.id1 = d.point_list[duty_entry(d, d.next, lane)];
+        d.id2 = d.point_list[duty_entry(d, d.next + 4 < nch ? d.next + 4 : d.next, lane)];
     }
-    for (uint32_t k = kHelpChunks; k < nch; ++k) {
-        const ChunkRegs cur = g;
-        const bool valid = sbeg + k * 64 + lane < send;
-        {   // issue the next chunk's loads (its ids arrived during the previous iteration) and the ids after that
-            const uint32_t idn = id_next;
-            id_next = point_list[entry(k + 2)];
-            g = load_chunk(rec4, idn);
-        }
-        if (k >= (uint32_t)kItemChunks) {   // wrap: wait until every consumer has finished chunk k - kItemChunks
-            for (;;) {
-                const uint32_t d0 = lds_load(&ring.done[0]), d1 = lds_load(&ring.done[1]);
-                const uint32_t d2 = lds_load(&ring.done[2]), d3 = lds_load(&ring.done[3]);
-                const uint32_t dmin = min(min(d0, d1), min(d2, d3));
-                if (dmin == kGone) return;
-                if (dmin + kItemChunks > k) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            GA_LDS_ORDER();
-        }
-        stage_chunk(ring, lane, k, cur, valid, tx0, ty0);
+    stage_chunk(ring, lane, k0, ga, d.sbeg + k0 * 64 + lane < d.send, d.tx0, d.ty0);
+    if (k1 < nch) stage_chunk(ring, lane, k1, gb, d.sbeg + k1 * 64 + lane < d.send, d.tx0, d.ty0);
+    if (d.next < nch) d.g = load_chunk(d.rec4, d.id1);
+}
+
+// stage chunk d.next (its slot held chunk d.next - kItemChunks: every wave must have finished that one) and move the
+// pipeline on.  Returns false when nobody is left to read it.
+__device__ __forceinline__ bool duty_stage(Ring &ring, Duty &d, int lane, uint32_t nch)
+{
+    const uint32_t k = d.next;
+    for (;;) {
+        const uint32_t d0 = lds_load(&ring.done[0]), d1 = lds_load(&ring.done[1]);
+        const uint32_t d2 = lds_load(&ring.done[2]), d3 = lds_load(&ring.done[3]);
+        const uint32_t dmin = min(min(d0, d1), min(d2, d3));
+        if (dmin == kGone) return false;
+        if (dmin + kItemChunks > k) break;
+        __builtin_amdgcn_s_sleep(2);
     }
+    GA_LDS_ORDER();
+    stage_chunk(ring, lane, k, d.g, d.sbeg + k * 64 + lane < d.send, d.tx0, d.ty0);
+    d.next = k + 4;
+    if (d.next < nch) {
+        d.id1 = d.id2;
+        d.g = load_chunk(d.rec4, d.id1);
+        d.id2 = d.point_list[duty_entry(d, d.next + 4 < nch ? d.next + 4 : d.next, lane)];
+    }
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -296,8 +303,9 @@ struct Consumer {
 #define GA_BLEND_KU 4
 #endif
 
-template <bool FULL>
-__device__ __forceinline__ void consume(Ring &ring, const Consumer &c, uint32_t nch, PixelAcc &a, bool &done, Stats &st, int flags)
+template <bool FULL, bool WRAP>
+__device__ __forceinline__ void consume(Ring &ring, const Consumer &c, uint32_t nch, PixelAcc &a, bool &done, Stats &st, int flags,
+                                        Duty &duty)
 {
     // Per-lane survivor masks of a TWO-chunk window: `cur` = what is left of the previous chunk, `nxt` = the chunk fetched
     // in this step.  A lane that has finished `cur` runs ahead into `nxt` while slower lanes still work on `cur`; the step
@@ -353,10 +361,10 @@ __device__ __forceinline__ void consume(Ring &ring, const Consumer &c, uint32_t 
         }
     };
 
-    const bool wraps = nch > (uint32_t)kItemChunks;
     uint32_t i = 0;
     for (; i < nch; ++i) {
         if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+        if (WRAP && duty.next == i + 4 && duty.next < nch) duty_stage(ring, duty, c.lane, nch);
         const int slot = (int)(i % kItemChunks);
         while (lds_load(&ring.stamp[slot]) != i + 1) __builtin_amdgcn_s_sleep(1);
         GA_LDS_ORDER();
@@ -371,15 +379,17 @@ __device__ __forceinline__ void consume(Ring &ring, const Consumer &c, uint32_t 
         trips((int)((i + kItemChunks - 1) % kItemChunks) * 64, slot * 64);   // until every lane has finished the previous chunk
         cur = nxt;           // what is left of this chunk becomes the "previous chunk" of the next step
         nxt = 0;
-        if (wraps) {         // chunks < i are finished: their slots may be reused
+        if (WRAP) {          // chunks < i are finished: their slots may be reused
             GA_LDS_ORDER();
             if (c.lane == 0) lds_store(&ring.done[c.quad], i);
         }
     }
     trips((int)((i + kItemChunks - 1) % kItemChunks) * 64, 0);  // drain: `cur` is the last fetched chunk, `nxt` is empty
-    if (wraps) {
+    if (WRAP) {
         GA_LDS_ORDER();
         if (c.lane == 0) lds_store(&ring.done[c.quad], kGone);
+        GA_LDS_ORDER();
+        while (duty.next < nch && duty_stage(ring, duty, c.lane, nch)) {}   // the others may still need my chunks
     }
 }
 
@@ -402,55 +412,33 @@ __device__ __forceinline__ void write_pixel(const PixelAcc &a, const float *__re
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Grid: [ segment region: capacity / 256 workgroups | one workgroup per (view, tile) ].  Workgroups of the segment region
-// take a ticket (status[GA_STATUS_SEG_TICKET]) and leave when the region is beyond status[GA_STATUS_SEG_WORK]; the
-// segmented tiles are the first status[GA_STATUS_LONG_TILES] slots of tile_order, which the tile region skips.
-#ifndef GA_BLEND_WAVES
-#define GA_BLEND_WAVES 4
-#endif
-__global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WAVES, GA_BLEND_WAVES))) void surfel_blend_kernel(const uint4 *__restrict__ tile_order,
-                                                           const uint32_t *__restrict__ point_list,
-                                                           const float *__restrict__ record,
-                                                           const float *__restrict__ bg, Dims dm, int ntiles,
-                                                           uint32_t seg_region,
-                                                           const uint32_t *__restrict__ seg_table,
-                                                           uint32_t *__restrict__ seg_sync,
-                                                           unsigned long long *__restrict__ seg_scratch, uint32_t epoch,
-                                                           float *__restrict__ out_color,
-                                                           float *__restrict__ out_others,
-                                                           int64_t *__restrict__ status, int flags)
-{
-    __shared__ Ring ring;
-    const int64_t overflow = status[GA_STATUS_OVERFLOW], nlong64 = status[GA_STATUS_LONG_TILES];
-    const int64_t segwork64 = status[GA_STATUS_SEG_WORK];
-    if (overflow) return;
-    const uint32_t nlong = (uint32_t)nlong64, segwork = (uint32_t)segwork64;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// One work item: tile_order slot `pos`, segment `seg` of `nsegs` (work item number `work` when segmented).
+struct BlendArgs {
+    const uint4 *__restrict__ tile_order;
+    const uint32_t *__restrict__ point_list;
+    const float *__restrict__ record;
+    const float *__restrict__ bg;
+    uint32_t *__restrict__ seg_sync;
+    unsigned long long *__restrict__ seg_scratch;
+    float *__restrict__ out_color;
+    float *__restrict__ out_others;
+    uint32_t epoch;
+    int flags;
+};
 
-    uint32_t pos, seg = 0, nsegs = 1, work = 0;
-    if (blockIdx.x < seg_region) {
-        if (blockIdx.x >= segwork) return;   // every workgroup sees the same bound: whole workgroups leave
-        if (threadIdx.x == 0)
-            ring.work = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_SEG_TICKET), 1ull);
-    } else {
-        pos = nlong + (blockIdx.x - seg_region);
-        if (pos >= (uint32_t)ntiles) return;
-    }
-    if (threadIdx.x < kItemChunks) ring.stamp[threadIdx.x] = 0;
-    if (threadIdx.x < 4) ring.done[threadIdx.x] = 0;
-    __syncthreads();
-    if (blockIdx.x < seg_region) {
-        work = ring.work;
-        // length class of the work item: classes are laid out longest first, seg_table[b] = (first slot, first work item)
-        // (non-increasing in b; class b owns [first(b), first(b - 1)); classes above the longest populated one start at 0)
-        int b = kSegClass;
-        while (b < 32 && seg_table[2 * b + 1] > work) ++b;
-        nsegs = seg_count(b);
-        const uint32_t rel = work - seg_table[2 * b + 1];
-        pos = seg_table[2 * b] + rel / nsegs;
-        seg = rel % nsegs;
-    }
+__device__ __forceinline__ void blend_item(Ring &ring, const BlendArgs &k, const Dims &dm, int lane, int wave, uint32_t pos,
+                                           uint32_t seg, uint32_t nsegs, uint32_t work, Stats &st)
+{
+    const uint4 *__restrict__ tile_order = k.tile_order;
+    const uint32_t *__restrict__ point_list = k.point_list;
+    const float *__restrict__ record = k.record;
+    const float *__restrict__ bg = k.bg;
+    uint32_t *__restrict__ seg_sync = k.seg_sync;
+    unsigned long long *__restrict__ seg_scratch = k.seg_scratch;
+    float *__restrict__ out_color = k.out_color;
+    float *__restrict__ out_others = k.out_others;
+    const uint32_t epoch = k.epoch;
+    const int flags = k.flags;
     const uint4 sched = tile_order[pos];  // longest lists first: (tile, list begin, list length)
     const uint32_t vt = sched.x;
     const int v = (int)(vt / (uint32_t)dm.tiles), tile = (int)(vt - (uint32_t)v * dm.tiles);
@@ -464,29 +452,36 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
     const float4 *rec4 = reinterpret_cast<const float4 *>(record) + (size_t)v * dm.N * (kRec / 4);
     const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
 
-    if (wave == 4) {
-        produce(ring, lane, sbeg, send, point_list, rec4, tx0, ty0);
-        return;
-    }
-    // my share of the staging: chunk `wave` (the others wait for it, so even a quadrant outside the image does it)
-    if ((uint32_t)wave < nch) stage_one(ring, lane, (uint32_t)wave, sbeg, send, point_list, rec4, tx0, ty0);
+    // my share of the staging (the others wait for it, so even a quadrant outside the image does it)
+    Duty duty;
+    duty.sbeg = sbeg; duty.send = send; duty.point_list = point_list; duty.rec4 = rec4; duty.tx0 = tx0; duty.ty0 = ty0;
+    duty_prologue(ring, duty, lane, wave, nch);
+    const bool wraps = nch > (uint32_t)kItemChunks;   // only unsegmented lists
 
+#ifdef GA_BLEND_STAMPS
+    if (nch) {
+        while (lds_load(&ring.stamp[0]) != 1) __builtin_amdgcn_s_sleep(1);
+        if (lane == 0) k.seg_scratch[(size_t)GA_BLEND_STAMPS + ((size_t)blockIdx.x * 4 + wave) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     Consumer c;
     c.lane = lane; c.quad = wave;
     c.col = (wave & 1) * 8 + (lane & 7); c.row = (wave >> 1) * 8 + (lane >> 3);
     c.dxy = f2{(float)c.col, (float)c.row};
     const int pxi = tx * kTile + c.col, pyi = ty * kTile + c.row;
     const bool inside = pxi < dm.W && pyi < dm.H;
-    Stats st{};
     PixelAcc a = fresh_pixel(1.0f);
     bool done = !inside;
     if (tx * kTile + (wave & 1) * 8 >= dm.W || ty * kTile + (wave >> 1) * 8 >= dm.H) {  // quadrant outside the image
         if (lane == 0) lds_store(&ring.done[wave], kGone);
+        GA_LDS_ORDER();
+        while (wraps && duty.next < nch && duty_stage(ring, duty, lane, nch)) {}
         return;
     }
 
     if (nsegs == 1) {
-        consume<true>(ring, c, nch, a, done, st, flags);
+        if (wraps) consume<true, true>(ring, c, nch, a, done, st, flags, duty);
+        else consume<true, false>(ring, c, nch, a, done, st, flags, duty);
         if (inside) write_pixel(a, bg, dm, v, pxi, pyi, out_color, out_others);
     } else {
         const uint32_t work0 = work - seg;                      // work item of segment 0 of this tile
@@ -495,7 +490,7 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
         unsigned long long *mine = seg_scratch + (size_t)work * kSegFloats;
         if (!last_seg) {   // pass 1: transmittance of my segment (nobody needs that of the last one)
             bool d1 = !inside;
-            consume<false>(ring, c, nch, a, d1, st, flags);
+            consume<false, false>(ring, c, nch, a, d1, st, flags, duty);
             xwg_store(mine + px, a.T, epoch);
         }
         // transmittance on entering my segment: product over the lower segments (they started before me: tickets)
@@ -505,7 +500,7 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
         a = fresh_pixel(P);
         done = done || P < 0.0001f;  // T never falls below 1e-4 in the sequential loop: it stopped before this segment
         a.median = -1.0f;            // depths are >= near > 0: a negative median means "not set inside this segment"
-        consume<true>(ring, c, nch, a, done, st, flags);
+        consume<true, false>(ring, c, nch, a, done, st, flags, duty);
         unsigned long long *o = mine + 256 + px;
         const float part[14] = {a.N2C0.y, a.C12.x, a.C12.y, a.N01.x, a.N01.y, a.N2C0.x, a.Dp, a.M.x, a.M.y, a.dist,
                                 a.median, a.T, done ? 1.0f : 0.0f, P};
@@ -538,7 +533,69 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
             if (inside) write_pixel(r, bg, dm, v, pxi, pyi, out_color, out_others);
         }
     }
-    if ((flags & GA_SURFEL_FLAG_STATS) && lane == 0) {
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Grid: [ segment region | one workgroup per (view, tile) ].  The kSegWGs workgroups of the segment region take tickets
+// (status[GA_STATUS_SEG_TICKET]) until the status[GA_STATUS_SEG_WORK] segment work items are handed out (the host does not
+// know their number; a region sized for the worst case, capacity / 256 workgroups that mostly find nothing to do, cost
+// 20 % of the launch); the segmented tiles are the first status[GA_STATUS_LONG_TILES] slots of tile_order, which the
+// tile region skips.
+#ifndef GA_BLEND_WAVES
+#define GA_BLEND_WAVES 3
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WAVES, GA_BLEND_WAVES))) void surfel_blend_kernel(BlendArgs k, Dims dm, int ntiles,
+                                                           uint32_t seg_region,
+                                                           const uint32_t *__restrict__ seg_table,
+                                                           int64_t *__restrict__ status)
+{
+    __shared__ Ring ring;
+    const int64_t overflow = status[GA_STATUS_OVERFLOW], nlong64 = status[GA_STATUS_LONG_TILES];
+    const int64_t segwork64 = status[GA_STATUS_SEG_WORK];
+    if (overflow) return;
+    const uint32_t nlong = (uint32_t)nlong64, segwork = (uint32_t)segwork64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    Stats st{};
+#ifdef GA_BLEND_STAMPS
+    // measurement build: (entry, exit) wall-clock stamps and hardware id per wave, in the upper half of the segment scratch
+    unsigned long long *stamps = k.seg_scratch + (size_t)GA_BLEND_STAMPS + ((size_t)blockIdx.x * 4 + wave) * 4;
+    const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
+    struct StampExit {
+        unsigned long long *p, t0; int lane;
+        __device__ ~StampExit() {
+            if (lane == 0) { p[0] = t0; p[1] = __builtin_amdgcn_s_memrealtime(); p[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
+        }
+    } stamp_exit{stamps, t_entry, lane};
+#endif
+    if (blockIdx.x < seg_region) {
+        if (blockIdx.x >= segwork) return;   // more workgroups than work items: whole workgroups leave
+        for (;;) {
+            if (threadIdx.x == 0)
+                ring.work = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_SEG_TICKET), 1ull);
+            if (threadIdx.x < kItemChunks) ring.stamp[threadIdx.x] = 0;
+            if (threadIdx.x < 4) ring.done[threadIdx.x] = 0;
+            __syncthreads();
+            const uint32_t work = ring.work;
+            if (work >= segwork) break;
+            // length class of the work item: classes are laid out longest first, seg_table[b] = (first slot, first work
+            // item) (non-increasing in b; class b owns [first(b), first(b - 1)); classes above the longest populated one
+            // start at 0)
+            int b = kSegClass;
+            while (b < 32 && seg_table[2 * b + 1] > work) ++b;
+            const uint32_t nsegs = seg_count(b), rel = work - seg_table[2 * b + 1];
+            blend_item(ring, k, dm, lane, wave, seg_table[2 * b] + rel / nsegs, rel % nsegs, nsegs, work, st);
+            __syncthreads();   // everybody has left the item: the LDS image and the ticket word may be overwritten
+        }
+    } else {
+        const uint32_t pos = nlong + (blockIdx.x - seg_region);
+        if (pos >= (uint32_t)ntiles) return;
+        if (threadIdx.x < kItemChunks) ring.stamp[threadIdx.x] = 0;
+        if (threadIdx.x < 4) ring.done[threadIdx.x] = 0;
+        __syncthreads();
+        blend_item(ring, k, dm, lane, wave, pos, 0u, 1u, 0u, st);
+    }
+    if ((k.flags & GA_SURFEL_FLAG_STATS) && lane == 0) {
         atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_ITERS), (unsigned long long)st.iters);
         atomicMax(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_MAX_ITERS), (unsigned long long)st.iters);
         atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_LANE_SLOTS), (unsigned long long)st.useful);
@@ -550,13 +607,15 @@ void launch_blend(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &
 {
     const int nt = d.V * d.tiles;
     // a segmented tile of class b holds >= 2^(b-1) entries and takes seg_count(b) = 2^(b-9) = 2^(b-1) / 256 work items
-    const uint32_t seg_region = (uint32_t)(a.capacity / 256);
+    constexpr uint32_t kSegWGs = 256;   // one per CU: the other workgroup slots of a CU take tiles from the start
+    const uint32_t seg_region = (uint32_t)std::min<int64_t>(a.capacity / 256, kSegWGs);
     static std::atomic<uint32_t> launches{0};
     uint32_t epoch = ++launches;
     if (epoch == 0) epoch = ++launches;   // 0 is what a fresh workspace may hold
-    hipLaunchKernelGGL(surfel_blend_kernel, dim3(seg_region + (unsigned)nt), dim3(320), 0, s,
-                       ws.tile_order, ws.point_list, ws.record, a.bg, d, nt, seg_region, ws.seg_table,
-                       ws.seg_sync, ws.seg_scratch, epoch, a.out_color, a.out_others, ws.status, a.flags);
+    const BlendArgs k{ws.tile_order, ws.point_list, ws.record, a.bg, ws.seg_sync, ws.seg_scratch, a.out_color, a.out_others,
+                      epoch, a.flags};
+    hipLaunchKernelGGL(surfel_blend_kernel, dim3(seg_region + (unsigned)nt), dim3(256), 0, s, k, d, nt, seg_region,
+                       ws.seg_table, ws.status);
 }
 
 }  // namespace ga

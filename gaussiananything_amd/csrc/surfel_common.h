@@ -39,11 +39,11 @@ constexpr int kLdsTiles = 8192;         // per-view tile counters aggregated in 
 // seg_count(b) segments of 256..512 entries, each blended by its own workgroup; a segment (<= kItemChunks chunks of 64)
 // stays resident in LDS for both of its passes, a shorter unsegmented list streams through the same LDS as a ring.
 constexpr int kItemChunks = 8;
-constexpr int kLongList = 1024;
 #ifndef GA_SEG_CLASS
-#define GA_SEG_CLASS 11
+#define GA_SEG_CLASS 12
 #endif
 constexpr int kSegClass = GA_SEG_CLASS;
+constexpr int kLongList = 1 << (GA_SEG_CLASS - 1);
 __host__ __device__ constexpr uint32_t seg_count(int b) { return b < kSegClass ? 1u : (1u << (b - 9)); }
 constexpr int kSegFloats = 15 * 256;     // scratch words per segment: transmittance + 14 partial sums for 256 pixels
 constexpr int kSortCap = GA_SURFEL_SORT_RUN;         // per-tile entries sorted in one LDS pass (16 KiB of u64 keys: 8+ workgroups per CU)

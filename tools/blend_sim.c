@@ -56,6 +56,37 @@ static long sim_window(const uint16_t (*cnt)[MAXCH], const int *lanes_last_chunk
     return trips;
 }
 
+/* per-lane chunk pointers: a lane takes up to kU entries of ITS current chunk per trip and moves on to the next chunk
+ * (mask fetch) when that one is exhausted; it may be at most W - 1 chunks ahead of the slowest lane of the wave.
+ * skip = 1: empty chunks cost the lane nothing (it fetches masks until it finds a non-empty one within the window). */
+static long sim_pointer(const uint16_t (*cnt)[MAXCH], const int *lanes_last_chunk, int nch, int W, int kU, int skip)
+{
+    static uint16_t rem[64][MAXCH];
+    int pc[64], last = -1;
+    for (int l = 0; l < 64; ++l) if (lanes_last_chunk[l] > last) last = lanes_last_chunk[l];
+    if (last < 0) return 0;
+    for (int l = 0; l < 64; ++l) { memcpy(rem[l], cnt[l], sizeof(uint16_t) * (last + 1)); pc[l] = 0; }
+    long trips = 0;
+    for (;;) {
+        int tail = last + 1;
+        for (int l = 0; l < 64; ++l) {
+            while (pc[l] <= last && rem[l][pc[l]] == 0 && (skip || 1)) { if (!skip) break; ++pc[l]; }
+            if (pc[l] < tail) tail = pc[l];
+        }
+        if (!skip) { /* without skipping: a lane advances one chunk per trip when its chunk is empty */ }
+        if (tail > last) break;
+        ++trips;
+        for (int l = 0; l < 64; ++l) {
+            if (pc[l] > last) continue;
+            if (pc[l] >= tail + W) continue;               /* outside the window: idle */
+            if (rem[l][pc[l]] == 0) { ++pc[l]; continue; }  /* (only reached when skip = 0) */
+            const int t = rem[l][pc[l]] < kU ? rem[l][pc[l]] : kU;
+            rem[l][pc[l]] -= (uint16_t)t;
+        }
+    }
+    return trips;
+}
+
 /* ideal: every lane walks its own list back to back: trips = ceil(max lane total / kU) */
 static long sim_ideal(const uint16_t (*cnt)[MAXCH], int nch, int kU)
 {
@@ -138,7 +169,8 @@ void blend_sim(int H, int W_img, int ntiles_x, int ntiles_y, const uint32_t *ran
                 double tile_max_w = 0, tile_max_i = 0;
                 for (int w = 0; w < 4; ++w) {
                     long chunks = 0;
-                    const long tr = sim_window((const uint16_t (*)[MAXCH])cnt[w], lastc[w], nch, window, kU, &chunks);
+                    long tr = sim_window((const uint16_t (*)[MAXCH])cnt[w], lastc[w], nch, window > 0 ? window : 2, kU, &chunks);
+                    if (window < 0) tr = sim_pointer((const uint16_t (*)[MAXCH])cnt[w], lastc[w], nch, -window, kU, 1);
                     const long ti = sim_ideal((const uint16_t (*)[MAXCH])cnt[w], nch, kU);
                     if (chunks == 0) continue;
                     const double cw = passes * (chunks * c_stage + tr * (c_trip + kU * c_entry));
