@@ -8,21 +8,21 @@
 // about instructions and LDS bytes per useful (pixel, splat) pair:
 //   * WORK ITEM = one 16x16 tile, or one SEGMENT (256..512 list entries) of a tile whose list has >= 1024 entries; the
 //     16x16 granularity is part of the semantics (the tile rect decides which pixels a splat may touch).
-//   * WORKGROUP = 5 wavefronts: four CONSUMERS, one per 8x8 pixel quadrant, and one PRODUCER.
+//   * WORKGROUP = four wavefronts, one per 8x8 pixel quadrant; all four share ONE LDS image of the item's list.
 //   * STAGING (lanes = entries, 64 list entries = one chunk): gather the 96-byte records, test every entry's conservative
 //     {alpha >= 1/255} pixel box against the 16 pixel columns and 16 pixel rows of the tile (32 ballots), rebase the plane
 //     coefficients to the tile origin, leave records and masks in LDS.  Each record is fetched and prepared ONCE per tile
 //     (round 1 did it once per quadrant: 2.3x the algorithmic HBM/L2 traffic and four times the staging instructions) and
-//     once for BOTH passes of a segment.  The first four chunks of an item are staged by the four consumer waves in
-//     parallel (they would otherwise sit out the load latencies of the first chunk), the rest by the producer with its
-//     loads one chunk ahead (ids two ahead).  Up to kItemChunks chunks stay resident; a longer unsegmented list
-//     (513..1023 entries) wraps around.
+//     once for BOTH passes of a segment.  The duty rotates: chunk k is staged by wave k % 4; the first eight chunks (two
+//     per wave) before the walk starts -- for a segment and for most tiles that is everything -- and in a longer
+//     unsegmented list (513..2047 entries) chunk i + 4 when its wave reaches chunk i, with the loads requested one duty
+//     earlier.  (A dedicated fifth producer wave was built and measured first: 5-wave workgroups only fit twice per CU.)
 //   * Consumers run with LANES = PIXELS and per-lane survivor lists: a lane ANDs the mask of its column with the mask of
 //     its row and walks only those entries, kU per trip (the LDS gathers and alpha evaluations of a trip are
 //     independent, the composites follow in order).  A two-chunk window lets a lane that has finished the older chunk
 //     run ahead into the newer one.  The only synchronisation is one LDS word per chunk (DS operations of a wave execute
-//     in order, so stamp-after-data is enough): no workgroup barrier in the list walk, the quadrants are independent of
-//     each other, a saturated quadrant leaves.
+//     in order, so stamp-after-data is enough) plus, for wrapping lists, one progress word per wave: no workgroup barrier
+//     in the list walk; a saturated quadrant leaves once its staging duties are done.
 //   * SEGMENTS make the serial chain of a long list short (round 1: one workgroup, the hottest quadrant of the 5 127-entry
 //     list, spanned the whole launch).  Pass 1: every segment multiplies (1 - alpha) over its pairs and publishes the
 //     per-pixel product; pass 2: a segment enters the UNCHANGED sequential blend with the product of its predecessors, so
@@ -427,9 +427,8 @@ struct BlendArgs {
 };
 
 __device__ __forceinline__ void blend_item(Ring &ring, const BlendArgs &k, const Dims &dm, int lane, int wave, uint32_t pos,
-                                           uint32_t seg, uint32_t nsegs, uint32_t work, Stats &st)
+                                           const uint4 sched, uint32_t seg, uint32_t nsegs, uint32_t work, Stats &st)
 {
-    const uint4 *__restrict__ tile_order = k.tile_order;
     const uint32_t *__restrict__ point_list = k.point_list;
     const float *__restrict__ record = k.record;
     const float *__restrict__ bg = k.bg;
@@ -439,8 +438,7 @@ __device__ __forceinline__ void blend_item(Ring &ring, const BlendArgs &k, const
     float *__restrict__ out_others = k.out_others;
     const uint32_t epoch = k.epoch;
     const int flags = k.flags;
-    const uint4 sched = tile_order[pos];  // longest lists first: (tile, list begin, list length)
-    const uint32_t vt = sched.x;
+    const uint32_t vt = sched.x;          // schedule entry, longest lists first: (tile, list begin, list length)
     const int v = (int)(vt / (uint32_t)dm.tiles), tile = (int)(vt - (uint32_t)v * dm.tiles);
     const int tx = tile % dm.gx, ty = tile / dm.gx;
     const uint32_t beg = sched.y, n = sched.z;
@@ -550,6 +548,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
                                                            int64_t *__restrict__ status)
 {
     __shared__ Ring ring;
+    // (requested before the status words are looked at: on overflow the entry is stale but the slot exists)
+    const uint4 my_sched = k.tile_order[blockIdx.x >= seg_region ? blockIdx.x - seg_region : 0u];
     const int64_t overflow = status[GA_STATUS_OVERFLOW], nlong64 = status[GA_STATUS_LONG_TILES];
     const int64_t segwork64 = status[GA_STATUS_SEG_WORK];
     if (overflow) return;
@@ -584,16 +584,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
             int b = kSegClass;
             while (b < 32 && seg_table[2 * b + 1] > work) ++b;
             const uint32_t nsegs = seg_count(b), rel = work - seg_table[2 * b + 1];
-            blend_item(ring, k, dm, lane, wave, seg_table[2 * b] + rel / nsegs, rel % nsegs, nsegs, work, st);
+            const uint32_t pos = seg_table[2 * b] + rel / nsegs;
+            blend_item(ring, k, dm, lane, wave, pos, k.tile_order[pos], rel % nsegs, nsegs, work, st);
             __syncthreads();   // everybody has left the item: the LDS image and the ticket word may be overwritten
         }
     } else {
-        const uint32_t pos = nlong + (blockIdx.x - seg_region);
-        if (pos >= (uint32_t)ntiles) return;
+        // schedule slot = block index: no dependence on the status words (one load latency less before the first record
+        // arrives); the slots of the segmented tiles lead the schedule and belong to the segment region
+        const uint32_t pos = blockIdx.x - seg_region;
+        if (pos < nlong) return;
         if (threadIdx.x < kItemChunks) ring.stamp[threadIdx.x] = 0;
         if (threadIdx.x < 4) ring.done[threadIdx.x] = 0;
         __syncthreads();
-        blend_item(ring, k, dm, lane, wave, pos, 0u, 1u, 0u, st);
+        blend_item(ring, k, dm, lane, wave, pos, my_sched, 0u, 1u, 0u, st);
     }
     if ((k.flags & GA_SURFEL_FLAG_STATS) && lane == 0) {
         atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_ITERS), (unsigned long long)st.iters);
@@ -607,7 +610,7 @@ void launch_blend(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &
 {
     const int nt = d.V * d.tiles;
     // a segmented tile of class b holds >= 2^(b-1) entries and takes seg_count(b) = 2^(b-9) = 2^(b-1) / 256 work items
-    constexpr uint32_t kSegWGs = 256;   // one per CU: the other workgroup slots of a CU take tiles from the start
+    constexpr uint32_t kSegWGs = 512;   // two of the three workgroup slots of a CU; beyond that they loop
     const uint32_t seg_region = (uint32_t)std::min<int64_t>(a.capacity / 256, kSegWGs);
     static std::atomic<uint32_t> launches{0};
     uint32_t epoch = ++launches;

@@ -27,9 +27,9 @@ try:
     nt = 8 * 1024
     seg_region = min(cap // 256, 256)
     nwg = seg_region + nt
-    scr[OFF:OFF + nwg * 20].zero_()
+    scr[OFF:OFF + nwg * 16].zero_()
     plan.run(); torch.cuda.synchronize()
-    st = scr[OFF:OFF + nwg * 20].cpu().numpy().reshape(nwg, 5, 4)
+    st = scr[OFF:OFF + nwg * 16].cpu().numpy().reshape(nwg, 4, 4)
     order = ws.section("tile_order", torch.int32, nt * 4).cpu().numpy().reshape(nt, 4)
     status = ws.status().cpu().numpy()
     nlong = int(status[7])
@@ -39,7 +39,7 @@ try:
     print("kernel span %.1f us; waves stamped %d" % (ext[live].max(), live.sum()))
     # resident consumer waves over time
     grid = np.arange(0, ext[live].max() + 1, 2.0)
-    cons = live.copy(); cons[:, 4] = False
+    cons = live.copy(); pass
     occ = [(np.sum((ent[cons] <= t) & (ext[cons] > t))) for t in grid]
     busy = [(np.sum((rdy[cons] <= t) & (ext[cons] > t) & (st[..., 3][cons] > 0))) for t in grid]
     print("time us      :", " ".join("%5d" % t for t in grid[::5]))
@@ -57,7 +57,7 @@ try:
         if sel.sum():
             cw = ext[sel][:, :4] - ent[sel][:, :4]
             print("tiles with %4d..%4d entries: %5d WGs, WG lifetime mean %.1f us (max %.1f), consumer lifetime mean %.1f, first-chunk wait mean %.1f us, producer lifetime %.1f"
-                  % (lo, hi, sel.sum(), dur[sel].mean(), dur[sel].max(), cw.mean(), np.nanmean(start_lat[sel]) if np.isfinite(start_lat[sel]).any() else 0, (ext[sel][:, 4] - ent[sel][:, 4]).mean()))
+                  % (lo, hi, sel.sum(), dur[sel].mean(), dur[sel].max(), cw.mean(), np.nanmean(start_lat[sel]) if np.isfinite(start_lat[sel]).any() else 0, 0.0))
     segw = wg_live & (np.arange(nwg) < seg_region)
     if segw.sum():
         print("segment WGs: %d, lifetime mean %.1f max %.1f us" % (segw.sum(), dur[segw].mean(), dur[segw].max()))
