@@ -8,7 +8,13 @@ Multi-GPU (N>1, launched by torch.distributed.run): every rank renders its own i
 data-path collective); the rendered RGB-D-N images of the last step are collected on rank 0 with ONE RCCL gather
 inside the timed region ("final image collection").
 
+The timed region holds the K forwards (and, for N > 1, the gather) only; stage events, the parity check, the CPU baseline
+and the denoiser / cascade sections run afterwards, untimed.
+
 Also on the JSON line:
+  parity       -- the bench workload itself, HIP path vs oracle, every view (bit-identical bins, pixel MSE <= 1e-5).
+  sec_per_sample / cascade -- BASELINE configs[3]/[4]: one 250-step cascaded sample per GPU (stage-1 DiT-L, stage-2 DiT-L,
+                  surfel decode, renders), all ranks, one gather to rank 0; euler (249 NFE per stage) and, at N=1, dopri5.
   roofline     -- the dominant kernel (surfel_blend_kernel): algorithmic bytes (76*D + 40*P per view) over its
                   mean duration measured with HIP events on the launch stream during the timed steps; HBM peak 8 TB/s.
   cpu_baseline -- the CPU oracle (oracle/surfel_raster.c, kind "port": the reference has no CPU rasterizer) timed on
@@ -181,11 +187,9 @@ def bench_dit(dev, arch, nfe, warmup, parity_mode=False, samples=1):
             "sec_per_250_step_euler_stage": round(sec250, 4), "nfe_timed": nfe, **extra}
 
 
-def bench_cascade(dev, cams):
-    """BASELINE configs[3] end to end, one sample, as ONE measured wall-clock figure: stage-1 DiT-L and stage-2 DiT-L
-    (250-step Euler each, CFG batch 2) -> surfel decode -> renders of all four levels for 8 views
-    (gaussiananything_amd/cascade.py); conditioning tensors start on the device, random weights."""
-    from gaussiananything_amd import cascade
+def build_cascade_models(dev):
+    """The released cascade at full size with seeded random weights (no checkpoints here): DiT-L stage 1, DiT-L stage 2,
+    surfel decoder."""
     from gaussiananything_amd.decode import SurfelDecoder
     from gaussiananything_amd.dit import DiT_models
     torch.manual_seed(0)
@@ -207,19 +211,97 @@ def bench_cascade(dev, cams):
             elif p_.dim() >= 2:
                 p_.copy_(torch.randn(p_.shape, generator=g) * (0.5 / p_.shape[-1] ** 0.5))
     dec.to(dev)
-    cond = {"img_crossattn": torch.randn(1, 1369, 1024, generator=g).to(dev), "img_vector": torch.randn(1, 1024, generator=g).to(dev)}
-    uc = {k: torch.zeros_like(v) for k, v in cond.items()}
+    return models[0], models[1], dec
+
+
+def bench_cascade(dev, cams, rank, world, dist, dopri5=True):
+    """BASELINE configs[3] / [4]: one cascaded sample PER RANK (independent seeds and conditioning), as ONE measured
+    wall-clock figure from the conditioning tensors on the device to the rendered multi-view RGB-D-N collected on rank 0:
+    stage-1 DiT-L and stage-2 DiT-L (250 grid points each, CFG batch 2) -> surfel decode -> renders of all four levels for
+    8 views -> one gather of [V,9,512,512] per rank (gaussiananything_amd/distributed.py: cascade_per_rank).  Timed between
+    barriers, maximum over the ranks.  (i) fixed mode: euler, 249 function evaluations per stage; (ii) parity mode, rank
+    0 at N=1 only: the reference's own sampler settings (dopri5, rtol 1e-3, atol 1e-6), evaluations recorded."""
+    from gaussiananything_amd import distributed as gd
+    m1, m2, dec = build_cascade_models(dev)
     c = {"cam_view": cams["cam_view"][None].to(dev), "cam_view_proj": cams["cam_view_proj"][None].to(dev),
          "cam_pos": cams["cam_pos"][None].to(dev), "tanfov": cams["tanfov"]}
-    kw = dict(cameras=c, num_steps=250, sampling_method="euler", render_all_scale=True)
-    cascade.cascade(models[0], models[1], dec, cond, uc, **dict(kw, num_steps=5))   # warm-up: lazy init, workspaces
+
+    def cond_fn(i):
+        g = torch.Generator().manual_seed(1000 + i)
+        cond = {"img_crossattn": torch.randn(1, 1369, 1024, generator=g).to(dev), "img_vector": torch.randn(1, 1024, generator=g).to(dev)}
+        return cond, {k: torch.zeros_like(v) for k, v in cond.items()}
+
+    def run(method, steps, stats=None):
+        return gd.cascade_per_rank(m1, m2, dec, cond_fn, c, world, base_seed=42, num_steps=steps, sampling_method=method,
+                                   render_all_scale=True, **({"stats": stats} if stats is not None else {}))
+
+    run("euler", 5)   # warm-up: lazy initialisation, workspaces, graph capture paths
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = cascade.cascade(models[0], models[1], dec, cond, uc, **kw)
+    gathered, mine = run("euler", 250)
     torch.cuda.synchronize()
-    sec = time.perf_counter() - t0
-    return {"sec_per_sample": round(sec, 4), "stages": "DiT-L x 249 NFE, stage2 DiT-L x 249 NFE, decode -> 73728 surfels, "
-            "renders 8 views x {128,256,384,512}^2", "surfels": int(out["gaussians_upsampled_3"].shape[1])}
+    if dist is not None:
+        dist.barrier()
+    sec = gd.max_over_ranks(time.perf_counter() - t0, dev)
+    out = {"sec_per_sample": round(sec, 4), "samples": world, "samples_per_sec": round(world / sec, 4),
+           "mode": "euler, 250 grid points = 249 function evaluations per stage",
+           "stages": "DiT-L x 249 NFE, stage-2 DiT-L x 249 NFE (cond_key img-xyz: uc == c), decode -> 73728 surfels, renders 8 views x "
+                     "{128,256,384,512}^2, gather of [8,9,512,512] fp32 per rank to rank 0",
+           "gathered_shape": list(gathered.shape) if gathered is not None else None}
+    if dopri5 and world == 1:
+        stats = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        try:
+            run("dopri5", 250, stats)
+            torch.cuda.synchronize()
+            out["dopri5"] = {"sec_per_sample": round(time.perf_counter() - t0, 4), "rtol": 1e-3, "atol": 1e-6, "num_steps": 250,
+                             "nfe_stage1": stats.get("stage1", {}).get("nfe"), "nfe_stage2": stats.get("stage2", {}).get("nfe"),
+                             "rejected": [stats.get("stage1", {}).get("rejected"), stats.get("stage2", {}).get("rejected")],
+                             "note": "adaptive: the evaluation count depends on the (random) weights"}
+        except (FloatingPointError, RuntimeError) as e:   # a random-weight ODE may be too stiff for the step cap
+            out["dopri5"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return out
+
+
+def parity_check(g, cams, H, W, dev):
+    """Untimed: the bench workload itself through the HIP path against the C oracle, every view -- integer artefacts (radii,
+    tile rects, per-tile ranges, depth-ordered point lists) bit-identical, pixel MSE per output channel (bar 1e-5)."""
+    from gaussiananything_amd import synthetic
+    from gaussiananything_amd.diff_surfel_rasterization import rasterize_views
+    from oracle import surfel as osurf
+    m, o, s, r, c = synthetic.split_gaussians(g)
+    V = cams["cam_view"].shape[0]
+    color, radii, allmap, ws = rasterize_views(*[t.to(dev) for t in (m, o, c, s, r)], cams["cam_view"].to(dev),
+                                               cams["cam_view_proj"].to(dev), torch.ones(3, device=dev), H, W, 1.0)
+    torch.cuda.synchronize()
+    N = m.shape[0]
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    st = ws.status().cpu().numpy()
+    D = int(st[0])
+    tile_start = ws.section("tile_start", torch.int32, V * tiles + 1).cpu().numpy().astype(np.int64)
+    rect = ws.section("rect", torch.int16, V * N * 4).cpu().numpy().view(np.uint16).reshape(V, N, 4)
+    plist = ws.section("point_list", torch.int32, max(D, 1)).cpu().numpy()[:D]
+    color, radii, allmap = color.cpu().numpy(), radii.cpu().numpy(), allmap.cpu().numpy()
+    exact, worst, total = True, 0.0, 0
+    for v in range(V):
+        ov = osurf.rasterize(m.numpy(), o.numpy(), c.numpy(), s.numpy(), r.numpy(), cams["cam_view"][v].numpy(),
+                             cams["cam_view_proj"][v].numpy(), np.ones(3, np.float32), H, W)
+        ts = tile_start[v * tiles:(v + 1) * tiles + 1]
+        cnt = ov["ranges"][:, 1].astype(np.int64) - ov["ranges"][:, 0].astype(np.int64)
+        exact &= bool(np.array_equal(radii[v], ov["radii"]) and np.array_equal(rect[v].astype(np.uint32), ov["rect"])
+                      and np.array_equal(np.diff(ts), cnt)
+                      and np.array_equal(plist[ts[0]:ts[0] + ov["D"]].astype(np.uint32), ov["point_list"]))
+        total += ov["D"]
+        worst = max(worst, float(np.mean((color[v] - ov["color"]) ** 2)),
+                    *[float(np.mean((allmap[v, ch] - ov["allmap"][ch]) ** 2)) for ch in range(7)])
+    exact &= total == D
+    return {"against": "oracle/surfel_raster.c (CPU port; parity unpinned vs upstream, see DESIGN.md)", "views": V,
+            "bins_bit_identical": bool(exact), "num_rendered_D": D, "max_channel_mse": float(f"{worst:.3e}"),
+            "mse_bar": 1e-5, "pass": bool(exact and worst <= 1e-5)}
 
 
 def bench_conditioner(dev, reps=5):
@@ -323,7 +405,9 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true")
-    ap.add_argument("--no-dit", action="store_true", help="skip the DiT/SiT denoiser section of the report")
+    ap.add_argument("--no-parity", action="store_true", help="skip the untimed HIP-vs-oracle check of the bench workload")
+    ap.add_argument("--no-dit", action="store_true", help="skip the DiT/SiT denoiser and cascade sections of the report")
+    ap.add_argument("--no-cascade", action="store_true", help="skip the cascaded-sample section (BASELINE configs[3]/[4])")
     ap.add_argument("--dit-nfe", type=int, default=20)
     a = ap.parse_args()
 
@@ -354,16 +438,14 @@ def main():
     plan = SurfelForwardPlan(m, o, c, s, r, cams["cam_view"].to(dev), cams["cam_view_proj"].to(dev),
                              torch.ones(3, device=dev), H, W)
     plan.run()
-    D = plan.ensure_capacity()
-    ev = None
-    if not a.no_stage_events:
-        ev = [HipEvents(5) for _ in range(a.steps)]
+    plan.ensure_capacity()
     gathered = None
     payload = None
     if world > 1:
         payload = torch.empty((a.views, 10, H, W), dtype=torch.float32, device=dev)
         gathered = torch.empty((world, a.views, 10, H, W), dtype=torch.float32, device=dev) if rank == 0 else None
 
+    # ---- the timed region: EXACTLY `steps` forwards (+ the one gather when N > 1), nothing else ----------------------------
     for _ in range(a.warmup):
         plan.run()
     torch.cuda.synchronize()
@@ -372,8 +454,6 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(a.steps):
-        if ev is not None:
-            plan.set_stage_events(ev[k].arr)
         plan.run()
     if world > 1:
         payload[:, 0:3].copy_(plan.color)
@@ -388,10 +468,24 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    plan.set_stage_events(None)
     st = plan.ws.status().cpu()
     assert int(st[1]) == 0, "binned-list overflow inside the timed region"
 
+    # ---- untimed: per-stage durations from HIP events on the launch stream (a separate pass of the same forwards) -------
+    stage = total_dev = None
+    if rank == 0 and not a.no_stage_events:
+        nev = min(a.steps, 30)
+        ev = [HipEvents(5) for _ in range(nev)]
+        for k in range(nev):
+            plan.set_stage_events(ev[k].arr)
+            plan.run()
+        torch.cuda.synchronize()
+        plan.set_stage_events(None)
+        names = ["preprocess", "tile_scan_fill", "tile_sort", "blend"]
+        stage = {nm: float(np.mean([e.elapsed(i, i + 1) for e in ev])) for i, nm in enumerate(names)}
+        total_dev = float(np.mean([e.elapsed(0, 4) for e in ev]))
+
+    out = None
     if rank == 0:
         n, v = a.points, a.views
         value = n * v * a.steps * world / dt / 1e6
@@ -407,22 +501,21 @@ def main():
                        "multi_gpu": "independent samples per rank; one RCCL gather of [V,10,H,W] fp32 per rank to "
                                     "rank 0 inside the timed region" if world > 1 else "single GPU"},
         }
-        if ev is not None:
-            names = ["preprocess", "tile_scan_fill", "tile_sort", "blend"]
-            stage = {nm: float(np.mean([e.elapsed(i, i + 1) for e in ev])) for i, nm in enumerate(names)}
-            total_dev = float(np.mean([e.elapsed(0, 4) for e in ev]))
+        if stage is not None:
             P = H * W
             blend_bytes = 76.0 * int(st[0]) + 40.0 * P * v      # per launch (all V views), SURVEY.md 8d
             achieved = blend_bytes / (stage["blend"] * 1e-3) / 1e9
-            traffic = None  # PMC counters cannot be collected live: taken from the committed rocprofv3 passes
-            pmc_file = os.path.join(ROOT, "profiles", "r1_blend_pmc.json")
+            traffic, tsrc = None, None  # PMC counters cannot be collected live: taken from the committed rocprofv3 passes
+            pmc_file = os.path.join(ROOT, "profiles", "r2_blend_pmc.json")
             if a.scene == "surface" and n == 100_000 and v == 8 and H == 512 and os.path.exists(pmc_file):
-                traffic = json.load(open(pmc_file))["traffic_bytes_per_launch"]
+                pj = json.load(open(pmc_file))
+                traffic, tsrc = pj["traffic_bytes_per_launch"], f"committed PMC ({pj['source']}, HEAD {pj.get('head')}), not measured in this run"
             out["roofline"] = {"bound": "hbm", "kernel": "surfel_blend_kernel", "achieved": round(achieved, 2),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                               "traffic": traffic, "algorithmic_bytes_per_launch": int(blend_bytes),
+                               "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": int(blend_bytes),
                                "avg_launch_ms": round(stage["blend"], 5),
-                               "note": "blend is VALU/latency-bound, not HBM-bound (SURVEY.md 8d): see blend_valu"}
+                               "launch_duration_source": "HIP events on the launch stream, separate untimed pass of the same forwards",
+                               "note": "blend is VALU/LDS-bound, not HBM-bound (SURVEY.md 8d): see blend_valu"}
             # What the blend actually executes (one untimed forward with the statistics flag): (pixel, splat) pairs that
             # survive the cull boxes, the wave-level evaluation slots they were packed into, and the ~60 flop / pair of
             # SURVEY.md 8d -- the bound that matters for this kernel is VALU issue, not HBM.
@@ -438,11 +531,13 @@ def main():
                                  "lane_slot_utilisation": round(pairs / max(slots, 1.0), 4),
                                  "tflops_at_60flop_per_evaluated_pair": round(pairs * 60 / (stage["blend"] * 1e-3) / 1e12, 3),
                                  "peak_fp32_valu_tflops": FP32_VALU_PEAK_TFLOPS,
-                                 "note": "VALU busy 63 % at 2.3 of 3 resident waves/SIMD (profiles/r1d_pmc.txt); the gap "
-                                         "to peak is mask/loop bookkeeping, idle lanes and the staging pass"}
+                                 "note": "53 M wave-level VALU instructions per launch, LDS 22 M active cycles (profiles/r2_pmc.txt); "
+                                         "lanes = pixels of an 8x8 quadrant cannot exceed 0.53 lane use on this scene (tools/blend_sim.py)"}
             del splan
             out["stage_ms"] = {k: round(x, 5) for k, x in stage.items()}
             out["stage_ms"]["device_total"] = round(total_dev, 5)
+        if not a.no_parity:
+            out["parity"] = parity_check(g, cams, H, W, dev)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g, cams, H, W)
         if world == 1 and not a.no_dit:
@@ -453,11 +548,16 @@ def main():
             out["dit_batched"] = bench_dit(dev, "DiT-PixArt-PCD-CLAY-L", a.dit_nfe, 3, samples=4)
             out["decode"] = bench_decode(dev, cams)
             out["conditioner"] = bench_conditioner(dev)
-            out["cascade_measured"] = bench_cascade(dev, cams)
-            # BASELINE configs[3]: stage-1 DiT + stage-2 DiT (250-step Euler each) + surfel decode + raster of the result
-            out["sec_per_sample_250step_cascaded_L"] = round(
-                out["dit"][1]["sec_per_250_step_euler_stage"] + out["dit"][2]["sec_per_250_step_euler_stage"]
-                + out["decode"]["ms_per_decode"] * 1e-3 + out["decode"]["raster_8x512_ms"] * 1e-3, 4)
+    # ---- BASELINE configs[3] / [4]: one cascaded sample per GPU, every rank takes part -------------------------------
+    if not a.no_dit and not a.no_cascade:
+        del plan
+        torch.cuda.empty_cache()
+        casc = bench_cascade(dev, cams, rank, world, dist)
+        if rank == 0:
+            out["cascade"] = casc
+            out["sec_per_sample"] = casc["sec_per_sample"]            # 250-step cascaded, euler; N samples on N GPUs
+            out["sec_per_sample_dopri5"] = casc.get("dopri5", {}).get("sec_per_sample")
+    if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

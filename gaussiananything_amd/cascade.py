@@ -22,7 +22,7 @@ PCD_SCALING_FACTOR = 0.45  # sgm/configs/stage2-i23d.yaml:55-57 -> PCD_Scaler (s
 
 @torch.no_grad()
 def sample(model, cond, uc, shape, batch_size=1, cfg_scale=4.0, seed=42, num_steps=250, sampling_method="dopri5",
-           transport_sampler=None, noise_dtype=torch.bfloat16, **ode_kwargs):
+           transport_sampler=None, noise_dtype=torch.bfloat16, stats=None, **ode_kwargs):
     """``FlowMatchingEngine.sample`` (flow_matching_trainer.py:700-744): CPU-seeded noise, CFG batch = [cond | uncond],
     ``sample_ode(num_steps=250, cfg=True)`` (dopri5 by default, as upstream), last state, conditional half.
 
@@ -40,6 +40,8 @@ def sample(model, cond, uc, shape, batch_size=1, cfg_scale=4.0, seed=42, num_ste
     c_out = {k: torch.cat((cond[k], uc[k]), 0) for k in cond}
     zs = torch.cat([zs, zs], 0)
     samples = sample_fn(zs, model.forward_with_cfg, context=c_out, cfg_scale=cfg_scale)[-1]
+    if stats is not None:   # function evaluations / accepted / rejected steps of this stage's ODE solve
+        stats.update(getattr(getattr(transport_sampler, "last_ode", None), "last_stats", {}) or {})
     samples, _ = samples.chunk(2, dim=0)
     return samples
 
@@ -73,16 +75,20 @@ def stage2_conditioning(cond, uc, fps_xyz, zero_image_uc=False):
 
 @torch.no_grad()
 def cascade(stage1, stage2, decoder, cond, uc, cameras=None, cfg_scale=4.0, seed=42, num_steps=250,
-            sampling_method="dopri5", render_all_scale=True, stage2_zero_image_uc=False, **ode_kwargs):
+            sampling_method="dopri5", render_all_scale=True, stage2_zero_image_uc=False, stats=None, **ode_kwargs):
     """Stage 1 -> stage 2 -> surfel decode (-> renders when ``cameras`` = {cam_view, cam_view_proj [B,V,4,4], cam_pos
     [B,V,3], tanfov} is given).  ``cond`` / ``uc``: {'img_crossattn' [S,1369,1024], 'img_vector' [S,1024]}."""
     S = cond["img_crossattn"].shape[0]
     L = decoder.vit_decoder.pos_embed.shape[1]  # 768 latent tokens in the release (z_shape, flow_matching_trainer.py:1158)
-    xyz = sample(stage1, cond, uc, (L, stage1.in_channels), S, cfg_scale, seed, num_steps, sampling_method, **ode_kwargs)
+    st1, st2 = ({}, {}) if stats is not None else (None, None)
+    xyz = sample(stage1, cond, uc, (L, stage1.in_channels), S, cfg_scale, seed, num_steps, sampling_method, stats=st1,
+                 **ode_kwargs)
     fps_xyz = (xyz * XYZ_STD).clip(-0.45, 0.45)
     cond2, uc2 = stage2_conditioning(cond, uc, fps_xyz, zero_image_uc=stage2_zero_image_uc)
     latent = sample(stage2, cond2, uc2, (L, stage2.in_channels), S, cfg_scale, seed, num_steps, sampling_method,
-                    **ode_kwargs)
+                    stats=st2, **ode_kwargs)
+    if stats is not None:
+        stats.update(stage1=st1, stage2=st2)
     ret = decoder.decode(latent, fps_xyz)
     if cameras is not None:
         ret["renders"] = decoder.triplane_decode(ret, cameras, render_all_scale=render_all_scale)

@@ -39,6 +39,38 @@ def pack_views(color: torch.Tensor, allmap: torch.Tensor) -> torch.Tensor:
     return torch.cat([color, allmap], dim=1).contiguous()
 
 
+def pack_render(render: dict, item: int = 0) -> torch.Tensor:
+    """One sample's rendered views of one level (the dict of ``GaussianRenderer2DGS.render``) -> contiguous [V,9,H,W]:
+    RGB (3), median depth (1), alpha (1), world-space normal (3), distortion (1) -- the "multi-view RGB-D-N" payload."""
+    return torch.cat([render["image"][item], render["depth"][item], render["alpha"][item], render["rend_normal"][item],
+                      render["dist"][item]], dim=1).contiguous()
+
+
+def cascade_per_rank(stage1, stage2, decoder, cond_fn, cameras, num_samples, base_seed=42, level="gaussians_upsampled_3",
+                     **cascade_kwargs):
+    """BASELINE configs[4]: ``num_samples`` independent cascaded samples sharded over the ranks (``shard_samples``), every
+    rank running ``cascade.cascade`` for its own seeds with NO data-path collective; the rendered multi-view RGB-D-N of the
+    finest level is collected on rank 0 with ONE gather per owned sample round.  ``cond_fn(sample_index) -> (cond, uc)``.
+    Returns (gathered [world, V, 9, H, W] on rank 0 else None, list of this rank's sample indices)."""
+    from . import cascade as _cascade
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    mine = shard_samples(num_samples, rank, world)
+    rounds = (num_samples + world - 1) // world
+    gathered = None
+    for r in range(rounds):
+        payload = None
+        if r < len(mine):
+            cond, uc = cond_fn(mine[r])
+            out = _cascade.cascade(stage1, stage2, decoder, cond, uc, cameras=cameras, seed=base_seed + mine[r],
+                                   **cascade_kwargs)
+            payload = pack_render(out["renders"][level])
+        if payload is None:   # fewer samples than ranks in the last round: an empty contribution keeps the gather collective
+            raise ValueError("num_samples must be a multiple of the world size")
+        gathered = gather_to_rank0(payload)
+    return gathered, mine
+
+
 def gather_to_rank0(payload: torch.Tensor, dst: int = 0):
     """Collect every rank's payload on ``dst``: returns [world, *payload.shape] there, None elsewhere."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

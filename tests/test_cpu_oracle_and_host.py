@@ -447,11 +447,11 @@ def test_conditioner_oracle_and_host_surface():
 
 
 def test_committed_bench_line_follows_the_contract():
-    """profiles/r1*_bench.json (the last full `python bench.py` line of the round) carries every field of the driver's
+    """profiles/r*_bench.json (the last full `python bench.py` line of the round) carries every field of the driver's
     contract with the right types, and the derived numbers are consistent with each other."""
     import glob
     import json
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r1*_bench.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_bench.json")))
     assert files
     d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
     for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),

@@ -9,6 +9,48 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _cascade_per_rank_with_stand_ins(gd, rank, world):
+    """BASELINE configs[4] code path (distributed.cascade_per_rank, the one bench.py --gpus N runs): one cascaded sample per
+    rank, own seed and conditioning, one gather to rank 0 -- with recording stand-ins for the two denoisers and the
+    decoder (the HIP models need a GPU)."""
+    class Den(torch.nn.Module):
+        def __init__(self, C):
+            super().__init__()
+            self.in_channels = C
+            self.w = torch.nn.Parameter(torch.zeros(1))
+
+        def forward_with_cfg(self, x, t, context=None, cfg_scale=1.0):
+            return -x + context["img_vector"].mean()
+
+    class Dec(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.vit_decoder = torch.nn.Module()
+            self.vit_decoder.pos_embed = torch.nn.Parameter(torch.zeros(1, 16, 4))
+
+        def decode(self, latent, xyz):
+            return {"latent": latent, "query_pcd_xyz": xyz}
+
+        def triplane_decode(self, ret, cams, render_all_scale=True):
+            v = float(ret["latent"].mean())
+            mk = lambda ch: torch.full((1, 2, ch, 4, 4), v)  # noqa: E731
+            return {"gaussians_upsampled_3": {"image": mk(3), "depth": mk(1), "alpha": mk(1), "rend_normal": mk(3), "dist": mk(1)}}
+
+    def cond_fn(i):
+        g = torch.Generator().manual_seed(100 + i)
+        cond = {"img_crossattn": torch.randn(1, 5, 8, generator=g), "img_vector": torch.randn(1, 8, generator=g)}
+        return cond, {k: torch.zeros_like(v) for k, v in cond.items()}
+
+    gathered, mine = gd.cascade_per_rank(Den(3), Den(10), Dec(), cond_fn, {"tanfov": 0.36}, world, base_seed=7, num_steps=4,
+                                         sampling_method="euler")
+    if mine != [rank]:
+        return False
+    if rank != 0:
+        return gathered is None
+    # every rank's payload arrived, and they differ (own seed, own conditioning)
+    return tuple(gathered.shape) == (world, 2, 9, 4, 4) and float((gathered[0] - gathered[1]).abs().max()) > 0
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -20,13 +62,14 @@ def _worker(rank, world, port, q):
     allmap = torch.full((2, 7, 4, 4), float(10 + r))
     out = gd.gather_to_rank0(gd.pack_views(color, allmap))
     t = gd.max_over_ranks(1.0 + r, torch.device("cpu"))
+    casc = _cascade_per_rank_with_stand_ins(gd, r, w)
     if r == 0:
         ok = out.shape == (w, 2, 10, 4, 4) and all(float(out[i, 0, 0, 0, 0]) == i and float(out[i, 0, 9, 0, 0]) == 10 + i
                                                     for i in range(w))
-        q.put((ok, mine, t))
+        q.put((ok and casc, mine, t))
     else:
         assert out is None
-        q.put((True, mine, t))
+        q.put((casc, mine, t))
     dist.barrier()
     dist.destroy_process_group()
 
