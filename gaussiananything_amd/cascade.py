@@ -22,13 +22,19 @@ PCD_SCALING_FACTOR = 0.45  # sgm/configs/stage2-i23d.yaml:55-57 -> PCD_Scaler (s
 
 @torch.no_grad()
 def sample(model, cond, uc, shape, batch_size=1, cfg_scale=4.0, seed=42, num_steps=250, sampling_method="dopri5",
-           transport_sampler=None, noise_dtype=torch.bfloat16, stats=None, **ode_kwargs):
+           transport_sampler=None, noise_dtype=torch.bfloat16, stats=None, dedup_noop_cfg=True, **ode_kwargs):
     """``FlowMatchingEngine.sample`` (flow_matching_trainer.py:700-744): CPU-seeded noise, CFG batch = [cond | uncond],
     ``sample_ode(num_steps=250, cfg=True)`` (dopri5 by default, as upstream), last state, conditional half.
 
     ``noise_dtype``: the reference draws fp32 noise on the CPU and rounds it to the engine dtype before sampling
     (``.to(self.dtype)``, :720; the release runs bf16 AMP), so the initial state is a bf16-representable tensor; the ODE
-    state is fp32 from the first update on.  ``None`` keeps the un-rounded fp32 draw."""
+    state is fp32 from the first update on.  ``None`` keeps the un-rounded fp32 draw.
+
+    ``dedup_noop_cfg``: when the unconditional conditioning IS the conditional one (``uc[k] is cond[k]`` for every key -- the
+    release's stage 2, ``stage2_conditioning``), both halves of the CFG batch are the same sequence, ``forward_with_cfg``
+    returns ``uncond + s * (cond - uncond) = cond`` and the two halves of the ODE state stay equal (dopri5's RMS norm over
+    the doubled state equals that over one half): the denoiser is evaluated on the conditional half alone -- the same
+    numbers up to the GEMM tile shapes chosen for the smaller batch, half the work."""
     if transport_sampler is None:
         transport_sampler = Sampler(create_transport("GVP", "velocity", None, None, None, snr_type="uniform"))
     sample_fn = transport_sampler.sample_ode(sampling_method=sampling_method, num_steps=num_steps, cfg=True, **ode_kwargs)
@@ -37,6 +43,13 @@ def sample(model, cond, uc, shape, batch_size=1, cfg_scale=4.0, seed=42, num_ste
     zs = torch.randn(batch_size, *shape).to(dev)
     if noise_dtype is not None:
         zs = zs.to(noise_dtype).float()
+    if dedup_noop_cfg and all(uc[k] is cond[k] for k in cond):
+        def cond_only(x, t, context=None, cfg_scale=None):
+            return model.forward(x, t, context)
+        samples = sample_fn(zs, getattr(model, "forward_cond", cond_only), context=dict(cond), cfg_scale=cfg_scale)[-1]
+        if stats is not None:
+            stats.update(getattr(getattr(transport_sampler, "last_ode", None), "last_stats", {}) or {}, noop_cfg_dedup=True)
+        return samples
     c_out = {k: torch.cat((cond[k], uc[k]), 0) for k in cond}
     zs = torch.cat([zs, zs], 0)
     samples = sample_fn(zs, model.forward_with_cfg, context=c_out, cfg_scale=cfg_scale)[-1]

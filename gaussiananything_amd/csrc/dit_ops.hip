@@ -210,14 +210,35 @@ struct FinalArgs {
     int M, D, Cout, rows_per_batch;
     const float *x, *table, *t, *w, *bias;
     float *out;
+    // fused sampler step (GaDitSamplerStep), state == nullptr: plain evaluation
+    float cfg_scale;
+    int cfg;
+    const float *dt;
+    float *state, *traj;
+    long long traj_stride;
+    const int *counter;
 };
 
 // One wave per row, the row (D <= 2048, D % 4 == 0) held in registers as in rmsnorm_modulate_kernel: one memory round trip
 // for x / table / t, the LayerNorm statistics by two wave sums, then Cout <= 16 dot products against the L2-resident weight.
-__global__ __launch_bounds__(256) void final_layer_kernel(FinalArgs a)
+// The sampler arithmetic of the fused step, every operation rounded once (no contraction into FMAs): these are the very
+// roundings of the eager PyTorch loop (forward_with_cfg: u + s * (c - u); euler: y + dt * v).
+__device__ __forceinline__ float cfg_combine(float c, float u, float s)
 {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= a.M) return;
+    const float d = c - u;
+    float m = s * d;
+    asm volatile("" : "+v"(m));   // this TU is built with -ffp-contract=fast: keep the product a value of its own
+    return u + m;
+}
+__device__ __forceinline__ float euler_update(float y, float dt, float v)
+{
+    float p = dt * v;
+    asm volatile("" : "+v"(p));
+    return y + p;
+}
+
+__device__ __forceinline__ void final_layer_row(const FinalArgs &a, int row, int lane, float (&res)[16])
+{
     const int D = a.D, b = row / a.rows_per_batch;
     const float *x = a.x + (size_t)row * D, *tb = a.t + (size_t)b * D;
     float4 v[8], sh[8], sc[8];
@@ -268,11 +289,57 @@ __global__ __launch_bounds__(256) void final_layer_kernel(FinalArgs a)
         }
     }
 #pragma unroll
-    for (int o = 0; o < 16; ++o)
-        if (o < a.Cout) {
-            const float r = wave_sum(acc[o]);
-            if (lane == 0) a.out[(size_t)row * a.Cout + o] = r + a.bias[o];
+    for (int o = 0; o < 16; ++o) res[o] = o < a.Cout ? wave_sum(acc[o]) + a.bias[o] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void final_layer_kernel(FinalArgs a)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (a.state == nullptr) {
+        if (row >= a.M) return;
+        float r[16];
+        final_layer_row(a, row, lane, r);
+        if (lane < a.Cout) {
+            float mine = 0.f;
+#pragma unroll
+            for (int o = 0; o < 16; ++o) mine = lane == o ? r[o] : mine;
+            a.out[(size_t)row * a.Cout + lane] = mine;
         }
+        return;
+    }
+    // fused sampler step: this wave owns row `row` of the conditional half and, with CFG, its unconditional twin
+    const int half = a.cfg ? a.M / 2 : a.M;
+    if (row >= half) return;
+    float v[16];
+    final_layer_row(a, row, lane, v);
+    if (a.cfg) {
+        float u[16];
+        final_layer_row(a, row + half, lane, u);
+#pragma unroll
+        for (int o = 0; o < 16; ++o) v[o] = cfg_combine(v[o], u[o], a.cfg_scale);
+    }
+    if (lane < a.Cout) {
+        float mine = 0.f;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) mine = lane == o ? v[o] : mine;
+        const float dtv = *a.dt;
+        float *slice = a.traj ? a.traj + (size_t)(*a.counter + 1) * a.traj_stride : nullptr;
+        for (int h = 0; h < (a.cfg ? 2 : 1); ++h) {
+            const size_t i = (size_t)(row + h * half) * a.Cout + lane;
+            const float y = euler_update(a.state[i], dtv, mine);   // both halves hold the same state and receive the same update
+            a.state[i] = y;
+            if (slice) slice[i] = y;
+        }
+    }
+}
+
+__global__ void sampler_advance_kernel(int *counter, const float *t_grid, const float *dt_grid, int grid_len, float *timesteps,
+                                       int batch, float *dt)
+{
+    const int c = min(*counter + 1, grid_len - 1);
+    __syncthreads();
+    if ((int)threadIdx.x < batch) timesteps[threadIdx.x] = t_grid[c];
+    if (threadIdx.x == 0) { *dt = dt_grid[c]; *counter = *counter + 1; }
 }
 
 }  // namespace gadit
@@ -395,7 +462,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
 {
     using namespace gadit;
     if (!model_ok(m) || !a) return GA_DIT_ERR_NULL_ARG;
-    if (!a->x || !a->timesteps || !a->img_vector || !a->ca_k || !a->ca_vt || !a->out || !a->workspace) return GA_DIT_ERR_NULL_ARG;
+    if (!a->x || !a->timesteps || !a->img_vector || !a->ca_k || !a->ca_vt || (!a->out && !a->step) || !a->workspace) return GA_DIT_ERR_NULL_ARG;
     if (m->stage2 && !a->fps_xyz) return GA_DIT_ERR_NULL_ARG;
     const int B = a->batch, L = a->tokens, D = m->hidden, Mrows = B * L;
     if (B <= 0 || B > 16 || L <= 0 || a->ctx_tokens <= 0) return GA_DIT_ERR_BAD_SHAPE;
@@ -496,8 +563,28 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         GA_UNLESS(8, ga_gemm_bf16(&g2, stream));
     }
     {
-        FinalArgs f{Mrows, D, m->out_channels, L, w.xres, m->final_table, w.tvec, m->final_w, m->final_b, a->out};
-        hipLaunchKernelGGL(final_layer_kernel, dim3((Mrows + 3) / 4), dim3(256), 0, s, f);
+        FinalArgs f{Mrows, D, m->out_channels, L, w.xres, m->final_table, w.tvec, m->final_w, m->final_b, a->out,
+                    0.f, 0, nullptr, nullptr, nullptr, 0, nullptr};
+        int rows = Mrows;
+        if (const GaDitSamplerStep *st = a->step) {
+            if (!st->dt || !st->state || !st->counter || (st->cfg && (B % 2 != 0)) || st->state != a->x ||
+                m->out_channels != m->in_channels)
+                return GA_DIT_ERR_BAD_SHAPE;
+            f.cfg_scale = st->cfg_scale; f.cfg = st->cfg ? 1 : 0; f.dt = st->dt; f.state = st->state; f.traj = st->traj;
+            f.traj_stride = st->traj_stride; f.counter = st->counter;
+            rows = st->cfg ? Mrows / 2 : Mrows;
+        }
+        hipLaunchKernelGGL(final_layer_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, f);
     }
+    return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
+}
+
+extern "C" int ga_dit_sampler_advance(int32_t *counter, const float *t_grid, const float *dt_grid, int32_t grid_len,
+                                      float *timesteps, int32_t batch, float *dt, void *stream)
+{
+    if (!counter || !t_grid || !dt_grid || !timesteps || !dt) return GA_DIT_ERR_NULL_ARG;
+    if (grid_len <= 0 || batch <= 0 || batch > 64) return GA_DIT_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(gadit::sampler_advance_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), counter, t_grid,
+                       dt_grid, grid_len, timesteps, batch, dt);
     return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
 }

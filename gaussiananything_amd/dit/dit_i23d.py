@@ -239,7 +239,7 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         return ck, cvt, max(ca_batch, 1)
 
     # -- the reference surface ------------------------------------------------------------------------------------------
-    def forward(self, x, timesteps=None, context=None, y=None, get_attr="", **kwargs):
+    def forward(self, x, timesteps=None, context=None, y=None, get_attr="", _step=None, **kwargs):
         assert isinstance(context, dict)
         if x.device.type != "cuda":
             raise RuntimeError("gaussiananything_amd DiT only runs on an MI355X (HIP) device; there is no CPU path")
@@ -249,13 +249,13 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         assert C == self.in_channels
         ck, cvt, ca_batch = self._context_kv(pack, context["img_crossattn"])
         Mctx = context["img_crossattn"].shape[1]
-        xin = x.detach().float().contiguous()
+        xin = x if _step is not None else x.detach().float().contiguous()
         t = timesteps.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
         if t.numel() == 1 and B > 1:
             t = t.expand(B).contiguous()
         vec = context["img_vector"].detach().float().contiguous()
         xyz = context["fps-xyz"].detach().float().contiguous() if self._stage2 else None
-        out = torch.empty((B, L, self.out_channels), dtype=torch.float32, device=dev)
+        out = torch.empty((B, L, self.out_channels), dtype=torch.float32, device=dev) if _step is None else None
         Lib = ops.lib()
         ws_key = (B, L, Mctx)
         if pack["ws_key"] != ws_key:
@@ -267,8 +267,9 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         buf = pack["ws"]
         base = buf.data_ptr() + ((-buf.data_ptr()) % 256)
         args = ops.GaDitForwardArgs(B, L, Mctx, xin.data_ptr(), t.data_ptr(), vec.data_ptr(),
-                                    xyz.data_ptr() if xyz is not None else None, ck.data_ptr(), cvt.data_ptr(), out.data_ptr(), base,
-                                    pack["ws_bytes"], ca_batch)
+                                    xyz.data_ptr() if xyz is not None else None, ck.data_ptr(), cvt.data_ptr(),
+                                    out.data_ptr() if out is not None else None, base, pack["ws_bytes"], ca_batch,
+                                    ctypes.pointer(_step) if _step is not None else None)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         ops.check(Lib.ga_dit_forward(ctypes.byref(pack["model"]), ctypes.byref(args), stream), "ga_dit_forward")
         return out
@@ -278,6 +279,66 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         cond_eps, uncond_eps = torch.split(eps, len(eps) // 2, dim=0)
         half_eps = uncond_eps + cfg_scale * (cond_eps - uncond_eps)
         return torch.cat([half_eps, half_eps], dim=0)
+
+    def forward_cond(self, x, t, context, cfg_scale=None):
+        """The conditional evaluation alone, with the call signature of ``forward_with_cfg``: what the sampling loop uses when
+        guidance is a no-op (unconditional conditioning == conditional one, the release's stage 2; cascade.sample)."""
+        return self.forward(x, t, context)
+
+    @torch.no_grad()
+    def sample_euler_fused(self, y0, t_grid, context, cfg_scale=1.0, cfg=True):
+        """The reference's fixed-grid Euler sampling loop (transport/integrators.py:100-119 with method "euler":
+        y_{k+1} = y_k + (t_{k+1} - t_k) f(t_k, y_k), all grid states returned) with the whole step on the device: the
+        function evaluation, the CFG combine of ``forward_with_cfg`` and the state update leave through the final-layer
+        kernel (GaDitSamplerStep), a one-thread kernel moves the step counter / time / step size on, and one step is
+        captured into a HIP graph and replayed -- nothing but this library's kernels between two steps, no host
+        synchronisation.  Bit-identical to the eager loop over ``forward_with_cfg`` / ``forward_cond``."""
+        dev = y0.device
+        tt = [float(v) for v in t_grid]
+        n = len(tt)
+        y = y0.detach().float().contiguous().clone()
+        out = torch.empty((n,) + tuple(y.shape), dtype=torch.float32, device=dev)
+        out[0].copy_(y)
+        if n < 2:
+            return out
+        B = y.shape[0]
+        t_arr = torch.tensor(tt[:-1], dtype=torch.float32, device=dev)
+        dt_arr = torch.tensor([b - a for a, b in zip(tt[:-1], tt[1:])], dtype=torch.float32, device=dev)
+        counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        tvec = torch.empty(B, dtype=torch.float32, device=dev)
+        dt = torch.empty(1, dtype=torch.float32, device=dev)
+        step = ops.GaDitSamplerStep(float(cfg_scale), 1 if cfg else 0, dt.data_ptr(), y.data_ptr(), out.data_ptr(),
+                                    y.numel(), counter.data_ptr())
+        Lib = ops.lib()
+
+        def one_step():
+            self.forward(y, tvec, context, _step=step)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            ops.check(Lib.ga_dit_sampler_advance(counter.data_ptr(), t_arr.data_ptr(), dt_arr.data_ptr(), n - 1,
+                                                 tvec.data_ptr(), B, dt.data_ptr(), stream), "ga_dit_sampler_advance")
+
+        def reset():
+            y.copy_(out[0])
+            counter.zero_()
+            tvec.fill_(tt[0])
+            dt.copy_(dt_arr[0:1])
+
+        reset()
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):   # warm-up outside the capture: lazy initialisation, workspace sizing, K/V caches
+            one_step()
+        cur.wait_stream(side)
+        reset()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            one_step()
+        reset()   # (capture does not execute; the state is as before)
+        for _ in range(n - 1):
+            graph.replay()
+        self._fused_keep = (y, t_arr, dt_arr, counter, tvec, dt, step, graph)   # alive until the replays have run
+        return out
 
 
 class DiT_I23D_PCD_PixelArt_noclip_clay_stage2(DiT_I23D_PCD_PixelArt_noclip):

@@ -85,7 +85,7 @@ class Sampler:
         t0, t1 = self.transport.check_interval(self.transport.train_eps, self.transport.sample_eps, sde=False, eval=True,
                                                reverse=reverse, last_step_size=0.0)
         self.last_ode = ode(drift=drift, t0=t0, t1=t1, sampler_type=sampling_method, num_steps=num_steps, atol=atol,
-                            rtol=rtol)
+                            rtol=rtol, plain_velocity_drift=not reverse)
         return self.last_ode.sample
 
     def sample_sde(self, *a, **k):

@@ -175,6 +175,24 @@ typedef struct GaDitModel {
     const GaDitBlockWeights *blocks;                    /* host array [depth]                          */
 } GaDitModel;
 
+/* Optional sampler step fused into the final layer (GaDitForwardArgs.step): the Euler update of the reference's fixed-grid
+ * sampling loop (/root/reference/transport/integrators.py:100-119 with torchdiffeq's euler: y += dt * f(t, y)) around
+ * forward_with_cfg (/root/reference/dit/dit_i23d.py:159-172):
+ *     v      = cfg ? u + cfg_scale * (c - u) : model output          (c, u: rows of batch item b < B'/2 and b + B'/2)
+ *     state += dt * v                                                 (both CFG halves receive the same v)
+ *     traj[(*counter + 1) * traj_stride ...] = state                  (the [num_steps, *x.shape] output of sample_ode)
+ * every product and sum rounded once, in this order -- bit-identical to the eager PyTorch loop.  `state` is the x of the
+ * evaluation (GaDitForwardArgs.x must point at it); `out` is not written.  ga_dit_sampler_advance moves the step on. */
+typedef struct GaDitSamplerStep {
+    float cfg_scale;
+    int32_t cfg;              /* 1: combine the two CFG halves; 0: v = model output                     */
+    const float *dt;          /* device scalar: step size of this step                                  */
+    float *state;             /* [B', L, Cout] fp32, updated in place                                    */
+    float *traj;              /* trajectory base (slice 0 = initial state, written by the caller) or NULL */
+    int64_t traj_stride;      /* floats per slice = B' * L * Cout                                        */
+    const int32_t *counter;   /* device: index of the grid interval this step integrates                */
+} GaDitSamplerStep;
+
 typedef struct GaDitForwardArgs {
     int32_t batch;            /* B' (CFG batch: 2 x samples), <= 16                                    */
     int32_t tokens;           /* L latent tokens per batch item                                        */
@@ -193,6 +211,7 @@ typedef struct GaDitForwardArgs {
      * RMSNorm(0) = 0), the softmax is uniform over zeros and the block's cross-attention reduces to `x += to_out.bias`:
      * those items skip the q projection, the 1369-key attention and the output projection -- bit-identical result. */
     int32_t ca_batch;
+    const GaDitSamplerStep *step;   /* host pointer, NULL = plain function evaluation into `out`                */
 } GaDitForwardArgs;
 
 size_t ga_dit_workspace_bytes(const GaDitModel *model, int32_t batch, int32_t tokens, int32_t ctx_tokens);
@@ -204,6 +223,11 @@ int ga_dit_cache_context(const GaDitModel *model, int32_t batch, int32_t ctx_tok
                          ga_bf16 *ca_k, ga_bf16 *ca_vt, void *stream);
 
 int ga_dit_forward(const GaDitModel *model, const GaDitForwardArgs *args, void *stream);
+
+/* host: one tiny kernel closing a fused sampler step: ++*counter; timesteps[0..batch) = t_grid[*counter];
+ * *dt = dt_grid[*counter] (both grids fp32 device arrays of num_steps - 1 entries; reads past the end are clamped). */
+int ga_dit_sampler_advance(int32_t *counter, const float *t_grid, const float *dt_grid, int32_t grid_len, float *timesteps,
+                           int32_t batch, float *dt, void *stream);
 
 const char *ga_dit_version(void);
 

@@ -507,6 +507,10 @@ def test_stage2_conditioning_follows_the_release_config():
             self.seen.append({k: v.clone() for k, v in context.items()} | {"x0": x.clone()})
             return -x
 
+        def forward(self, x, t, context=None):
+            self.seen.append({k: v.clone() for k, v in context.items()} | {"x0": x.clone(), "cond_only": True})
+            return -x
+
     class Dec(torch.nn.Module):
         def __init__(self):
             super().__init__()
@@ -519,7 +523,7 @@ def test_stage2_conditioning_follows_the_release_config():
     s1, s2, dec = Den(3), Den(10), Dec()
     cond = {"img_crossattn": torch.randn(1, 5, 8), "img_vector": torch.randn(1, 8)}
     uc = {k: torch.zeros_like(v) for k, v in cond.items()}
-    out = cascade.cascade(s1, s2, dec, cond, uc, num_steps=4, sampling_method="euler", seed=7)
+    out = cascade.cascade(s1, s2, dec, cond, uc, num_steps=4, sampling_method="euler", seed=7, dedup_noop_cfg=False)
     first1, first2 = s1.seen[0], s2.seen[0]
     # stage 1: [cond | zero uncond]; initial state = CPU-seeded noise rounded to bf16 (flow_matching_trainer.py:720)
     assert torch.equal(first1["img_crossattn"][1], torch.zeros(5, 8)) and torch.equal(first1["img_crossattn"][0], cond["img_crossattn"][0])
@@ -531,5 +535,10 @@ def test_stage2_conditioning_follows_the_release_config():
     assert float(raw.abs().max()) <= 0.45
     assert torch.allclose(first2["fps-xyz"][0], raw[0] / 0.45) and torch.equal(first2["fps-xyz"][0], first2["fps-xyz"][1])
     assert torch.equal(first2["img_crossattn"][0], first2["img_crossattn"][1]) and torch.equal(first2["img_crossattn"][0], cond["img_crossattn"][0])
+    # default: the no-op guidance of stage 2 is recognised and the denoiser runs on the conditional half alone -- same result
+    n_before = len(s2.seen)
+    out_d = cascade.cascade(s1, s2, dec, cond, uc, num_steps=4, sampling_method="euler", seed=7)
+    assert s2.seen[n_before].get("cond_only") and s2.seen[n_before]["x0"].shape[0] == 1
+    assert torch.allclose(s2.seen[n_before]["fps-xyz"][0], raw[0] / 0.45) and torch.equal(out_d["latent"], out["latent"])
     out0 = cascade.cascade(s1, s2, dec, cond, uc, num_steps=4, sampling_method="euler", seed=7, stage2_zero_image_uc=True)
     assert torch.equal(s2.seen[-1]["img_crossattn"][1], torch.zeros(5, 8)) and out0["latent"].shape == (1, 16, 10)

@@ -396,5 +396,25 @@ def test_sampler_graph_replay_equals_eager_loop(gpu_device, method, monkeypatch)
     assert outs["1"].shape == (7,) + tuple(x.shape)
     if method == "euler":
         assert torch.equal(outs["0"], outs["1"])
+        assert sampler.last_ode.last_stats.get("fused")      # the on-device step (GaDitSamplerStep) was the one replayed
     else:
         assert rel_l2(outs["1"], outs["0"]) < 1e-5
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+def test_fused_euler_step_without_guidance_equals_eager_loop(gpu_device, stage, monkeypatch):
+    """forward_cond (guidance is a no-op: the release's stage 2) through the fused on-device Euler step, against the eager
+    loop over the same callable: bit-identical states at every grid point."""
+    from gaussiananything_amd.transport import Sampler, create_transport
+    z, model, ctx = _load_golden(stage, gpu_device)
+    half = z["x"].shape[0] // 2
+    x = z["x"][:half].to(gpu_device)
+    c = {k: v[:half].contiguous() for k, v in ctx.items()}
+    sampler = Sampler(create_transport("GVP", "velocity", None, None, None, snr_type="uniform"))
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("GA_ODE_GRAPH", flag)
+        fn = sampler.sample_ode(sampling_method="euler", num_steps=9)
+        with torch.no_grad():
+            outs[flag] = fn(x, model.forward_cond, context=c, cfg_scale=z["cfg_scale"])
+    assert torch.equal(outs["0"], outs["1"]) and sampler.last_ode.last_stats.get("fused")

@@ -22,6 +22,9 @@ def _cascade_per_rank_with_stand_ins(gd, rank, world):
         def forward_with_cfg(self, x, t, context=None, cfg_scale=1.0):
             return -x + context["img_vector"].mean()
 
+        def forward(self, x, t, context=None):
+            return -x + context["img_vector"].mean()
+
     class Dec(torch.nn.Module):
         def __init__(self):
             super().__init__()
