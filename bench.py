@@ -81,14 +81,48 @@ def cpu_baseline(g, cams, H, W, min_seconds=3.0):
                       f"single-threaded, blend OpenMP over tiles ({cores} threads); includes numpy buffer setup"}
 
 
-def dit_flops_per_nfe(D, depth, L, M, ctx, batch):
-    """Algorithmic FLOPs of one function evaluation with the image-token K/V cached:
-    per block and sequence  SA: 2L*D*3D + 4L^2*D + 2L*D^2 ; CA: 2L*D^2 (q) + 4L*M*D + 2L*D^2 (out) ; MLP: 16L*D^2."""
+def dit_flops_per_nfe(D, depth, L, M, ctx, batch, ca_batch=None):
+    """FLOPs of one function evaluation with the image-token K/V cached: per block and sequence
+    SA: 2L*D*3D + 4L^2*D + 2L*D^2 ; CA: 2L*D^2 (q) + 4L*M*D + 2L*D^2 (out) ; MLP: 16L*D^2.  Returns (algorithmic: every batch
+    item through its cross-attention, EXECUTED: only `ca_batch` items do -- the zero-context unconditional half of a CFG
+    batch skips it, include/ga_dit.h -- and the attention-only share of the executed count)."""
+    ca_batch = batch if ca_batch is None else ca_batch
     sa = 2 * L * D * 3 * D + 4 * L * L * D + 2 * L * D * D
     ca = 2 * L * D * D + 4 * L * M * D + 2 * L * D * D
     mlp = 16 * L * D * D
-    attn_only = 4 * L * L * D + 4 * L * M * D
-    return batch * depth * (sa + ca + mlp), batch * depth * attn_only
+    return (batch * depth * (sa + ca + mlp), depth * (batch * (sa + mlp) + ca_batch * ca),
+            depth * (batch * 4 * L * L * D + ca_batch * 4 * L * M * D))
+
+
+def bench_attention(dev, reps=50):
+    """north_star: 'MFMA utilisation for DiT attention'.  The two attention shapes of a DiT-L evaluation timed alone with HIP
+    events around back-to-back launches: self-attention (CFG batch 2 x 16 heads x 768 x 768) and the image cross-attention
+    of the conditional half (1 x 16 x 768 x 1369), d = 64; FLOPs = 4 * Lq * Lk * d per (batch, head) (QK^T + PV)."""
+    from gaussiananything_amd import dit_ops as ops
+    g = torch.Generator().manual_seed(3)
+    out = {}
+    for name, B, Lq, Lk in (("self_attention_2x16x768x768", 2, 768, 768), ("cross_attention_1x16x768x1369", 1, 768, 1369)):
+        H = 16
+        Lp = (Lk + 63) // 64 * 64
+        q = torch.randn(B, Lq, H, 64, generator=g).to(dev).bfloat16()
+        k = torch.randn(B, Lk, H, 64, generator=g).to(dev).bfloat16()
+        vt = torch.zeros(B * H * 64, Lp, dtype=torch.bfloat16, device=dev)
+        vt[:, :Lk] = torch.randn(B * H * 64, Lk, generator=g).to(dev).bfloat16()
+        for _ in range(5):
+            ops.attention(q, k, vt)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.attention(q, k, vt)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        fl = 4.0 * B * H * Lq * Lk * 64
+        out[name] = {"us": round(us, 2), "tflops": round(fl / (us * 1e-6) / 1e12, 1),
+                     "frac_of_bf16_mfma_peak": round(fl / (us * 1e-6) / 1e12 / 2500.0, 4)}
+    out["note"] = ("launches on torch's current stream, timed with events on that stream; MFMA-busy counters of the same kernels: "
+                   "profiles/r1f_attention_pmc.txt (the kernel is unchanged since)")
+    return out
 
 
 def bench_dit(dev, arch, nfe, warmup, parity_mode=False, samples=1):
@@ -179,10 +213,12 @@ def bench_dit(dev, arch, nfe, warmup, parity_mode=False, samples=1):
                                      "cores": ncpu,
                                      "sample": "best of 2 forward_with_cfg calls of the fp32 PyTorch oracle on the host "
                                                "cores (CFG batch 2 x 768 tokens); x249 for a 250-step Euler stage"}
-    fl, fl_attn = dit_flops_per_nfe(model.embed_dim, model.depth, L, M, 1024, B)
-    tf = fl / (ms * 1e-3) / 1e12
+    fl, fl_exec, fl_attn = dit_flops_per_nfe(model.embed_dim, model.depth, L, M, 1024, B, ca_batch=samples)
+    tf = fl_exec / (ms * 1e-3) / 1e12
     return {"arch": arch, "cfg_batch": B, "tokens": L, "ctx_tokens": M, "ms_per_nfe": round(ms, 4),
-            "algorithmic_tflop_per_nfe": round(fl / 1e12, 4), "achieved_tflops": round(tf, 2),
+            "algorithmic_tflop_per_nfe": round(fl / 1e12, 4), "executed_tflop_per_nfe": round(fl_exec / 1e12, 4),
+            "achieved_tflops": round(tf, 2), "achieved_tflops_note": "EXECUTED flops (the zero-context half skips its cross-attention) / time",
+            "algorithmic_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
             "bf16_mfma_peak_tflops": 2500.0, "frac_of_mfma_peak": round(tf / 2500.0, 4),
             "sec_per_250_step_euler_stage": round(sec250, 4), "nfe_timed": nfe, **extra}
 
@@ -546,6 +582,7 @@ def main():
                           ("DiT-PixArt-PCD-CLAY-B", "DiT-PixArt-PCD-CLAY-L", "DiT-PixArt-PCD-CLAY-stage2-L")]
             # throughput mode: four independent samples batched on the GPU (M = 6144 rows fill the chip; one sample does not)
             out["dit_batched"] = bench_dit(dev, "DiT-PixArt-PCD-CLAY-L", a.dit_nfe, 3, samples=4)
+            out["attention"] = bench_attention(dev)
             out["decode"] = bench_decode(dev, cams)
             out["conditioner"] = bench_conditioner(dev)
     # ---- BASELINE configs[3] / [4]: one cascaded sample per GPU, every rank takes part -------------------------------

@@ -190,7 +190,7 @@ struct ChunkRegs {
 
 __device__ __forceinline__ ChunkRegs load_chunk(const float4 *__restrict__ rec4, uint32_t id)
 {
-    const float4 *r = rec4 + (size_t)id * 6;
+    const float4 *r = rec4 + (size_t)id * (kRec / 4);
     return ChunkRegs{r[0], r[1], r[2], r[3], r[4], *reinterpret_cast<const f2 *>(r + 5)};
 }
 
