@@ -155,6 +155,11 @@ def bench_dit(dev, arch, nfe, warmup, parity_mode=False, samples=1):
         for _ in range(warmup):
             model.forward_with_cfg(x, t, ctx, 4.0)
         torch.cuda.synchronize()
+        tw = time.perf_counter()
+        while time.perf_counter() - tw < 0.5:     # the GPU idled through the CPU legs before this: let the clocks come back
+            for _ in range(10):
+                model.forward_with_cfg(x, t, ctx, 4.0)
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(nfe):
             model.forward_with_cfg(x, t, ctx, 4.0)
