@@ -79,6 +79,12 @@ def main():
                ("pointer scheme, window 8, kU 4", dict(window=-8, kU=4, map=0, seg_min=1024, nseg=4)),
                ("pointer scheme, window 8, kU 2", dict(window=-8, kU=2, map=0, seg_min=1024, nseg=4)),
                ("pointer scheme, window 8, kU 3", dict(window=-8, kU=3, map=0, seg_min=1024, nseg=4)),
+               ("sorted groups + pointer scheme, window 8, kU 2", dict(window=-8, kU=2, map=2, seg_min=2048, nseg=8)),
+               ("sorted groups + pointer scheme, window 8, kU 3", dict(window=-8, kU=3, map=2, seg_min=2048, nseg=8)),
+               ("sorted groups + pointer scheme, window 8, kU 4", dict(window=-8, kU=4, map=2, seg_min=2048, nseg=8)),
+               ("sorted groups, window 2 (cur/nxt), kU 4", dict(window=2, kU=4, map=2, seg_min=2048, nseg=8)),
+               ("quadrants, window 2, kU 4, 8 seg >= 2048 (today)", dict(window=2, kU=4, map=0, seg_min=2048, nseg=8)),
+               ("quadrants + pointer scheme, window 8, kU 2", dict(window=-8, kU=2, map=0, seg_min=2048, nseg=8)),
                ("quadrants, window 2, no segments", dict(window=2, kU=4, map=0, seg_min=1 << 30, nseg=1)),
                ("quadrants, window 4, 8 seg >= 2048 (else 4 >= 1024 not modelled)", dict(window=4, kU=4, map=0, seg_min=2048, nseg=8)),
                ]
