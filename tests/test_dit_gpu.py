@@ -353,6 +353,17 @@ def test_dopri5_on_the_golden_model_against_the_ode_oracle(gpu_device):
             return model.forward_with_cfg(torch.from_numpy(yy).float().to(gpu_device), tt, context=ctx,
                                           cfg_scale=z["cfg_scale"]).double().cpu().numpy()
 
+    # the fixed-grid reading of "250 steps" (euler; here through the fused on-device step) against the oracle integrator on
+    # the same function: same grid, same number of evaluations, same states
+    fn_e = sampler.sample_ode(sampling_method="euler", num_steps=n_out)
+    with torch.no_grad():
+        out_e = fn_e(x.to(gpu_device), model.forward_with_cfg, context=ctx, cfg_scale=z["cfg_scale"])
+    s_e = {}
+    same_e = oo.odeint(f_hip, x.double().numpy(), tgrid, method="euler", stats=s_e)
+    assert sampler.last_ode.last_stats["nfe"] == s_e["nfe"] == n_out - 1
+    assert rel_l2(out_e.cpu().double(), torch.from_numpy(same_e)) < 3e-3
+
+    fn = sampler.sample_ode(sampling_method="dopri5", num_steps=n_out, atol=1e-6, rtol=1e-3)
     s_same = {}
     same = oo.odeint(f_hip, x.double().numpy(), tgrid, method="dopri5", atol=1e-6, rtol=1e-3, stats=s_same)
     assert (s_hip["nfe"], s_hip["steps"], s_hip["rejected"]) == (s_same["nfe"], s_same["steps"], s_same["rejected"]), (s_hip, s_same)
