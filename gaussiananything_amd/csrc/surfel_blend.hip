@@ -153,28 +153,33 @@ __device__ __forceinline__ float pair_depth(const Rec &r, const Alpha &e)
     return e.use3d ? (d.x + d.y) + r.q3.z : r.q3.z;
 }
 
-__device__ __forceinline__ void composite(const Rec &r, const Alpha &e, PixelAcc &a, bool &done)
+// `go`: this lane really has this pair (a live entry of its list that passed the filters, pixel not finished).  The
+// update is branch-free: a pair that does not count enters with weight 0 and a harmless depth, so the wave executes one
+// straight instruction stream instead of an EXEC-masked region per entry (of the 312 VALU + 105 SALU instructions of a
+// four-entry trip, 41 v_mov and ~60 SALU were that masking and its register copies).  Measured: same time -- the trip
+// loop is as much LDS-bound (88 bytes gathered per entry, 12 waves on one LDS pipe) as VALU-bound.
+__device__ __forceinline__ void composite(const Rec &r, const Alpha &e, PixelAcc &a, bool &done, bool go)
 {
     const float kM = kFar / (kFar - kNear);
-    const float depth = pair_depth(r, e);
+    const float depth_raw = pair_depth(r, e);
+    const bool near_ok = go && !(depth_raw < kNear);        // upstream: depth < near -> skip (before the alpha test)
     const float test_T = a.T * (1.0f - e.alpha);
-    const bool near_ok = !(depth < kNear);            // upstream: depth < near -> skip (before the alpha test)
-    const bool stop = near_ok && test_T < 0.0001f;    // upstream: done = true
+    const bool stop = near_ok && test_T < 0.0001f;          // upstream: done = true
+    const bool use = near_ok && !stop;
     done = done || stop;
-    if (near_ok && !stop) {
-        const float w = e.alpha * a.T;
-        const float A = 1.0f - a.T;
-        const float m = kM * (1.0f - kNear * __builtin_amdgcn_rcpf(depth));
-        const f2 mm = f2{m, m * m};
-        a.dist += (mm.y * A + a.M.y - 2.0f * m * a.M.x) * w;
-        a.Dp += depth * w;
-        a.M += mm * w;
-        if (a.T > 0.5f) a.median = depth;
-        a.N01 += lo2(r.q4) * w;
-        a.N2C0 += hi2(r.q4) * w;
-        a.C12 += r.q5 * w;
-        a.T = test_T;
-    }
+    const float depth = use ? depth_raw : 1.0f;
+    const float w = use ? e.alpha * a.T : 0.0f;
+    const float A = 1.0f - a.T;
+    const float m = kM * (1.0f - kNear * __builtin_amdgcn_rcpf(depth));
+    const f2 mm = f2{m, m * m};
+    a.dist += (mm.y * A + a.M.y - 2.0f * m * a.M.x) * w;
+    a.Dp += depth * w;
+    a.M += mm * w;
+    a.median = (use && a.T > 0.5f) ? depth : a.median;
+    a.N01 += lo2(r.q4) * w;
+    a.N2C0 += hi2(r.q4) * w;
+    a.C12 += r.q5 * w;
+    a.T = use ? test_T : a.T;
 }
 
 struct Stats {
@@ -319,7 +324,7 @@ __device__ __forceinline__ void consume(Ring &ring, const Consumer &c, uint32_t 
         while (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
             int j[kU];
             bool live[kU];
-            int last = oldb;
+            int last = newb;   // (a staged slot: an exhausted lane reads finite values)
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 const bool has = cur != 0;
@@ -345,7 +350,7 @@ __device__ __forceinline__ void consume(Ring &ring, const Consumer &c, uint32_t 
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 if (FULL) {
-                    if (live[u] && e[u].pass && !done) composite(r[u], e[u], a, done);
+                    composite(r[u], e[u], a, done, live[u] && e[u].pass && !done);
                 } else {
                     const float depth = pair_depth(r[u], e[u]);
                     if (live[u] && e[u].pass && !done && !(depth < kNear)) {
