@@ -461,7 +461,7 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("GA_BENCH_FORCE_DIST"):   # (the variable lets a 1-GPU box walk the multi-rank code path)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
@@ -483,7 +483,7 @@ def main():
     plan.ensure_capacity()
     gathered = None
     payload = None
-    if world > 1:
+    if dist is not None:
         payload = torch.empty((a.views, 10, H, W), dtype=torch.float32, device=dev)
         gathered = torch.empty((world, a.views, 10, H, W), dtype=torch.float32, device=dev) if rank == 0 else None
 
@@ -510,7 +510,7 @@ def main():
     # the rasterizer: it is executed once here and timed on its own (the cascade section below times it where it belongs,
     # at the end of a whole sample)
     gather_ms = None
-    if world > 1:
+    if dist is not None:
         torch.cuda.synchronize()
         dist.barrier()
         tg = time.perf_counter()
@@ -612,10 +612,15 @@ def main():
             out["cascade"] = casc
             out["sec_per_sample"] = casc["sec_per_sample"]            # 250-step cascaded, euler; N samples on N GPUs
             out["sec_per_sample_dopri5"] = casc.get("dopri5", {}).get("sec_per_sample")
-    if rank == 0:
-        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        try:   # RCCL's version banner sits in the C stdio buffer: let it out BEFORE the one JSON line, not after it
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
