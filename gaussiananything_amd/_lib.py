@@ -40,6 +40,14 @@ class GaSurfelWorkspaceLayout(ctypes.Structure):
         "point_list", "seg_table", "seg_scratch", "total_bytes")]
 
 
+class GaSurfelBackwardArgs(ctypes.Structure):
+    """include/ga_surfel.h: GaSurfelBackwardArgs"""
+    _fields_ = [("fwd", GaSurfelForwardArgs), ("grad_color", ctypes.c_void_p), ("grad_others", ctypes.c_void_p),
+                ("scratch", ctypes.c_void_p), ("scratch_bytes", ctypes.c_size_t), ("grad_means3D", ctypes.c_void_p),
+                ("grad_opacities", ctypes.c_void_p), ("grad_colors", ctypes.c_void_p), ("grad_scales", ctypes.c_void_p),
+                ("grad_rotations", ctypes.c_void_p)]
+
+
 class GaSurfelPostArgs(ctypes.Structure):
     """include/ga_surfel.h: GaSurfelPostArgs"""
     _fields_ = [("num_views", ctypes.c_int32), ("image_height", ctypes.c_int32), ("image_width", ctypes.c_int32),
@@ -47,7 +55,8 @@ class GaSurfelPostArgs(ctypes.Structure):
                 ("image", ctypes.c_void_p), ("rend_normal", ctypes.c_void_p), ("depth", ctypes.c_void_p)]
 
 
-EXPORTS = ("ga_surfel_version", "ga_surfel_workspace_layout", "ga_surfel_forward", "ga_surfel_postprocess")
+EXPORTS = ("ga_surfel_version", "ga_surfel_workspace_layout", "ga_surfel_forward", "ga_surfel_postprocess",
+           "ga_surfel_backward", "ga_surfel_backward_scratch_bytes")
 
 _lib = None
 
@@ -77,6 +86,10 @@ def lib():
                                                                        ctypes.POINTER(GaSurfelWorkspaceLayout)]
         L.ga_surfel_forward.restype = ctypes.c_int
         L.ga_surfel_forward.argtypes = [ctypes.POINTER(GaSurfelForwardArgs), ctypes.c_void_p]
+        L.ga_surfel_backward.restype = ctypes.c_int
+        L.ga_surfel_backward.argtypes = [ctypes.POINTER(GaSurfelBackwardArgs), ctypes.c_void_p]
+        L.ga_surfel_backward_scratch_bytes.restype = ctypes.c_size_t
+        L.ga_surfel_backward_scratch_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
         L.ga_surfel_postprocess.restype = ctypes.c_int
         L.ga_surfel_postprocess.argtypes = [ctypes.POINTER(GaSurfelPostArgs), ctypes.c_void_p]
         _lib = L

@@ -91,7 +91,6 @@ def _f32c(t: torch.Tensor, name: str, device) -> torch.Tensor:
     return t.detach().contiguous().float()
 
 
-_warned_grad = False
 
 
 def postprocess_views(color, allmap, viewmatrix, image=None, rend_normal=None, depth=None):
@@ -116,9 +115,87 @@ def postprocess_views(color, allmap, viewmatrix, image=None, rend_normal=None, d
     return image, rend_normal, depth
 
 
+class _RasterizeViews(torch.autograd.Function):
+    """Differentiable ``rasterize_views``: forward = ``ga_surfel_forward`` on a workspace of its own (the backward reads the
+    tile ranges and point lists of exactly this call again), backward = ``ga_surfel_backward`` (gradients with respect to
+    means3D, opacities, colours, scales and rotations, summed over the views; include/ga_surfel.h)."""
+
+    @staticmethod
+    def forward(ctx, means3D, opacities, colors, scales, rotations, vm, pm, bg, h, w, scale_modifier):
+        n, v = means3D.shape[0], vm.shape[0]
+        ws = SurfelWorkspace(means3D.device, n, v, h, w, max(4 * n * v, 1 << 16))
+        while True:
+            color, radii, allmap, _ = _rasterize_views_nograd(means3D, opacities, colors, scales, rotations, vm, pm, bg, h, w,
+                                                              scale_modifier, workspace=ws, check_overflow=False)
+            st = ws.status().cpu()
+            if int(st[_lib.GA_STATUS_OVERFLOW]) == 0:
+                break
+            need = int(st[_lib.GA_STATUS_NUM_RENDERED])
+            ws = SurfelWorkspace(means3D.device, n, v, h, w, need + need // 4)
+        ctx.save_for_backward(means3D, opacities, colors, scales, rotations, vm, pm, bg, color, allmap, radii)
+        ctx.ws, ctx.geom = ws, (n, v, h, w, float(scale_modifier))
+        ctx.mark_non_differentiable(radii)
+        return color, radii, allmap
+
+    @staticmethod
+    def backward(ctx, g_color, g_radii, g_allmap):
+        means3D, opacities, colors, scales, rotations, vm, pm, bg, color, allmap, radii = ctx.saved_tensors
+        n, v, h, w, mod = ctx.geom
+        ws, dev = ctx.ws, means3D.device
+        g_color = torch.zeros_like(color) if g_color is None else g_color.detach().float().contiguous()
+        g_allmap = torch.zeros_like(allmap) if g_allmap is None else g_allmap.detach().float().contiguous()
+        L = _lib.lib()
+        scratch = torch.empty(int(L.ga_surfel_backward_scratch_bytes(n, v)) + 16, dtype=torch.uint8, device=dev)
+        d_means, d_op = torch.empty_like(means3D), torch.empty_like(opacities)
+        d_col, d_sc, d_rot = torch.empty_like(colors), torch.empty_like(scales), torch.empty_like(rotations)
+        fwd = _lib.GaSurfelForwardArgs(
+            n, v, h, w, mod, 0, means3D.data_ptr(), opacities.data_ptr(), colors.data_ptr(), scales.data_ptr(),
+            rotations.data_ptr(), vm.data_ptr(), pm.data_ptr(), bg.data_ptr(), color.data_ptr(), allmap.data_ptr(),
+            radii.data_ptr(), ws.ptr, ws.layout.total_bytes, ws.capacity, None)
+        args = _lib.GaSurfelBackwardArgs(fwd, g_color.data_ptr(), g_allmap.data_ptr(), scratch.data_ptr(), scratch.numel(),
+                                         d_means.data_ptr(), d_op.data_ptr(), d_col.data_ptr(), d_sc.data_ptr(), d_rot.data_ptr())
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(L.ga_surfel_backward(ctypes.byref(args), stream), "ga_surfel_backward")
+        return d_means, d_op, d_col, d_sc, d_rot, None, None, None, None, None, None
+
+
 def rasterize_views(means3D, opacities, colors_precomp, scales, rotations, viewmatrix, projmatrix, bg,
                     image_height, image_width, scale_modifier=1.0, workspace: Optional[SurfelWorkspace] = None,
                     check_overflow: bool = True, stage_events=None):
+    """``_rasterize_views_nograd`` (below), differentiable when autograd is recording and a Gaussian tensor requires grad:
+    ``color`` and ``allmap`` then carry a grad_fn whose backward is ``ga_surfel_backward`` (the median-depth channel and
+    ``radii`` are not differentiable; the workspace of such a call is its own)."""
+    if torch.is_grad_enabled() and any(getattr(t, "requires_grad", False) for t in
+                                       (means3D, opacities, colors_precomp, scales, rotations)):
+        device = means3D.device
+        m = _f32g(means3D, "means3D", device)
+        n = m.shape[0]
+        o = _f32g(opacities, "opacities", device).reshape(-1)
+        c, s, r = _f32g(colors_precomp, "colors_precomp", device), _f32g(scales, "scales", device), _f32g(rotations, "rotations", device)
+        if m.shape != (n, 3) or o.shape != (n,) or c.shape != (n, 3) or s.shape != (n, 2) or r.shape != (n, 4):
+            raise ValueError("expected means3D[N,3], opacities[N,1], colors_precomp[N,3], scales[N,2], rotations[N,4]")
+        vm = _f32c(viewmatrix, "viewmatrix", device).reshape(-1, 16)
+        pm = _f32c(projmatrix, "projmatrix", device).reshape(-1, 16)
+        color, radii, allmap = _RasterizeViews.apply(m, o, c, s, r, vm, pm, _f32c(bg, "bg", device).reshape(3),
+                                                     int(image_height), int(image_width), float(scale_modifier))
+        return color, radii, allmap, None
+    return _rasterize_views_nograd(means3D, opacities, colors_precomp, scales, rotations, viewmatrix, projmatrix, bg,
+                                   image_height, image_width, scale_modifier, workspace, check_overflow, stage_events)
+
+
+def _f32g(t: torch.Tensor, name: str, device) -> torch.Tensor:
+    """``_f32c`` that keeps the autograd graph."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if t.device.type != "cuda" or t.device != device:
+        raise RuntimeError(f"{name} is on {t.device}: the surfel rasterizer only runs on an MI355X (HIP) device; there is no CPU path")
+    return t.contiguous().float()
+
+
+def _rasterize_views_nograd(means3D, opacities, colors_precomp, scales, rotations, viewmatrix, projmatrix, bg,
+                            image_height, image_width, scale_modifier=1.0, workspace: Optional[SurfelWorkspace] = None,
+                            check_overflow: bool = True, stage_events=None):
     """Rasterize V views of one Gaussian set.  ``viewmatrix`` / ``projmatrix``: ``[V,4,4]`` row-vector matrices
     (``cam_view`` / ``cam_view_proj``).  Returns ``color [V,3,H,W]``, ``radii [V,N] int32``, ``allmap [V,7,H,W]`` and
     the workspace used (its ``status()`` holds D / overflow / longest tile list).
@@ -128,12 +205,7 @@ def rasterize_views(means3D, opacities, colors_precomp, scales, rotations, viewm
     caller inspects ``workspace.status()`` itself.  ``stage_events``: optional ctypes array of 5 ``hipEvent_t`` (see
     ``include/ga_surfel.h``), measurement only.
     """
-    global _warned_grad
     device = means3D.device
-    if torch.is_grad_enabled() and any(getattr(t, "requires_grad", False) for t in
-                                       (means3D, opacities, colors_precomp, scales, rotations)) and not _warned_grad:
-        warnings.warn("gaussiananything_amd surfel rasterizer is forward-only in this tier: outputs carry no grad_fn")
-        _warned_grad = True
     means3D = _f32c(means3D, "means3D", device)
     n = means3D.shape[0]
     opacities = _f32c(opacities, "opacities", device).reshape(-1)
@@ -182,7 +254,9 @@ def rasterize_views(means3D, opacities, colors_precomp, scales, rotations, viewm
 
 
 class GaussianRasterizer(nn.Module):
-    """Same surface as ``diff_surfel_rasterization.GaussianRasterizer`` (forward only)."""
+    """Same surface as ``diff_surfel_rasterization.GaussianRasterizer``; differentiable with respect to means3D, opacities,
+    colors_precomp, scales and rotations (``means2D`` is accepted and ignored: the reference passes zeros without
+    requires_grad, /root/reference/nsr/gs_surfel.py:104-106, and never reads its gradient)."""
 
     def __init__(self, raster_settings: GaussianRasterizationSettings):
         super().__init__()

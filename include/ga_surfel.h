@@ -128,6 +128,30 @@ typedef struct GaSurfelPostArgs {
 } GaSurfelPostArgs;
 int ga_surfel_postprocess(const GaSurfelPostArgs *args, void *stream);
 
+/* host: BACKWARD of ga_surfel_forward (the gradient the reference's training call sites take through
+ * GaussianRasterizer(...)(means3D, means2D, ...), /root/reference/nsr/gs_surfel.py:104-114; upstream backward.cu is third
+ * party and absent: oracle/surfel_autograd.py is the oracle).  `fwd` is the argument block of the forward call it
+ * differentiates, UNCHANGED, with the workspace as that call left it (tile ranges and point lists are read again) and its
+ * outputs out_color / out_others / radii.  grad_color [V,3,H,W] and grad_others [V,7,H,W] are dL/d(out_color) and
+ * dL/d(out_others); the gradients with respect to the Gaussians are summed over the views.  The selection
+ * min(rho3d, rho2d), the alpha / depth / transmittance tests, the 0.99 clamp, the normal's facing sign and the median depth
+ * (channel 5 of out_others) are constants of the gradient.  Nothing is allocated; `scratch` holds
+ * ga_surfel_backward_scratch_bytes(N, V) bytes. */
+typedef struct GaSurfelBackwardArgs {
+    GaSurfelForwardArgs fwd;
+    const float *grad_color;   /* [V,3,H,W]                                                      */
+    const float *grad_others;  /* [V,7,H,W]                                                      */
+    void *scratch;
+    size_t scratch_bytes;
+    float *grad_means3D;       /* [N,3]  (all five are overwritten)                              */
+    float *grad_opacities;     /* [N]                                                            */
+    float *grad_colors;        /* [N,3]                                                          */
+    float *grad_scales;        /* [N,2]                                                          */
+    float *grad_rotations;     /* [N,4]  with respect to the quaternion as given (not normalised) */
+} GaSurfelBackwardArgs;
+size_t ga_surfel_backward_scratch_bytes(int32_t num_points, int32_t num_views);
+int ga_surfel_backward(const GaSurfelBackwardArgs *args, void *stream);
+
 /* host: library identification, e.g. "ga_mi355 surfel gfx950 r1" */
 const char *ga_surfel_version(void);
 
