@@ -22,11 +22,13 @@
 //   3. surfel_preprocess_bwd_kernel per (view, Gaussian): through M = Hm P N_pix (and the bounding-box centre formula for the
 //      low-pass filter's centre), the view rotation of the normal and the normalised quaternion to means3D, scales, rotations,
 //      opacities and colours, summed over the views with atomics.
+#include <hip/hip_fp16.h>
+
 #include "surfel_common.h"
 
 namespace ga {
 
-constexpr int kBRec = 24;    // backward record floats: Tu(3) Tv(3) Tw(3) xy(2) opa nv(3) rgb(3) | pad
+constexpr int kBRec = 24;    // backward record floats: Tu(3) Tv(3) Tw(3) xy(2) opa nv(3) rgb(3) | cull half-extents rx ry | pad
 constexpr int kGRec = 18;    // gradient record floats: dTu(3) dTv(3) dTw(3) dxy(2) dopa dnv(3) drgb(3)
 constexpr int kBwdChunk = 128;
 
@@ -85,8 +87,8 @@ __global__ __launch_bounds__(256) void surfel_bwd_record_kernel(const float *__r
                                                                 const float *__restrict__ colors, const float *__restrict__ scales,
                                                                 const float *__restrict__ rotations, const float *__restrict__ viewmatrix,
                                                                 const float *__restrict__ projmatrix, float scale_modifier, Dims dm,
-                                                                const int32_t *__restrict__ radii, float *__restrict__ brec,
-                                                                float *__restrict__ grec)
+                                                                const int32_t *__restrict__ radii, const float *__restrict__ fwd_record,
+                                                                float *__restrict__ brec, float *__restrict__ grec)
 {
     const int v = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= dm.N) return;
@@ -99,6 +101,11 @@ __global__ __launch_bounds__(256) void surfel_bwd_record_kernel(const float *__r
     float *b = brec + idx * kBRec;
     for (int a = 0; a < 3; ++a) { b[a] = s.Tu[a]; b[3 + a] = s.Tv[a]; b[6 + a] = s.Tw[a]; b[12 + a] = s.nv[a]; b[15 + a] = colors[3 * i + a]; }
     b[9] = s.cx; b[10] = s.cy; b[11] = opacities[i];
+    // the forward's conservative {alpha >= 1/255} box (two fp16 half-extents about the centre, surfel_common.h): pairs outside
+    // it were not evaluated by the forward and contribute nothing here either
+    const uint32_t cull = __float_as_uint(fwd_record[idx * kRec + 15]);
+    b[18] = __half2float(__ushort_as_half((unsigned short)(cull & 0xffffu)));
+    b[19] = __half2float(__ushort_as_half((unsigned short)(cull >> 16)));
 }
 
 // one (pixel, entry) evaluation: the forward's arithmetic (oracle_blend) with what the gradient needs kept
@@ -110,11 +117,12 @@ struct PairFwd {
 __device__ __forceinline__ void pair_forward(const float *__restrict__ b, float pxf, float pyf, PairFwd &o)
 {
     const float *Tu = b, *Tv = b + 3, *Tw = b + 6;
+    o.ok = false;
+    if (!(fabsf(pxf - b[9]) <= b[18]) || !(fabsf(pyf - b[10]) <= b[19])) return;   // outside the cull box
     for (int a = 0; a < 3; ++a) { o.k[a] = pxf * Tw[a] - Tu[a]; o.l[a] = pyf * Tw[a] - Tv[a]; }
     o.p[0] = o.k[1] * o.l[2] - o.k[2] * o.l[1];
     o.p[1] = o.k[2] * o.l[0] - o.k[0] * o.l[2];
     o.p[2] = o.k[0] * o.l[1] - o.k[1] * o.l[0];
-    o.ok = false;
     if (o.p[2] == 0.0f) return;
     o.sx = o.p[0] / o.p[2]; o.sy = o.p[1] / o.p[2];
     const float rho3d = o.sx * o.sx + o.sy * o.sy;
@@ -354,7 +362,8 @@ extern "C" int ga_surfel_backward(const GaSurfelBackwardArgs *a, void *stream_v)
     (void)hipMemsetAsync(a->grad_rotations, 0, (size_t)d.N * 4 * 4, s);
     const dim3 gridN((unsigned)((d.N + 255) / 256), (unsigned)d.V);
     hipLaunchKernelGGL(surfel_bwd_record_kernel, gridN, dim3(256), 0, s, f.means3D, f.opacities, f.colors, f.scales, f.rotations,
-                       f.viewmatrix, f.projmatrix, f.scale_modifier, d, f.radii, brec, grec);
+                       f.viewmatrix, f.projmatrix, f.scale_modifier, d, f.radii, reinterpret_cast<const float *>(w + L.record), brec,
+                       grec);
     hipLaunchKernelGGL(surfel_blend_bwd_kernel, dim3((unsigned)(d.V * d.tiles)), dim3(256), 0, s, tile_start, point_list, brec, f.bg, d,
                        f.out_color, f.out_others, a->grad_color, a->grad_others, grec, status);
     hipLaunchKernelGGL(surfel_preprocess_bwd_kernel, gridN, dim3(256), 0, s, f.means3D, f.scales, f.rotations, f.viewmatrix,

@@ -33,6 +33,22 @@ class GaussianRenderer2DGS:
 
         S = output_size
         dev = gaussians.device
+        if torch.is_grad_enabled() and gaussians.requires_grad:
+            # training call sites: the rasterizer is differentiable (ga_surfel_backward); the renderer-level post-processing
+            # then runs as the reference writes it (nsr/gs_surfel.py:121-163), in PyTorch, so that autograd sees it
+            outs = {k: [] for k in ("image", "alpha", "depth", "rend_normal", "dist")}
+            for b in range(B):
+                g = gaussians[b]
+                view = cam_view[b].float()
+                color, _radii, allmap, _ = rasterize_views(
+                    g[:, 0:3], g[:, 3:4], g[:, 10:13], g[:, 4:6], g[:, 6:10], view, cam_view_proj[b].float(),
+                    bg_color.to(g.device), S, S, scale_modifier)
+                outs["image"].append(color.clamp(0, 1))
+                outs["alpha"].append(allmap[:, 1:2])
+                outs["rend_normal"].append(torch.einsum("vchw,vdc->vdhw", allmap[:, 2:5], view[:, :3, :3]))
+                outs["depth"].append(torch.nan_to_num(allmap[:, 5:6], 0, 0))
+                outs["dist"].append(allmap[:, 6:7])
+            return {k: torch.stack(v, dim=0) for k, v in outs.items()}
         image = torch.empty((B, V, 3, S, S), dtype=torch.float32, device=dev)
         rend_normal = torch.empty((B, V, 3, S, S), dtype=torch.float32, device=dev)
         depth = torch.empty((B, V, 1, S, S), dtype=torch.float32, device=dev)

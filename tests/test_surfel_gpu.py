@@ -370,3 +370,20 @@ def test_rasterizer_module_is_differentiable(gpu_device):
     (image.mean() + allmap[1].mean() + 0.1 * allmap[6].mean()).backward()
     for t in (m, op, sc, rot, rgb):
         assert t.grad is not None and bool(torch.isfinite(t.grad).all()) and float(t.grad.abs().max()) > 0
+
+
+def test_renderer_is_differentiable_end_to_end(gpu_device):
+    """GaussianRenderer2DGS.render with a Gaussian tensor that requires grad (training call sites, nsr/gs_surfel.py:41-202):
+    same outputs as the inference path, and the gradient of a loss on image + alpha + normal + distortion reaches it."""
+    from gaussiananything_amd.gs_surfel import GaussianRenderer2DGS
+    cams = synthetic.eval_cameras(3)
+    g = synthetic.random_surfels(800, seed=4).to(gpu_device)
+    r = GaussianRenderer2DGS(64, 3, {})
+    cv, cvp, cp = (cams[k][None].to(gpu_device) for k in ("cam_view", "cam_view_proj", "cam_pos"))
+    ref = r.render(g, cv, cvp, cp, cams["tanfov"])
+    gg = g.clone().requires_grad_(True)
+    out = r.render(gg, cv, cvp, cp, cams["tanfov"])
+    for k in ("image", "alpha", "depth", "rend_normal", "dist"):
+        assert out[k].shape == ref[k].shape and float((out[k] - ref[k]).abs().max()) < 1e-5, k
+    (out["image"].mean() + out["alpha"].mean() + out["rend_normal"].square().mean() + out["dist"].mean()).backward()
+    assert gg.grad is not None and bool(torch.isfinite(gg.grad).all()) and float(gg.grad.abs().max()) > 0
