@@ -89,7 +89,7 @@ def lib():
         L.ga_surfel_backward.restype = ctypes.c_int
         L.ga_surfel_backward.argtypes = [ctypes.POINTER(GaSurfelBackwardArgs), ctypes.c_void_p]
         L.ga_surfel_backward_scratch_bytes.restype = ctypes.c_size_t
-        L.ga_surfel_backward_scratch_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
+        L.ga_surfel_backward_scratch_bytes.argtypes = [ctypes.POINTER(GaSurfelForwardArgs)]
         L.ga_surfel_postprocess.restype = ctypes.c_int
         L.ga_surfel_postprocess.argtypes = [ctypes.POINTER(GaSurfelPostArgs), ctypes.c_void_p]
         _lib = L

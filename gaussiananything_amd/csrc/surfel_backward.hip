@@ -31,6 +31,9 @@ namespace ga {
 constexpr int kBRec = 24;    // backward record floats: Tu(3) Tv(3) Tw(3) xy(2) opa nv(3) rgb(3) | cull half-extents rx ry | pad
 constexpr int kGRec = 18;    // gradient record floats: dTu(3) dTv(3) dTw(3) dxy(2) dopa dnv(3) drgb(3)
 constexpr int kBwdChunk = 128;
+#ifndef GA_BWD_WAVE_MAJOR_LANES
+#define GA_BWD_WAVE_MAJOR_LANES 12   // a wave walks entry-major when its entries are evaluated by this many of its lanes on average
+#endif
 
 struct SplatFwd {   // the forward's per-splat quantities (surfel_preprocess.hip / oracle_preprocess, same formulas)
     float Tu[3], Tv[3], Tw[3], cx, cy, nv[3], mult;
@@ -108,160 +111,465 @@ __global__ __launch_bounds__(256) void surfel_bwd_record_kernel(const float *__r
     b[19] = __half2float(__ushort_as_half((unsigned short)(cull >> 16)));
 }
 
-// one (pixel, entry) evaluation: the forward's arithmetic (oracle_blend) with what the gradient needs kept
+// one (pixel, entry) evaluation: the forward's arithmetic (oracle_blend) with what the gradient needs kept.  The record is
+// read from the workgroup's LDS image, one plane per field (b[f * kBwdChunk]), so that lanes on different entries hit
+// different banks.
 struct PairFwd {
-    float k[3], l[3], p[3], sx, sy, rho, G, raw, alpha, depth, dxc, dyc;
+    float k[3], l[3], p[3], Tw[3], rz, sx, sy, rho, G, raw, alpha, depth, dxc, dyc;
     bool use3d, ok;
 };
 
+#define GA_BF(f) b[(f) * kBwdChunk]
+
+// (reciprocal and exponential as the forward kernel takes them: v_rcp_f32 / v_exp_f32, surfel_blend.hip)
 __device__ __forceinline__ void pair_forward(const float *__restrict__ b, float pxf, float pyf, PairFwd &o)
 {
-    const float *Tu = b, *Tv = b + 3, *Tw = b + 6;
     o.ok = false;
-    if (!(fabsf(pxf - b[9]) <= b[18]) || !(fabsf(pyf - b[10]) <= b[19])) return;   // outside the cull box
-    for (int a = 0; a < 3; ++a) { o.k[a] = pxf * Tw[a] - Tu[a]; o.l[a] = pyf * Tw[a] - Tv[a]; }
+    for (int a = 0; a < 3; ++a) {
+        o.Tw[a] = GA_BF(6 + a);
+        o.k[a] = pxf * o.Tw[a] - GA_BF(a);
+        o.l[a] = pyf * o.Tw[a] - GA_BF(3 + a);
+    }
     o.p[0] = o.k[1] * o.l[2] - o.k[2] * o.l[1];
     o.p[1] = o.k[2] * o.l[0] - o.k[0] * o.l[2];
     o.p[2] = o.k[0] * o.l[1] - o.k[1] * o.l[0];
     if (o.p[2] == 0.0f) return;
-    o.sx = o.p[0] / o.p[2]; o.sy = o.p[1] / o.p[2];
+    o.rz = __builtin_amdgcn_rcpf(o.p[2]);
+    o.sx = o.p[0] * o.rz; o.sy = o.p[1] * o.rz;
     const float rho3d = o.sx * o.sx + o.sy * o.sy;
-    o.dxc = b[9] - pxf; o.dyc = b[10] - pyf;
+    o.dxc = GA_BF(9) - pxf; o.dyc = GA_BF(10) - pyf;
     const float rho2d = kFilterInvSquare * (o.dxc * o.dxc + o.dyc * o.dyc);
     o.use3d = rho3d <= rho2d;
     o.rho = fminf(rho3d, rho2d);
-    o.depth = o.use3d ? (o.sx * Tw[0] + o.sy * Tw[1]) + Tw[2] : Tw[2];
+    o.depth = o.use3d ? (o.sx * o.Tw[0] + o.sy * o.Tw[1]) + o.Tw[2] : o.Tw[2];
     if (o.depth < kNear) return;
-    if (-0.5f * o.rho > 0.0f) return;
-    o.G = expf(-0.5f * o.rho);
-    o.raw = b[11] * o.G;
+    if (o.rho < 0.0f) return;
+    o.G = __builtin_amdgcn_exp2f(o.rho * -0.72134752044f);
+    o.raw = GA_BF(11) * o.G;
     o.alpha = fminf(0.99f, o.raw);
     if (o.alpha < 1.0f / 255.0f) return;
     o.ok = true;
 }
 
-__global__ __launch_bounds__(256) void surfel_blend_bwd_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
-                                                               const float *__restrict__ brec, const float *__restrict__ bg, Dims dm,
-                                                               const float *__restrict__ out_color, const float *__restrict__ out_others,
-                                                               const float *__restrict__ g_color, const float *__restrict__ g_others,
-                                                               float *__restrict__ grec, const int64_t *__restrict__ status)
-{
-    __shared__ float srec[kBwdChunk][kBRec];
-    __shared__ float sgrad[kBwdChunk][kGRec + 1];   // (+1: the 18 words of neighbouring entries start in different banks)
-    __shared__ uint32_t sid[kBwdChunk];
-    if (status[GA_STATUS_OVERFLOW]) return;
-    const int vt = blockIdx.x, v = vt / dm.tiles, tile = vt - v * dm.tiles;
-    const int tx = tile % dm.gx, ty = tile / dm.gx;
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int pxi = tx * kTile + lx, pyi = ty * kTile + ly;
-    const bool inside = pxi < dm.W && pyi < dm.H;
-    const float pxf = (float)pxi, pyf = (float)pyi;
-    const uint32_t beg = tile_start[vt], end = tile_start[vt + 1];
-    if (beg == end) return;
-    const float kM = kFar / (kFar - kNear);
-    const size_t HW = (size_t)dm.H * dm.W, pid = (size_t)pyi * dm.W + pxi;
-    const size_t vbase = (size_t)v * dm.N;
+// ---- the blend backward, one workgroup per 128-entry SEGMENT of a tile's list -------------------------------------------
+// A tile's list is cut into segments of kBwdSeg entries and every segment is a workgroup of its own in each of three
+// launches, so that the longest list of a view (thousands of entries) is no longer one workgroup's serial walk:
+//   trans  T_seg(pixel) = prod (1 - alpha) over the segment's contributing entries;
+//   sums   with T_start = prod of the earlier segments' T_seg (a pixel whose T_start is below 1e-4 terminated earlier:
+//          the test that ends a walk fires at the entry that would take T below 1e-4, and T only falls): the forward walk
+//          of the segment with its termination, leaving W' = sum w, M1' = sum w m, M2' = sum w m^2,
+//          A' = sum w (gC.c + gN.n + gD d) and the transmittance the pixel leaves the segment with;
+//   grad   totals and prefixes from the tile's segments (W, M1, M2, V = sum A' + 2 gDist (W M2 - M1^2), the final
+//          transmittance, P_start = sum over earlier segments of A' + gDist (W M2' - 2 M1 M1' + M2 W')), then the
+//          gradient walk of the segment.
+// Shared by the three: the segment's records in LDS by field plane, and per 64-entry half the survivor masks -- bit e of
+// col[h][c] says that column c of the tile lies inside entry e's cull box, row[h][r] likewise; a pixel's survivors are
+// col & row, so a lane walks only the entries the forward evaluated for its pixel (4 % of all pairs at BASELINE configs[1]).
+constexpr int kBwdSeg = kBwdChunk;
 
-    auto stage = [&](uint32_t cbeg, uint32_t cn) {
-        __syncthreads();   // everybody has left the previous chunk
-        for (uint32_t e = threadIdx.x; e < cn; e += 256) sid[e] = point_list[cbeg + e];
-        for (uint32_t w = threadIdx.x; w < cn * (kGRec + 1); w += 256) (&sgrad[0][0])[w] = 0.0f;
+struct BwdShared {
+    float rec[kBRec][kBwdChunk];
+    unsigned long long col[2][kTile], row[2][kTile];
+    unsigned long long call[2], rowstrip[2][4];   // union of the columns' masks; of the rows of each wave's strip
+    uint32_t id[kBwdChunk];
+};
+
+struct BwdPlan {   // the segment table and the per-(segment, pixel) exchange arrays, all inside `scratch`
+    uint32_t *seg_base;     // [V tiles + 1] first segment of every tile's list; the last word is the number of segments
+    uint32_t *seg_owner;    // [max_segs] the (view, tile) a segment belongs to
+    float *Tseg;            // [max_segs][256]
+    float *Tend;            // [max_segs][256]
+    float4 *part;           // [max_segs][256]  W', M1', M2', A'
+    uint32_t max_segs;
+};
+
+// Sums of 18 words over the wavefront in 5 registers: halves of the wave exchanged between pairs of words
+// (v_permlane32_swap: one add then carries two words, 32 lanes each), rows of 16 lanes between pairs of those
+// (v_permlane16_swap: four words per register, one per row), then an inclusive scan along each row (DPP).  The totals end
+// in the last lane of every row: of word 4 i + {0, 2, 1, 3}[row] in q[i] (i < 4), of word 16 (rows 0, 1) / 17 (rows 2, 3) in
+// q[4].  All 64 lanes must be active.
+// (inline assembly: the second result of __builtin_amdgcn_permlane{16,32}_swap comes back as a copy of the first with this
+// compiler -- tools/swap_test.hip; the s_nop pairs cover the VALU-write -> swap-read and swap-write -> VALU-read
+// wait states, which the hazard recogniser does not see through an asm statement)
+__device__ __forceinline__ void swap_halves(float &a, float &b)
+{
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap_rows(float &a, float &b)
+{
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+template <int kCtrl>
+__device__ __forceinline__ float dpp_row(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), kCtrl, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void wave_totals18(const float (&w)[18], float (&q)[5])
+{
+    float r[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { float a = w[2 * j], b = w[2 * j + 1]; swap_halves(a, b); r[j] = a + b; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { float a = r[2 * i], b = r[2 * i + 1]; swap_rows(a, b); q[i] = a + b; }
+    { float a = r[8], b = r[8]; asm("" : "+v"(b)); swap_rows(a, b); q[4] = a + b; }   // (two registers: the swap is in place)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) q[i] += dpp_row<0x111>(q[i]);   // row_shr:1
+#pragma unroll
+    for (int i = 0; i < 5; ++i) q[i] += dpp_row<0x112>(q[i]);   // row_shr:2
+#pragma unroll
+    for (int i = 0; i < 5; ++i) q[i] += dpp_row<0x114>(q[i]);   // row_shr:4
+#pragma unroll
+    for (int i = 0; i < 5; ++i) q[i] += dpp_row<0x118>(q[i]);   // row_shr:8
+}
+
+// number of segments of every tile's list, their exclusive prefix and the owner of every segment (one workgroup)
+__global__ __launch_bounds__(1024) void surfel_bwd_segtable_kernel(const uint32_t *__restrict__ tile_start, int vtiles, BwdPlan pl,
+                                                                  const int64_t *__restrict__ status)
+{
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry;
+    if (status[GA_STATUS_OVERFLOW]) { if (threadIdx.x == 0) pl.seg_base[vtiles] = 0; return; }
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int base = 0; base < vtiles; base += 1024) {
+        const int vt = base + (int)threadIdx.x;
+        uint32_t n = 0;
+        if (vt < vtiles) n = (tile_start[vt + 1] - tile_start[vt] + kBwdSeg - 1) / kBwdSeg;
+        uint32_t inc = n;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wave_tot[wv] = inc;
         __syncthreads();
-        for (uint32_t w = threadIdx.x; w < cn * kBRec; w += 256) {
-            const uint32_t e = w / kBRec, f = w - e * kBRec;
-            srec[e][f] = brec[(vbase + sid[e]) * kBRec + f];
+        uint32_t off = carry;
+        for (int w = 0; w < wv; ++w) off += wave_tot[w];
+        const uint32_t first = off + inc - n;
+        if (vt < vtiles) {
+            pl.seg_base[vt] = first;
+            for (uint32_t j = 0; j < n; ++j)
+                if (first + j < pl.max_segs) pl.seg_owner[first + j] = (uint32_t)vt;
         }
         __syncthreads();
+        if (threadIdx.x == 1023) carry = off + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) pl.seg_base[vtiles] = carry;
+}
+
+struct SegCtx {
+    int vt, v, tx, ty, k, nseg;      // (view, tile), this segment's index within the tile's list, the list's segments
+    uint32_t s0, cbeg, cn;           // first segment of the tile; this segment's entries
+    int pxi, pyi;
+    bool inside;
+    float pxf, pyf;
+    size_t vbase;
+};
+
+__device__ __forceinline__ bool seg_context(const uint32_t *__restrict__ tile_start, const BwdPlan &pl, const Dims &dm, SegCtx &c)
+{
+    const int vtiles = dm.V * dm.tiles;
+    const uint32_t s = blockIdx.x;
+    if (s >= pl.seg_base[vtiles] || s >= pl.max_segs) return false;
+    c.vt = (int)pl.seg_owner[s];
+    c.s0 = pl.seg_base[c.vt];
+    c.k = (int)(s - c.s0);
+    c.v = c.vt / dm.tiles;
+    const int tile = c.vt - c.v * dm.tiles;
+    c.tx = tile % dm.gx; c.ty = tile / dm.gx;
+    const uint32_t beg = tile_start[c.vt], end = tile_start[c.vt + 1];
+    c.nseg = (int)((end - beg + kBwdSeg - 1) / kBwdSeg);
+    c.cbeg = beg + (uint32_t)c.k * kBwdSeg;
+    c.cn = min((uint32_t)kBwdSeg, end - c.cbeg);
+    c.pxi = c.tx * kTile + (int)(threadIdx.x & 15);
+    c.pyi = c.ty * kTile + (int)(threadIdx.x >> 4);
+    c.inside = c.pxi < dm.W && c.pyi < dm.H;
+    c.pxf = (float)c.pxi; c.pyf = (float)c.pyi;
+    c.vbase = (size_t)c.v * dm.N;
+    return true;
+}
+
+// stage the segment: records to the field planes (kFields of them), survivor masks of my pixel
+template <int kFields>
+__device__ __forceinline__ void stage_segment(BwdShared &sh, const SegCtx &c, const uint32_t *__restrict__ point_list,
+                                              const float *__restrict__ brec, unsigned long long &m0, unsigned long long &m1)
+{
+    const int se = threadIdx.x & (kBwdChunk - 1), spart = threadIdx.x / kBwdChunk;   // entry, half of its record
+    float bx = 0.f, by = 0.f, rx = -1.f, ry = -1.f;   // (an absent entry's box is empty)
+    if ((uint32_t)se < c.cn) {
+        const uint32_t id = point_list[c.cbeg + se];
+        if (spart == 0) sh.id[se] = id;
+        const float4 *src = reinterpret_cast<const float4 *>(brec + (c.vbase + id) * kBRec) + 3 * spart;
+        if (spart == 0) {
+            const float4 q0 = src[0], q1 = src[1], q2 = src[2];
+            sh.rec[0][se] = q0.x; sh.rec[1][se] = q0.y; sh.rec[2][se] = q0.z; sh.rec[3][se] = q0.w;
+            sh.rec[4][se] = q1.x; sh.rec[5][se] = q1.y; sh.rec[6][se] = q1.z; sh.rec[7][se] = q1.w;
+            sh.rec[8][se] = q2.x; sh.rec[9][se] = q2.y; sh.rec[10][se] = q2.z; sh.rec[11][se] = q2.w;
+            bx = q2.y; by = q2.z;
+        } else {
+            const float4 q1 = src[1];
+            sh.rec[18][se] = q1.z; sh.rec[19][se] = q1.w;
+            if (kFields > 12) {
+                const float4 q0 = src[0];
+                sh.rec[12][se] = q0.x; sh.rec[13][se] = q0.y; sh.rec[14][se] = q0.z; sh.rec[15][se] = q0.w;
+                sh.rec[16][se] = q1.x; sh.rec[17][se] = q1.y;
+            }
+        }
+    }
+    // waves 0,1 hold the centres of entries 0..63 / 64..127, waves 2,3 their half-extents: hand the half-extents over
+    __syncthreads();
+    if (spart == 0) {
+        if ((uint32_t)se < c.cn) { rx = sh.rec[18][se]; ry = sh.rec[19][se]; }
+        const int h = se >> 6;
+        const float ox = bx - (float)(c.tx * kTile), oy = by - (float)(c.ty * kTile);
+        unsigned long long call = 0ull, rs = 0ull;
+        for (int q = 0; q < kTile; ++q) {
+            const unsigned long long mc = __ballot(fabsf((float)q - ox) <= rx);
+            const unsigned long long mr = __ballot(fabsf((float)q - oy) <= ry);
+            call |= mc; rs |= mr;
+            if ((se & 63) == 0) { sh.col[h][q] = mc; sh.row[h][q] = mr; }
+            if ((q & 3) == 3) { if ((se & 63) == 0) sh.rowstrip[h][q >> 2] = rs; rs = 0ull; }
+        }
+        if ((se & 63) == 0) sh.call[h] = call;
+    }
+    __syncthreads();
+    m0 = sh.col[0][threadIdx.x & 15] & sh.row[0][threadIdx.x >> 4];
+    m1 = sh.col[1][threadIdx.x & 15] & sh.row[1][threadIdx.x >> 4];
+}
+
+// transmittance my pixel enters segment k with (the product of the earlier segments' T_seg, in list order)
+__device__ __forceinline__ float seg_T_start(const BwdPlan &pl, const SegCtx &c)
+{
+    float T = 1.0f;
+    for (int j = 0; j < c.k; ++j) T *= pl.Tseg[(size_t)(c.s0 + j) * 256 + threadIdx.x];
+    return T;
+}
+
+__global__ __launch_bounds__(256) void surfel_bwd_trans_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+                                                               const float *__restrict__ brec, Dims dm, BwdPlan pl)
+{
+    __shared__ BwdShared sh;
+    SegCtx c;
+    if (!seg_context(tile_start, pl, dm, c)) return;
+    unsigned long long m[2];
+    stage_segment<12>(sh, c, point_list, brec, m[0], m[1]);
+    float T = 1.0f;
+    for (int h = 0; h < 2; ++h) {
+        unsigned long long mm = c.inside ? m[h] : 0ull;
+        while (mm) {
+            const int e = __builtin_ctzll(mm) + 64 * h;
+            mm &= mm - 1;
+            PairFwd f;
+            pair_forward(&sh.rec[0][e], c.pxf, c.pyf, f);
+            if (f.ok) T *= 1.0f - f.alpha;
+        }
+    }
+    pl.Tseg[(size_t)blockIdx.x * 256 + threadIdx.x] = T;
+}
+
+struct PixelGrads { float gC[3], gN[3], gD, gA, gDist; };
+
+__device__ __forceinline__ void load_pixel_grads(const float *__restrict__ g_color, const float *__restrict__ g_others, const Dims &dm,
+                                                 const SegCtx &c, PixelGrads &o)
+{
+    for (int q = 0; q < 3; ++q) { o.gC[q] = 0.f; o.gN[q] = 0.f; }
+    o.gD = 0.f; o.gA = 0.f; o.gDist = 0.f;
+    if (!c.inside) return;
+    const size_t HW = (size_t)dm.H * dm.W, pid = (size_t)c.pyi * dm.W + c.pxi;
+    for (int q = 0; q < 3; ++q) o.gC[q] = g_color[((size_t)c.v * 3 + q) * HW + pid];
+    const float *go = g_others + (size_t)c.v * 7 * HW + pid;
+    o.gD = go[0]; o.gA = go[HW]; o.gN[0] = go[2 * HW]; o.gN[1] = go[3 * HW]; o.gN[2] = go[4 * HW]; o.gDist = go[6 * HW];
+}
+
+__global__ __launch_bounds__(256) void surfel_bwd_sums_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+                                                              const float *__restrict__ brec, Dims dm, BwdPlan pl,
+                                                              const float *__restrict__ g_color, const float *__restrict__ g_others)
+{
+    __shared__ BwdShared sh;
+    SegCtx c;
+    if (!seg_context(tile_start, pl, dm, c)) return;
+    const float kM = kFar / (kFar - kNear);
+    float T = seg_T_start(pl, c);
+    bool done = !c.inside || T < 0.0001f;
+    float W = 0.f, M1 = 0.f, M2 = 0.f, A = 0.f;
+    const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (!__syncthreads_and(done)) {
+        PixelGrads pg;
+        load_pixel_grads(g_color, g_others, dm, c, pg);
+        unsigned long long m[2];
+        stage_segment<kBRec>(sh, c, point_list, brec, m[0], m[1]);
+        for (int h = 0; h < 2; ++h) {
+            unsigned long long mm = done ? 0ull : m[h];
+            while (mm) {
+                const int e = __builtin_ctzll(mm) + 64 * h;
+                mm &= mm - 1;
+                const float *b = &sh.rec[0][e];
+                PairFwd f;
+                pair_forward(b, c.pxf, c.pyf, f);
+                if (!f.ok) continue;
+                const float test_T = T * (1.0f - f.alpha);
+                if (test_T < 0.0001f) { done = true; break; }
+                const float w = f.alpha * T, mz = kM * (1.0f - kNear * __builtin_amdgcn_rcpf(f.depth));
+                W += w; M1 += mz * w; M2 += mz * mz * w;
+                A += w * ((pg.gC[0] * GA_BF(15) + pg.gC[1] * GA_BF(16) + pg.gC[2] * GA_BF(17)) +
+                          (pg.gN[0] * GA_BF(12) + pg.gN[1] * GA_BF(13) + pg.gN[2] * GA_BF(14)) + pg.gD * f.depth);
+                T = test_T;
+            }
+        }
+    }
+    pl.part[slot] = make_float4(W, M1, M2, A);
+    pl.Tend[slot] = T;
+}
+
+// Two ways to walk a 64-entry half of the segment, chosen per wave from its survivor masks:
+//   lane-major   every lane walks its own survivors and adds its 18 words to the segment's gradient image with LDS atomics:
+//                no idle lanes beyond the spread of the list lengths, but lanes on the same entry serialise on its words;
+//   entry-major  the wave walks the union of its lanes' survivors, all lanes evaluate the same entry (one broadcast record
+//                read), the words are summed across the wave (wave_totals18) and four lanes add the totals: cheaper as soon
+//                as an entry is evaluated by GA_BWD_WAVE_MAJOR_LANES lanes of the wave on average (large splats).
+__global__ __launch_bounds__(256) void surfel_bwd_grad_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+                                                              const float *__restrict__ brec, const float *__restrict__ bg, Dims dm, BwdPlan pl,
+                                                              const float *__restrict__ g_color, const float *__restrict__ g_others,
+                                                              float *__restrict__ grec)
+{
+    __shared__ BwdShared sh;
+    __shared__ float sgrad[kBwdChunk][kGRec + 1];   // (+1: the 18 words of neighbouring entries start in different banks)
+    SegCtx c;
+    if (!seg_context(tile_start, pl, dm, c)) return;
+    const float kM = kFar / (kFar - kNear);
+    // my pixel's prefixes and totals from the tile's segments
+    float T = 1.0f, T_final = 1.0f, W = 0.f, M1 = 0.f, M2 = 0.f, Aall = 0.f, Wp = 0.f, M1p = 0.f, M2p = 0.f, Ap = 0.f, Trun = 1.0f;
+    for (int j = 0; j < c.nseg; ++j) {
+        const size_t sl = (size_t)(c.s0 + j) * 256 + threadIdx.x;
+        if (j == c.k) { T = Trun; Wp = W; M1p = M1; M2p = M2; Ap = Aall; }
+        if (Trun >= 0.0001f) T_final = pl.Tend[sl];
+        const float4 q = pl.part[sl];
+        W += q.x; M1 += q.y; M2 += q.z; Aall += q.w;
+        Trun *= pl.Tseg[sl];
+    }
+    bool done = !c.inside || T < 0.0001f;
+    if (__syncthreads_and(done)) return;
+    PixelGrads pg;
+    load_pixel_grads(g_color, g_others, dm, c, pg);
+    const float Vtot = Aall + 2.0f * pg.gDist * (W * M2 - M1 * M1);
+    float P = Ap + pg.gDist * (W * M2p - 2.0f * M1 * M1p + M2 * Wp);
+    const float bgterm = (pg.gC[0] * bg[0] + pg.gC[1] * bg[1] + pg.gC[2] * bg[2]) - pg.gA;
+    for (uint32_t w = threadIdx.x; w < kBwdChunk * (kGRec + 1); w += 256) (&sgrad[0][0])[w] = 0.0f;
+    unsigned long long m[2];
+    stage_segment<kBRec>(sh, c, point_list, brec, m[0], m[1]);   // (its barriers also publish the cleared gradient image)
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float pxf = c.pxf, pyf = c.pyf;
+
+    // one contributing (pixel, entry) pair: the 18 gradient words in cw[]
+    auto pair_grad = [&](const float *b, const PairFwd &f, float test_T, float *cw) {
+        const float rd = __builtin_amdgcn_rcpf(f.depth);
+        const float w = f.alpha * T, mz = kM * (1.0f - kNear * rd);
+        const float Dq = mz * mz * W - 2.0f * mz * M1 + M2;
+        const float vi = (pg.gC[0] * GA_BF(15) + pg.gC[1] * GA_BF(16) + pg.gC[2] * GA_BF(17)) +
+                         (pg.gN[0] * GA_BF(12) + pg.gN[1] * GA_BF(13) + pg.gN[2] * GA_BF(14)) + pg.gD * f.depth + pg.gDist * Dq;
+        P += w * vi;
+        const float inv1ma = __builtin_amdgcn_rcpf(1.0f - f.alpha);
+        const float dL_dalpha = T * vi - (Vtot - P) * inv1ma - T_final * bgterm * inv1ma;
+        const float dL_ddepth = w * pg.gD + 2.0f * pg.gDist * w * (mz * W - M1) * (kM * kNear * rd * rd);
+        for (int q = 0; q < 3; ++q) { cw[15 + q] = w * pg.gC[q]; cw[12 + q] = w * pg.gN[q]; }
+        const float dL_draw = f.raw > 0.99f ? 0.0f : dL_dalpha;       // the clamp carries no gradient
+        cw[11] = f.G * dL_draw;
+        const float dL_drho = -0.5f * f.raw * dL_draw;
+        float dsx = 0.f, dsy = 0.f, dTw[3] = {0.f, 0.f, dL_ddepth};
+        cw[9] = 0.f; cw[10] = 0.f;
+        if (f.use3d) {
+            dsx = 2.0f * f.sx * dL_drho + dL_ddepth * f.Tw[0];
+            dsy = 2.0f * f.sy * dL_drho + dL_ddepth * f.Tw[1];
+            dTw[0] = dL_ddepth * f.sx; dTw[1] = dL_ddepth * f.sy;
+        } else {
+            cw[9] = 2.0f * kFilterInvSquare * f.dxc * dL_drho;
+            cw[10] = 2.0f * kFilterInvSquare * f.dyc * dL_drho;
+        }
+        // s = p.xy / p.z ; p = k x l ; k = px Tw - Tu ; l = py Tw - Tv
+        const float ipz = f.rz;
+        const float gp[3] = {dsx * ipz, dsy * ipz, -(dsx * f.sx + dsy * f.sy) * ipz};
+        const float dk[3] = {f.l[1] * gp[2] - f.l[2] * gp[1], f.l[2] * gp[0] - f.l[0] * gp[2], f.l[0] * gp[1] - f.l[1] * gp[0]};
+        const float dl[3] = {gp[1] * f.k[2] - gp[2] * f.k[1], gp[2] * f.k[0] - gp[0] * f.k[2], gp[0] * f.k[1] - gp[1] * f.k[0]};
+        for (int q = 0; q < 3; ++q) {
+            cw[q] = -dk[q];
+            cw[3 + q] = -dl[q];
+            cw[6 + q] = dTw[q] + pxf * dk[q] + pyf * dl[q];
+        }
+        T = test_T;
     };
 
-    // ---- pass 1: totals of the forward walk of my pixel ---------------------------------------------------------
-    float T = 1.0f, W = 0.0f, M1 = 0.0f, M2 = 0.0f;
-    bool done = !inside;
-    for (uint32_t cbeg = beg; cbeg < end; cbeg += kBwdChunk) {
-        const uint32_t cn = min((uint32_t)kBwdChunk, end - cbeg);
-        if (__syncthreads_and(done)) break;
-        stage(cbeg, cn);
-        for (uint32_t e = 0; e < cn && !done; ++e) {
-            PairFwd f;
-            pair_forward(srec[e], pxf, pyf, f);
-            if (!f.ok) continue;
-            const float test_T = T * (1.0f - f.alpha);
-            if (test_T < 0.0001f) { done = true; break; }
-            const float w = f.alpha * T, m = kM * (1.0f - kNear / f.depth);
-            W += w; M1 += m * w; M2 += m * m * w;
-            T = test_T;
+    for (int h = 0; h < 2; ++h) {
+        unsigned long long un = sh.call[h] & sh.rowstrip[h][wv];
+        un = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(un >> 32)) << 32) |
+             (uint32_t)__builtin_amdgcn_readfirstlane((int)un);
+        if (un == 0ull) continue;
+        // (pixel, entry) pairs of this wave / entries it meets: the lanes that evaluate an entry on average
+        float pairs = done ? 0.0f : (float)__popcll(m[h]);
+        pairs += dpp_row<0x111>(pairs); pairs += dpp_row<0x112>(pairs); pairs += dpp_row<0x114>(pairs); pairs += dpp_row<0x118>(pairs);
+        const float wave_pairs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pairs), 15)) +
+                                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pairs), 31)) +
+                                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pairs), 47)) +
+                                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pairs), 63));
+        if (wave_pairs >= (float)GA_BWD_WAVE_MAJOR_LANES * (float)__popcll(un)) {
+            while (un) {
+                const int eh = __builtin_ctzll(un);
+                un &= un - 1;
+                const bool act = !done && ((m[h] >> eh) & 1ull);
+                if (!__any(act)) continue;
+                const int e = eh + 64 * h;
+                const float *b = &sh.rec[0][e];
+                PairFwd f;
+                pair_forward(b, pxf, pyf, f);
+                float test_T = T;
+                bool on = act && f.ok;
+                if (on) {
+                    test_T = T * (1.0f - f.alpha);
+                    if (test_T < 0.0001f) { done = true; on = false; }
+                }
+                float cw[kGRec];
+#pragma unroll
+                for (int q = 0; q < kGRec; ++q) cw[q] = 0.0f;
+                if (on) pair_grad(b, f, test_T, cw);
+                if (!__any(on)) continue;
+                float q[5];
+                wave_totals18(cw, q);
+                if ((lane & 15) == 15) {   // the last lane of row r holds word 4 i + {0, 2, 1, 3}[r] of q[i]
+                    const int r = lane >> 4;
+                    float *g = &sgrad[e][((r & 1) << 1) | (r >> 1)];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) atomicAdd(g + 4 * i, q[i]);
+                    if (!(r & 1)) atomicAdd(&sgrad[e][16 + (r >> 1)], q[4]);
+                }
+            }
+        } else {
+            unsigned long long mm = done ? 0ull : m[h];
+            while (mm) {
+                const int e = __builtin_ctzll(mm) + 64 * h;
+                mm &= mm - 1;
+                const float *b = &sh.rec[0][e];
+                PairFwd f;
+                pair_forward(b, pxf, pyf, f);
+                if (!f.ok) continue;
+                const float test_T = T * (1.0f - f.alpha);
+                if (test_T < 0.0001f) { done = true; break; }
+                float cw[kGRec];
+                pair_grad(b, f, test_T, cw);
+#pragma unroll
+                for (int q = 0; q < kGRec; ++q)
+                    if (cw[q] != 0.0f) atomicAdd(&sgrad[e][q], cw[q]);
+            }
         }
     }
-    const float T_final = T;
-    float gC[3] = {0.f, 0.f, 0.f}, gN[3] = {0.f, 0.f, 0.f}, gD = 0.f, gA = 0.f, gDist = 0.f, Vtot = 0.f;
-    if (inside) {
-        for (int c = 0; c < 3; ++c) gC[c] = g_color[((size_t)v * 3 + c) * HW + pid];
-        const float *go = g_others + (size_t)v * 7 * HW + pid, *oo = out_others + (size_t)v * 7 * HW + pid;
-        gD = go[0]; gA = go[HW]; gN[0] = go[2 * HW]; gN[1] = go[3 * HW]; gN[2] = go[4 * HW]; gDist = go[6 * HW];
-        const float *oc = out_color + (size_t)v * 3 * HW + pid;
-        // V = sum w v = gC.(C - T bg) + gN.N + gD Dp + 2 gDist (W M2 - M1^2)
-        for (int c = 0; c < 3; ++c) Vtot += gC[c] * (oc[c * HW] - T_final * bg[c]);
-        Vtot += gN[0] * oo[2 * HW] + gN[1] * oo[3 * HW] + gN[2] * oo[4 * HW] + gD * oo[0] + 2.0f * gDist * (W * M2 - M1 * M1);
-    }
-    const float bgterm = (gC[0] * bg[0] + gC[1] * bg[1] + gC[2] * bg[2]) - gA;
-
-    // ---- pass 2: gradients ---------------------------------------------------------------------------------------
-    T = 1.0f;
-    float P = 0.0f;
-    done = !inside;
-    for (uint32_t cbeg = beg; cbeg < end; cbeg += kBwdChunk) {
-        const uint32_t cn = min((uint32_t)kBwdChunk, end - cbeg);
-        if (__syncthreads_and(done)) break;
-        stage(cbeg, cn);
-        for (uint32_t e = 0; e < cn && !done; ++e) {
-            const float *b = srec[e];
-            PairFwd f;
-            pair_forward(b, pxf, pyf, f);
-            if (!f.ok) continue;
-            const float test_T = T * (1.0f - f.alpha);
-            if (test_T < 0.0001f) { done = true; break; }
-            const float w = f.alpha * T, m = kM * (1.0f - kNear / f.depth);
-            const float Dq = m * m * W - 2.0f * m * M1 + M2;
-            const float vi = (gC[0] * b[15] + gC[1] * b[16] + gC[2] * b[17]) + (gN[0] * b[12] + gN[1] * b[13] + gN[2] * b[14]) +
-                             gD * f.depth + gDist * Dq;
-            P += w * vi;
-            const float inv1ma = 1.0f / (1.0f - f.alpha);
-            const float dL_dalpha = T * vi - (Vtot - P) * inv1ma - T_final * bgterm * inv1ma;
-            const float dL_ddepth = w * gD + 2.0f * gDist * w * (m * W - M1) * (kM * kNear / (f.depth * f.depth));
-            float *g = sgrad[e];
-            for (int c = 0; c < 3; ++c) { atomicAdd(g + 15 + c, w * gC[c]); atomicAdd(g + 12 + c, w * gN[c]); }
-            const float dL_draw = f.raw > 0.99f ? 0.0f : dL_dalpha;       // the clamp carries no gradient
-            atomicAdd(g + 11, f.G * dL_draw);
-            const float dL_drho = -0.5f * f.raw * dL_draw;
-            float dsx = 0.f, dsy = 0.f, dTw[3] = {0.f, 0.f, dL_ddepth};
-            if (f.use3d) {
-                dsx = 2.0f * f.sx * dL_drho + dL_ddepth * b[6];
-                dsy = 2.0f * f.sy * dL_drho + dL_ddepth * b[7];
-                dTw[0] = dL_ddepth * f.sx; dTw[1] = dL_ddepth * f.sy;
-            } else {
-                atomicAdd(g + 9, 2.0f * kFilterInvSquare * f.dxc * dL_drho);
-                atomicAdd(g + 10, 2.0f * kFilterInvSquare * f.dyc * dL_drho);
-            }
-            // s = p.xy / p.z ; p = k x l ; k = px Tw - Tu ; l = py Tw - Tv
-            const float ipz = 1.0f / f.p[2];
-            const float gp[3] = {dsx * ipz, dsy * ipz, -(dsx * f.sx + dsy * f.sy) * ipz};
-            const float dk[3] = {f.l[1] * gp[2] - f.l[2] * gp[1], f.l[2] * gp[0] - f.l[0] * gp[2], f.l[0] * gp[1] - f.l[1] * gp[0]};
-            const float dl[3] = {gp[1] * f.k[2] - gp[2] * f.k[1], gp[2] * f.k[0] - gp[0] * f.k[2], gp[0] * f.k[1] - gp[1] * f.k[0]};
-            for (int a = 0; a < 3; ++a) {
-                atomicAdd(g + a, -dk[a]);
-                atomicAdd(g + 3 + a, -dl[a]);
-                atomicAdd(g + 6 + a, dTw[a] + pxf * dk[a] + pyf * dl[a]);
-            }
-            T = test_T;
-        }
-        __syncthreads();   // the chunk's gradient words are complete: one global atomic per word
-        for (uint32_t w2 = threadIdx.x; w2 < cn * kGRec; w2 += 256) {
-            const uint32_t e = w2 / kGRec, f2 = w2 - e * kGRec;
-            const float val = sgrad[e][f2];
-            if (val != 0.0f) atomicAdd(grec + (vbase + sid[e]) * kGRec + f2, val);
-        }
+    __syncthreads();   // the segment's gradient words are complete: one global atomic per word
+    for (uint32_t w2 = threadIdx.x; w2 < c.cn * kGRec; w2 += 256) {
+        const uint32_t e = w2 / kGRec, f2 = w2 - e * kGRec;
+        const float val = sgrad[e][f2];
+        if (val != 0.0f) atomicAdd(grec + (c.vbase + sh.id[e]) * kGRec + f2, val);
     }
 }
+
+#undef GA_BF
 
 __global__ __launch_bounds__(256) void surfel_preprocess_bwd_kernel(const float *__restrict__ means3D, const float *__restrict__ scales,
                                                                     const float *__restrict__ rotations, const float *__restrict__ viewmatrix,
@@ -328,15 +636,50 @@ __global__ __launch_bounds__(256) void surfel_preprocess_bwd_kernel(const float 
 
 }  // namespace ga
 
+namespace ga {
+
+// `scratch`: brec | grec | seg_base | seg_owner | Tseg | Tend | part (every section 256-byte aligned)
+struct BwdScratch {
+    size_t brec, grec, seg_base, seg_owner, Tseg, Tend, part, total;
+    uint32_t max_segs;
+};
+
+static bool bwd_scratch_layout(int64_t N, int64_t V, int64_t tiles, int64_t capacity, BwdScratch &o)
+{
+    if (N < 0 || V <= 0 || tiles <= 0 || capacity < 0) return false;
+    const int64_t segs = capacity / kBwdSeg + V * tiles + 1;   // sum over lists of ceil(len / kBwdSeg) <= D / kBwdSeg + lists
+    if (segs > 0x7fffffffll) return false;
+    o.max_segs = (uint32_t)segs;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+    o.brec = take((size_t)N * V * kBRec * 4);
+    o.grec = take((size_t)N * V * kGRec * 4);
+    o.seg_base = take((size_t)(V * tiles + 1) * 4);
+    o.seg_owner = take((size_t)segs * 4);
+    o.Tseg = take((size_t)segs * 256 * 4);
+    o.Tend = take((size_t)segs * 256 * 4);
+    o.part = take((size_t)segs * 256 * 16);
+    o.total = off;
+    return true;
+}
+
+static bool bwd_dims(const GaSurfelForwardArgs &f, Dims &d)
+{
+    const int64_t gx = ((int64_t)f.image_width + kTile - 1) / kTile, gy = ((int64_t)f.image_height + kTile - 1) / kTile;
+    if (f.num_points < 0 || f.num_views <= 0 || f.image_height <= 0 || f.image_width <= 0) return false;
+    d.N = f.num_points; d.V = f.num_views; d.H = f.image_height; d.W = f.image_width; d.gx = (int)gx; d.gy = (int)gy; d.tiles = (int)(gx * gy);
+    return true;
+}
+
+}  // namespace ga
+
 extern "C" int ga_surfel_backward(const GaSurfelBackwardArgs *a, void *stream_v)
 {
     using namespace ga;
     if (!a) return GA_ERR_NULL_ARG;
     const GaSurfelForwardArgs &f = a->fwd;
     Dims d;
-    const int64_t gx = ((int64_t)f.image_width + kTile - 1) / kTile, gy = ((int64_t)f.image_height + kTile - 1) / kTile;
-    if (f.num_points < 0 || f.num_views <= 0 || f.image_height <= 0 || f.image_width <= 0) return GA_ERR_BAD_SHAPE;
-    d.N = f.num_points; d.V = f.num_views; d.H = f.image_height; d.W = f.image_width; d.gx = (int)gx; d.gy = (int)gy; d.tiles = (int)(gx * gy);
+    if (!bwd_dims(f, d)) return GA_ERR_BAD_SHAPE;
     GaSurfelWorkspaceLayout L;
     const int rc = ga_surfel_workspace_layout(d.N, d.V, d.H, d.W, f.capacity, &L);
     if (rc != GA_OK) return rc;
@@ -345,7 +688,9 @@ extern "C" int ga_surfel_backward(const GaSurfelBackwardArgs *a, void *stream_v)
         !a->grad_colors || !a->grad_scales || !a->grad_rotations)
         return GA_ERR_NULL_ARG;
     if (d.N > 0 && (!f.means3D || !f.opacities || !f.colors || !f.scales || !f.rotations)) return GA_ERR_NULL_ARG;
-    if (a->scratch_bytes < ga_surfel_backward_scratch_bytes(d.N, d.V)) return GA_ERR_WORKSPACE;
+    BwdScratch sc;
+    if (!bwd_scratch_layout(d.N, d.V, d.tiles, f.capacity, sc)) return GA_ERR_BAD_SHAPE;
+    if (a->scratch_bytes < sc.total || (reinterpret_cast<uintptr_t>(a->scratch) & 15)) return GA_ERR_WORKSPACE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_v);
     (void)hipGetLastError();
     if (d.N == 0) return GA_OK;
@@ -353,8 +698,16 @@ extern "C" int ga_surfel_backward(const GaSurfelBackwardArgs *a, void *stream_v)
     const int64_t *status = reinterpret_cast<const int64_t *>(w + L.status);
     const uint32_t *tile_start = reinterpret_cast<const uint32_t *>(w + L.tile_start);
     const uint32_t *point_list = reinterpret_cast<const uint32_t *>(w + L.point_list);
-    float *brec = static_cast<float *>(a->scratch);
-    float *grec = brec + (size_t)d.N * d.V * kBRec;
+    unsigned char *sp = static_cast<unsigned char *>(a->scratch);
+    float *brec = reinterpret_cast<float *>(sp + sc.brec);
+    float *grec = reinterpret_cast<float *>(sp + sc.grec);
+    BwdPlan pl;
+    pl.seg_base = reinterpret_cast<uint32_t *>(sp + sc.seg_base);
+    pl.seg_owner = reinterpret_cast<uint32_t *>(sp + sc.seg_owner);
+    pl.Tseg = reinterpret_cast<float *>(sp + sc.Tseg);
+    pl.Tend = reinterpret_cast<float *>(sp + sc.Tend);
+    pl.part = reinterpret_cast<float4 *>(sp + sc.part);
+    pl.max_segs = sc.max_segs;
     (void)hipMemsetAsync(a->grad_means3D, 0, (size_t)d.N * 3 * 4, s);
     (void)hipMemsetAsync(a->grad_opacities, 0, (size_t)d.N * 4, s);
     (void)hipMemsetAsync(a->grad_colors, 0, (size_t)d.N * 3 * 4, s);
@@ -364,15 +717,24 @@ extern "C" int ga_surfel_backward(const GaSurfelBackwardArgs *a, void *stream_v)
     hipLaunchKernelGGL(surfel_bwd_record_kernel, gridN, dim3(256), 0, s, f.means3D, f.opacities, f.colors, f.scales, f.rotations,
                        f.viewmatrix, f.projmatrix, f.scale_modifier, d, f.radii, reinterpret_cast<const float *>(w + L.record), brec,
                        grec);
-    hipLaunchKernelGGL(surfel_blend_bwd_kernel, dim3((unsigned)(d.V * d.tiles)), dim3(256), 0, s, tile_start, point_list, brec, f.bg, d,
-                       f.out_color, f.out_others, a->grad_color, a->grad_others, grec, status);
+    hipLaunchKernelGGL(surfel_bwd_segtable_kernel, dim3(1), dim3(1024), 0, s, tile_start, d.V * d.tiles, pl, status);
+    // (the grid covers the bound on the number of segments; the workgroups past the real count leave at once)
+    const dim3 gridS(sc.max_segs);
+    hipLaunchKernelGGL(surfel_bwd_trans_kernel, gridS, dim3(256), 0, s, tile_start, point_list, brec, d, pl);
+    hipLaunchKernelGGL(surfel_bwd_sums_kernel, gridS, dim3(256), 0, s, tile_start, point_list, brec, d, pl, a->grad_color,
+                       a->grad_others);
+    hipLaunchKernelGGL(surfel_bwd_grad_kernel, gridS, dim3(256), 0, s, tile_start, point_list, brec, f.bg, d, pl,
+                       a->grad_color, a->grad_others, grec);
     hipLaunchKernelGGL(surfel_preprocess_bwd_kernel, gridN, dim3(256), 0, s, f.means3D, f.scales, f.rotations, f.viewmatrix,
                        f.projmatrix, f.scale_modifier, d, f.radii, grec, a->grad_means3D, a->grad_opacities, a->grad_colors,
                        a->grad_scales, a->grad_rotations);
     return hipGetLastError() == hipSuccess ? GA_OK : GA_ERR_LAUNCH;
 }
 
-extern "C" size_t ga_surfel_backward_scratch_bytes(int32_t num_points, int32_t num_views)
+extern "C" size_t ga_surfel_backward_scratch_bytes(const GaSurfelForwardArgs *fwd)
 {
-    return (size_t)num_points * (size_t)num_views * (ga::kBRec + ga::kGRec) * sizeof(float);
+    ga::Dims d;
+    ga::BwdScratch sc;
+    if (!fwd || !ga::bwd_dims(*fwd, d) || !ga::bwd_scratch_layout(d.N, d.V, d.tiles, fwd->capacity, sc)) return 0;
+    return sc.total;
 }

@@ -145,13 +145,16 @@ class _RasterizeViews(torch.autograd.Function):
         g_color = torch.zeros_like(color) if g_color is None else g_color.detach().float().contiguous()
         g_allmap = torch.zeros_like(allmap) if g_allmap is None else g_allmap.detach().float().contiguous()
         L = _lib.lib()
-        scratch = torch.empty(int(L.ga_surfel_backward_scratch_bytes(n, v)) + 16, dtype=torch.uint8, device=dev)
         d_means, d_op = torch.empty_like(means3D), torch.empty_like(opacities)
         d_col, d_sc, d_rot = torch.empty_like(colors), torch.empty_like(scales), torch.empty_like(rotations)
         fwd = _lib.GaSurfelForwardArgs(
             n, v, h, w, mod, 0, means3D.data_ptr(), opacities.data_ptr(), colors.data_ptr(), scales.data_ptr(),
             rotations.data_ptr(), vm.data_ptr(), pm.data_ptr(), bg.data_ptr(), color.data_ptr(), allmap.data_ptr(),
             radii.data_ptr(), ws.ptr, ws.layout.total_bytes, ws.capacity, None)
+        nbytes = int(L.ga_surfel_backward_scratch_bytes(ctypes.byref(fwd)))
+        if nbytes == 0:
+            raise RuntimeError("ga_surfel_backward_scratch_bytes: bad shape")
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         args = _lib.GaSurfelBackwardArgs(fwd, g_color.data_ptr(), g_allmap.data_ptr(), scratch.data_ptr(), scratch.numel(),
                                          d_means.data_ptr(), d_op.data_ptr(), d_col.data_ptr(), d_sc.data_ptr(), d_rot.data_ptr())
         with torch.cuda.device(dev):

@@ -135,8 +135,9 @@ int ga_surfel_postprocess(const GaSurfelPostArgs *args, void *stream);
  * outputs out_color / out_others / radii.  grad_color [V,3,H,W] and grad_others [V,7,H,W] are dL/d(out_color) and
  * dL/d(out_others); the gradients with respect to the Gaussians are summed over the views.  The selection
  * min(rho3d, rho2d), the alpha / depth / transmittance tests, the 0.99 clamp, the normal's facing sign and the median depth
- * (channel 5 of out_others) are constants of the gradient.  Nothing is allocated; `scratch` holds
- * ga_surfel_backward_scratch_bytes(N, V) bytes. */
+ * (channel 5 of out_others) are constants of the gradient.  Nothing is allocated; `scratch` (16-byte aligned) holds
+ * ga_surfel_backward_scratch_bytes(&fwd) bytes: the per-(view, Gaussian) records and gradient words, and the table and
+ * per-pixel exchange arrays of the 128-entry list segments the blend backward is parallel over (sized from fwd.capacity). */
 typedef struct GaSurfelBackwardArgs {
     GaSurfelForwardArgs fwd;
     const float *grad_color;   /* [V,3,H,W]                                                      */
@@ -149,7 +150,7 @@ typedef struct GaSurfelBackwardArgs {
     float *grad_scales;        /* [N,2]                                                          */
     float *grad_rotations;     /* [N,4]  with respect to the quaternion as given (not normalised) */
 } GaSurfelBackwardArgs;
-size_t ga_surfel_backward_scratch_bytes(int32_t num_points, int32_t num_views);
+size_t ga_surfel_backward_scratch_bytes(const GaSurfelForwardArgs *fwd);   /* 0: bad shape */
 int ga_surfel_backward(const GaSurfelBackwardArgs *args, void *stream);
 
 /* host: library identification, e.g. "ga_mi355 surfel gfx950 r1" */
