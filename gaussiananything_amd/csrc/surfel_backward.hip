@@ -155,6 +155,7 @@ __device__ __forceinline__ void pair_forward(const float *__restrict__ b, float 
 // A tile's list is cut into segments of kBwdSeg entries and every segment is a workgroup of its own in each of three
 // launches, so that the longest list of a view (thousands of entries) is no longer one workgroup's serial walk:
 //   trans  T_seg(pixel) = prod (1 - alpha) over the segment's contributing entries;
+//   (a one-workgroup-per-tile launch after each of the first two turns T_seg into T_start and the sums into prefixes and totals)
 //   sums   with T_start = prod of the earlier segments' T_seg (a pixel whose T_start is below 1e-4 terminated earlier:
 //          the test that ends a walk fires at the entry that would take T below 1e-4, and T only falls): the forward walk
 //          of the segment with its termination, leaving W' = sum w, M1' = sum w m, M2' = sum w m^2,
@@ -177,9 +178,11 @@ struct BwdShared {
 struct BwdPlan {   // the segment table and the per-(segment, pixel) exchange arrays, all inside `scratch`
     uint32_t *seg_base;     // [V tiles + 1] first segment of every tile's list; the last word is the number of segments
     uint32_t *seg_owner;    // [max_segs] the (view, tile) a segment belongs to
-    float *Tseg;            // [max_segs][256]
+    float *Tseg;            // [max_segs][256]  trans: T_seg; after the first prefix launch: T_start
     float *Tend;            // [max_segs][256]
-    float4 *part;           // [max_segs][256]  W', M1', M2', A'
+    float4 *part;           // [max_segs][256]  sums: W', M1', M2', A'; after the second prefix launch: their sums over the earlier segments
+    float4 *total;          // [V tiles][256]   W, M1, M2, sum A' of the whole list
+    float *Tfinal;          // [V tiles][256]
     uint32_t max_segs;
 };
 
@@ -338,14 +341,6 @@ __device__ __forceinline__ void stage_segment(BwdShared &sh, const SegCtx &c, co
     m1 = sh.col[1][threadIdx.x & 15] & sh.row[1][threadIdx.x >> 4];
 }
 
-// transmittance my pixel enters segment k with (the product of the earlier segments' T_seg, in list order)
-__device__ __forceinline__ float seg_T_start(const BwdPlan &pl, const SegCtx &c)
-{
-    float T = 1.0f;
-    for (int j = 0; j < c.k; ++j) T *= pl.Tseg[(size_t)(c.s0 + j) * 256 + threadIdx.x];
-    return T;
-}
-
 __global__ __launch_bounds__(256) void surfel_bwd_trans_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
                                                                const float *__restrict__ brec, Dims dm, BwdPlan pl)
 {
@@ -366,6 +361,44 @@ __global__ __launch_bounds__(256) void surfel_bwd_trans_kernel(const uint32_t *_
         }
     }
     pl.Tseg[(size_t)blockIdx.x * 256 + threadIdx.x] = T;
+}
+
+// per tile (one workgroup, one thread per pixel), linear in the list's segments: T_seg -> T_start in place
+__global__ __launch_bounds__(256) void surfel_bwd_prefix_T_kernel(const uint32_t *__restrict__ tile_start, BwdPlan pl, int vtiles)
+{
+    const int vt = blockIdx.x;
+    if (pl.seg_base[vtiles] == 0) return;   // (no segments: nothing rendered, or the forward overflowed its lists)
+    const uint32_t s0 = pl.seg_base[vt];
+    const int nseg = (int)((tile_start[vt + 1] - tile_start[vt] + kBwdSeg - 1) / kBwdSeg);
+    float T = 1.0f;
+    for (int j = 0; j < nseg; ++j) {
+        float *p = pl.Tseg + (size_t)(s0 + j) * 256 + threadIdx.x;
+        const float t = *p;
+        *p = T;
+        T *= t;
+    }
+}
+
+// ... and the sums of the earlier segments in place of every segment's own, the totals and the final transmittance (that of
+// the last segment the pixel entered alive)
+__global__ __launch_bounds__(256) void surfel_bwd_prefix_sums_kernel(const uint32_t *__restrict__ tile_start, BwdPlan pl, int vtiles)
+{
+    const int vt = blockIdx.x;
+    if (pl.seg_base[vtiles] == 0) return;
+    const uint32_t s0 = pl.seg_base[vt];
+    const int nseg = (int)((tile_start[vt + 1] - tile_start[vt] + kBwdSeg - 1) / kBwdSeg);
+    if (nseg == 0) return;
+    float4 run = make_float4(0.f, 0.f, 0.f, 0.f);
+    float T_final = 1.0f;
+    for (int j = 0; j < nseg; ++j) {
+        const size_t sl = (size_t)(s0 + j) * 256 + threadIdx.x;
+        if (pl.Tseg[sl] >= 0.0001f) T_final = pl.Tend[sl];
+        const float4 q = pl.part[sl];
+        pl.part[sl] = run;
+        run.x += q.x; run.y += q.y; run.z += q.z; run.w += q.w;
+    }
+    pl.total[(size_t)vt * 256 + threadIdx.x] = run;
+    pl.Tfinal[(size_t)vt * 256 + threadIdx.x] = T_final;
 }
 
 struct PixelGrads { float gC[3], gN[3], gD, gA, gDist; };
@@ -390,7 +423,7 @@ __global__ __launch_bounds__(256) void surfel_bwd_sums_kernel(const uint32_t *__
     SegCtx c;
     if (!seg_context(tile_start, pl, dm, c)) return;
     const float kM = kFar / (kFar - kNear);
-    float T = seg_T_start(pl, c);
+    float T = pl.Tseg[(size_t)blockIdx.x * 256 + threadIdx.x];   // (T_start since the prefix launch)
     bool done = !c.inside || T < 0.0001f;
     float W = 0.f, M1 = 0.f, M2 = 0.f, A = 0.f;
     const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -438,18 +471,14 @@ __global__ __launch_bounds__(256) void surfel_bwd_grad_kernel(const uint32_t *__
     SegCtx c;
     if (!seg_context(tile_start, pl, dm, c)) return;
     const float kM = kFar / (kFar - kNear);
-    // my pixel's prefixes and totals from the tile's segments
-    float T = 1.0f, T_final = 1.0f, W = 0.f, M1 = 0.f, M2 = 0.f, Aall = 0.f, Wp = 0.f, M1p = 0.f, M2p = 0.f, Ap = 0.f, Trun = 1.0f;
-    for (int j = 0; j < c.nseg; ++j) {
-        const size_t sl = (size_t)(c.s0 + j) * 256 + threadIdx.x;
-        if (j == c.k) { T = Trun; Wp = W; M1p = M1; M2p = M2; Ap = Aall; }
-        if (Trun >= 0.0001f) T_final = pl.Tend[sl];
-        const float4 q = pl.part[sl];
-        W += q.x; M1 += q.y; M2 += q.z; Aall += q.w;
-        Trun *= pl.Tseg[sl];
-    }
+    // my pixel's state on entering the segment, and the totals of its whole walk
+    const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float T = pl.Tseg[slot];
     bool done = !c.inside || T < 0.0001f;
     if (__syncthreads_and(done)) return;
+    const float4 pre = pl.part[slot], tot = pl.total[(size_t)c.vt * 256 + threadIdx.x];
+    const float T_final = pl.Tfinal[(size_t)c.vt * 256 + threadIdx.x];
+    const float W = tot.x, M1 = tot.y, M2 = tot.z, Aall = tot.w, Wp = pre.x, M1p = pre.y, M2p = pre.z, Ap = pre.w;
     PixelGrads pg;
     load_pixel_grads(g_color, g_others, dm, c, pg);
     const float Vtot = Aall + 2.0f * pg.gDist * (W * M2 - M1 * M1);
@@ -638,9 +667,9 @@ __global__ __launch_bounds__(256) void surfel_preprocess_bwd_kernel(const float 
 
 namespace ga {
 
-// `scratch`: brec | grec | seg_base | seg_owner | Tseg | Tend | part (every section 256-byte aligned)
+// `scratch`: brec | grec | seg_base | seg_owner | Tseg | Tend | part | totals | Tfinal (every section 256-byte aligned)
 struct BwdScratch {
-    size_t brec, grec, seg_base, seg_owner, Tseg, Tend, part, total;
+    size_t brec, grec, seg_base, seg_owner, Tseg, Tend, part, totals, Tfinal, total;
     uint32_t max_segs;
 };
 
@@ -659,6 +688,8 @@ static bool bwd_scratch_layout(int64_t N, int64_t V, int64_t tiles, int64_t capa
     o.Tseg = take((size_t)segs * 256 * 4);
     o.Tend = take((size_t)segs * 256 * 4);
     o.part = take((size_t)segs * 256 * 16);
+    o.totals = take((size_t)V * tiles * 256 * 16);
+    o.Tfinal = take((size_t)V * tiles * 256 * 4);
     o.total = off;
     return true;
 }
@@ -707,6 +738,8 @@ extern "C" int ga_surfel_backward(const GaSurfelBackwardArgs *a, void *stream_v)
     pl.Tseg = reinterpret_cast<float *>(sp + sc.Tseg);
     pl.Tend = reinterpret_cast<float *>(sp + sc.Tend);
     pl.part = reinterpret_cast<float4 *>(sp + sc.part);
+    pl.total = reinterpret_cast<float4 *>(sp + sc.totals);
+    pl.Tfinal = reinterpret_cast<float *>(sp + sc.Tfinal);
     pl.max_segs = sc.max_segs;
     (void)hipMemsetAsync(a->grad_means3D, 0, (size_t)d.N * 3 * 4, s);
     (void)hipMemsetAsync(a->grad_opacities, 0, (size_t)d.N * 4, s);
@@ -721,8 +754,10 @@ extern "C" int ga_surfel_backward(const GaSurfelBackwardArgs *a, void *stream_v)
     // (the grid covers the bound on the number of segments; the workgroups past the real count leave at once)
     const dim3 gridS(sc.max_segs);
     hipLaunchKernelGGL(surfel_bwd_trans_kernel, gridS, dim3(256), 0, s, tile_start, point_list, brec, d, pl);
+    hipLaunchKernelGGL(surfel_bwd_prefix_T_kernel, dim3((unsigned)(d.V * d.tiles)), dim3(256), 0, s, tile_start, pl, d.V * d.tiles);
     hipLaunchKernelGGL(surfel_bwd_sums_kernel, gridS, dim3(256), 0, s, tile_start, point_list, brec, d, pl, a->grad_color,
                        a->grad_others);
+    hipLaunchKernelGGL(surfel_bwd_prefix_sums_kernel, dim3((unsigned)(d.V * d.tiles)), dim3(256), 0, s, tile_start, pl, d.V * d.tiles);
     hipLaunchKernelGGL(surfel_bwd_grad_kernel, gridS, dim3(256), 0, s, tile_start, point_list, brec, f.bg, d, pl,
                        a->grad_color, a->grad_others, grec);
     hipLaunchKernelGGL(surfel_preprocess_bwd_kernel, gridN, dim3(256), 0, s, f.means3D, f.scales, f.rotations, f.viewmatrix,
