@@ -7,19 +7,21 @@
 // alpha >= 1/255, depth >= near and T(1 - alpha) >= 1e-4 tests, the 0.99 clamp (no gradient above it), the sign that turns
 // the normal towards the camera, and the median depth (not differentiated).
 //
-// Three kernels, correctness first (the forward is the hot path of this repository; this is the training-side widening):
-//   1. surfel_bwd_record_kernel   per (view, Gaussian): the forward's per-splat quantities once more -- Tu, Tv, Tw, the
-//      screen-space centre, the camera-facing normal, opacity, colour -- as a 24-float record;
-//   2. surfel_blend_bwd_kernel    one workgroup per 16x16 tile, one thread per pixel.  Pass 1 walks the tile's depth-ordered
-//      list as the forward does and leaves the totals W = sum w, M1 = sum w m, M2 = sum w m^2 and the final
-//      transmittance; pass 2 walks it again with the prefix P_i = sum_{j<=i} w_j v_j and forms, per contributing pair,
-//          v_i        = gC.c_i + gN.n_i + gD d_i + gDist (m_i^2 W - 2 m_i M1 + M2)      (dist = sum_{j<i} w_i w_j (m_i - m_j)^2)
-//          dL/dalpha_i = T_i v_i - (V - P_i) / (1 - alpha_i) - T_final (gC.bg - gA) / (1 - alpha_i)
+// Launches (all on the caller's stream, nothing allocated):
+//   1. surfel_bwd_record_kernel      per (view, Gaussian): the forward's per-splat quantities once more -- Tu, Tv, Tw, the
+//      screen-space centre, the camera-facing normal, opacity, colour, the forward's cull half-extents -- as a 24-float record;
+//   2. surfel_bwd_segtable_kernel    every tile's depth-ordered list cut into 128-entry segments: first segment of each tile,
+//      owner of each segment;
+//   3. the blend backward, ONE WORKGROUP PER SEGMENT in each of three launches (see the comment above BwdShared) with a
+//      one-workgroup-per-tile prefix launch after the first two: surfel_bwd_trans_kernel, surfel_bwd_prefix_T_kernel,
+//      surfel_bwd_sums_kernel, surfel_bwd_prefix_sums_kernel, surfel_bwd_grad_kernel.  Per contributing (pixel, entry) pair
+//          v_i         = gC.c_i + gN.n_i + gD d_i + gDist (m_i^2 W - 2 m_i M1 + M2)     (dist = sum_{j<i} w_i w_j (m_i - m_j)^2)
+//          dL/dalpha_i = T_i v_i - (V - P_i) / (1 - alpha_i) - T_final (gC.bg - gA) / (1 - alpha_i),   P_i = sum_{j<=i} w_j v_j
 //          dL/ddepth_i = w_i gD + 2 gDist w_i (m_i W - M1) dm/dd
 //      and from them the gradients of opacity, colour, normal, centre and of Tu / Tv / Tw through
-//      p = (px Tw - Tu) x (py Tw - Tv).  A tile's list is staged 128 entries at a time; the 18 gradient words of an entry
-//      are accumulated with LDS atomics and flushed with one global atomic per word and (tile, entry);
-//   3. surfel_preprocess_bwd_kernel per (view, Gaussian): through M = Hm P N_pix (and the bounding-box centre formula for the
+//      p = (px Tw - Tu) x (py Tw - Tv); the 18 gradient words of an entry are accumulated in LDS per segment and flushed
+//      with one global atomic per word and (segment, entry);
+//   4. surfel_preprocess_bwd_kernel  per (view, Gaussian): through M = Hm P N_pix (and the bounding-box centre formula for the
 //      low-pass filter's centre), the view rotation of the normal and the normalised quaternion to means3D, scales, rotations,
 //      opacities and colours, summed over the views with atomics.
 #include <hip/hip_fp16.h>
@@ -171,7 +173,7 @@ constexpr int kBwdSeg = kBwdChunk;
 struct BwdShared {
     float rec[kBRec][kBwdChunk];
     unsigned long long col[2][kTile], row[2][kTile];
-    unsigned long long call[2], rowstrip[2][4];   // union of the columns' masks; of the rows of each wave's strip
+    unsigned long long colq[2][2], rowq[2][2];    // union of the masks of the columns / rows 0..7 and 8..15 (a wave = an 8 x 8 quadrant)
     uint32_t id[kBwdChunk];
 };
 
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(1024) void surfel_bwd_segtable_kernel(const uint32_
 struct SegCtx {
     int vt, v, tx, ty, k, nseg;      // (view, tile), this segment's index within the tile's list, the list's segments
     uint32_t s0, cbeg, cn;           // first segment of the tile; this segment's entries
-    int pxi, pyi;
+    int lx, ly, pxi, pyi;            // my pixel inside the tile / in the image
     bool inside;
     float pxf, pyf;
     size_t vbase;
@@ -285,8 +287,11 @@ __device__ __forceinline__ bool seg_context(const uint32_t *__restrict__ tile_st
     c.nseg = (int)((end - beg + kBwdSeg - 1) / kBwdSeg);
     c.cbeg = beg + (uint32_t)c.k * kBwdSeg;
     c.cn = min((uint32_t)kBwdSeg, end - c.cbeg);
-    c.pxi = c.tx * kTile + (int)(threadIdx.x & 15);
-    c.pyi = c.ty * kTile + (int)(threadIdx.x >> 4);
+    // a wave is an 8 x 8 quadrant of the tile (fewer entries per wave than a 16 x 4 strip meets)
+    c.lx = (int)(((threadIdx.x >> 6) & 1) * 8 + (threadIdx.x & 7));
+    c.ly = (int)((threadIdx.x >> 7) * 8 + ((threadIdx.x >> 3) & 7));
+    c.pxi = c.tx * kTile + c.lx;
+    c.pyi = c.ty * kTile + c.ly;
     c.inside = c.pxi < dm.W && c.pyi < dm.H;
     c.pxf = (float)c.pxi; c.pyf = (float)c.pyi;
     c.vbase = (size_t)c.v * dm.N;
@@ -326,19 +331,18 @@ __device__ __forceinline__ void stage_segment(BwdShared &sh, const SegCtx &c, co
         if ((uint32_t)se < c.cn) { rx = sh.rec[18][se]; ry = sh.rec[19][se]; }
         const int h = se >> 6;
         const float ox = bx - (float)(c.tx * kTile), oy = by - (float)(c.ty * kTile);
-        unsigned long long call = 0ull, rs = 0ull;
+        unsigned long long cs = 0ull, rs = 0ull;
         for (int q = 0; q < kTile; ++q) {
             const unsigned long long mc = __ballot(fabsf((float)q - ox) <= rx);
             const unsigned long long mr = __ballot(fabsf((float)q - oy) <= ry);
-            call |= mc; rs |= mr;
+            cs |= mc; rs |= mr;
             if ((se & 63) == 0) { sh.col[h][q] = mc; sh.row[h][q] = mr; }
-            if ((q & 3) == 3) { if ((se & 63) == 0) sh.rowstrip[h][q >> 2] = rs; rs = 0ull; }
+            if ((q & 7) == 7) { if ((se & 63) == 0) { sh.colq[h][q >> 3] = cs; sh.rowq[h][q >> 3] = rs; } cs = 0ull; rs = 0ull; }
         }
-        if ((se & 63) == 0) sh.call[h] = call;
     }
     __syncthreads();
-    m0 = sh.col[0][threadIdx.x & 15] & sh.row[0][threadIdx.x >> 4];
-    m1 = sh.col[1][threadIdx.x & 15] & sh.row[1][threadIdx.x >> 4];
+    m0 = sh.col[0][c.lx] & sh.row[0][c.ly];
+    m1 = sh.col[1][c.lx] & sh.row[1][c.ly];
 }
 
 __global__ __launch_bounds__(256) void surfel_bwd_trans_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(256) void surfel_bwd_grad_kernel(const uint32_t *__
     };
 
     for (int h = 0; h < 2; ++h) {
-        unsigned long long un = sh.call[h] & sh.rowstrip[h][wv];
+        unsigned long long un = sh.colq[h][wv & 1] & sh.rowq[h][wv >> 1];
         un = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(un >> 32)) << 32) |
              (uint32_t)__builtin_amdgcn_readfirstlane((int)un);
         if (un == 0ull) continue;
