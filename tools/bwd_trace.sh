@@ -10,4 +10,4 @@ mkdir -p $R/gpurun_out/$tag
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$tag -o x -- python $R/tools/bwd_bench.py --reps 10 --scene ${2:-surface} > /dev/null 2>$R/gpurun_out/$tag/err.txt
 python $R/tools/rocpd_stats.py $(ls $R/gpurun_out/$tag/*.db $R/gpurun_out/$tag/*/*.db 2>/dev/null | head -1) | python -c "import sys
 for l in sys.stdin:
-    f=l.split(\" | \"); print(f[0][:50].ljust(50), *f[1:])" | head -14 | tee $R/gpurun_out/${tag}_stats.txt
+    f=l.split(\" | \"); print(f[0][:50].ljust(50), *f[1:])" | head -40 | grep -v "^$" | tee $R/gpurun_out/${tag}_stats.txt
