@@ -55,8 +55,24 @@ class GaSurfelPostArgs(ctypes.Structure):
                 ("image", ctypes.c_void_p), ("rend_normal", ctypes.c_void_p), ("depth", ctypes.c_void_p)]
 
 
+class GaTsdfVolume(ctypes.Structure):
+    """include/ga_tsdf.h: GaTsdfVolume"""
+    _fields_ = [("units", ctypes.c_int32 * 3), ("unit0", ctypes.c_int32 * 3), ("voxel_length", ctypes.c_double),
+                ("sdf_trunc", ctypes.c_double), ("tsdf", ctypes.c_void_p), ("weight", ctypes.c_void_p),
+                ("color", ctypes.c_void_p), ("touched", ctypes.c_void_p), ("allocated", ctypes.c_void_p)]
+
+
+class GaTsdfFrame(ctypes.Structure):
+    """include/ga_tsdf.h: GaTsdfFrame"""
+    _fields_ = [("height", ctypes.c_int32), ("width", ctypes.c_int32), ("rgb", ctypes.c_void_p), ("depth", ctypes.c_void_p),
+                ("alpha", ctypes.c_void_p), ("alpha_thres", ctypes.c_float), ("depth_trunc", ctypes.c_float),
+                ("fx", ctypes.c_double), ("fy", ctypes.c_double), ("cx", ctypes.c_double), ("cy", ctypes.c_double),
+                ("extrinsic", ctypes.c_double * 16), ("pose", ctypes.c_double * 16), ("depth_sampling_stride", ctypes.c_int32)]
+
+
 EXPORTS = ("ga_surfel_version", "ga_surfel_workspace_layout", "ga_surfel_forward", "ga_surfel_postprocess",
-           "ga_surfel_backward", "ga_surfel_backward_scratch_bytes")
+           "ga_surfel_backward", "ga_surfel_backward_scratch_bytes",
+           "ga_tsdf_integrate", "ga_tsdf_mesh_scratch_bytes", "ga_tsdf_mesh_count", "ga_tsdf_mesh_emit")
 
 _lib = None
 
@@ -92,6 +108,15 @@ def lib():
         L.ga_surfel_backward_scratch_bytes.argtypes = [ctypes.POINTER(GaSurfelForwardArgs)]
         L.ga_surfel_postprocess.restype = ctypes.c_int
         L.ga_surfel_postprocess.argtypes = [ctypes.POINTER(GaSurfelPostArgs), ctypes.c_void_p]
+        L.ga_tsdf_integrate.restype = ctypes.c_int
+        L.ga_tsdf_integrate.argtypes = [ctypes.POINTER(GaTsdfVolume), ctypes.POINTER(GaTsdfFrame), ctypes.c_void_p]
+        L.ga_tsdf_mesh_scratch_bytes.restype = ctypes.c_size_t
+        L.ga_tsdf_mesh_scratch_bytes.argtypes = [ctypes.POINTER(GaTsdfVolume)]
+        L.ga_tsdf_mesh_count.restype = ctypes.c_int
+        L.ga_tsdf_mesh_count.argtypes = [ctypes.POINTER(GaTsdfVolume), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+        L.ga_tsdf_mesh_emit.restype = ctypes.c_int
+        L.ga_tsdf_mesh_emit.argtypes = [ctypes.POINTER(GaTsdfVolume), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
     return _lib
 

@@ -1,0 +1,209 @@
+"""TSDF fusion of the rendered views and mesh export -- the host side of include/ga_tsdf.h.
+
+Mirrors the reference's mesh export of a generated object, function by function:
+    FlowMatchingEngine_gs.export_mesh_from_2dgs   /root/reference/nsr/lsgm/flow_matching_trainer.py:1244-1315
+    FlowMatchingEngine_gs.extract_mesh_bounded    /root/reference/nsr/lsgm/flow_matching_trainer.py:1318-1395
+    to_cam_open3d_compat, post_process_mesh       /root/reference/utils/mesh_util.py:80-110, 22-44
+with Open3D's ScalableTSDFVolume (CPU, third party) replaced by ``TSDFVolume`` (HIP kernels, csrc/tsdf.hip; dense over the
+bounding cube, which 288 GB of HBM afford).  Fusion and marching cubes run on the GPU; the connected-component filter of
+``post_process_mesh`` and the OBJ writer are host code over the (small) finished mesh, as in the reference.  There is no CPU
+fallback: without the HIP library the calls raise."""
+import ctypes
+import math
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+UNIT = 16
+
+
+def to_cam_open3d_compat(c: dict, image_size: int = 512):
+    """utils/mesh_util.py:80-110: pinhole intrinsics (fx, fy, cx, cy) and the 4x4 world->camera extrinsic of one camera in the
+    reference's 3DGS format (``cam_view`` row-vector convention; ``projection_matrix`` if present, else ``tanfov``)."""
+    W = H = image_size
+    if "projection_matrix" in c:
+        pm = torch.as_tensor(c["projection_matrix"]).float().cpu()
+        ndc2pix = torch.tensor([[W / 2, 0, 0, (W - 1) / 2], [0, H / 2, 0, (H - 1) / 2], [0, 0, 0, 1]]).float().T
+        intr = (pm @ ndc2pix)[:3, :3].T
+        fx, fy, cx, cy = intr[0, 0].item(), intr[1, 1].item(), intr[0, 2].item(), intr[1, 2].item()
+    else:
+        t = c["tanfov"]
+        tx, ty = (t, t) if not isinstance(t, (tuple, list)) else t
+        # getProjectionMatrix stores 1 / tan(fov / 2) in a float32 matrix; the product with W / 2 is a float32 product
+        fx = float(np.float32(1.0 / float(tx)) * np.float32(W / 2))
+        fy = float(np.float32(1.0 / float(ty)) * np.float32(H / 2))
+        cx, cy = float(np.float32((W - 1) / 2)), float(np.float32((H - 1) / 2))
+    extrinsic = np.asarray(torch.as_tensor(c["cam_view"]).float().cpu().T.numpy(), dtype=np.float64)
+    return (fx, fy, cx, cy), extrinsic
+
+
+class TSDFVolume:
+    """Dense stand-in for ``o3d.pipelines.integration.ScalableTSDFVolume(voxel_length, sdf_trunc, RGB8)`` over the box
+    [bound_min, bound_max] (rounded outwards to whole 16^3-voxel units of Open3D's unit lattice)."""
+
+    def __init__(self, voxel_length: float, sdf_trunc: float, bound_min: Sequence[float], bound_max: Sequence[float],
+                 device="cuda", depth_sampling_stride: int = 4):
+        self.voxel_length, self.sdf_trunc = float(voxel_length), float(sdf_trunc)
+        self.stride = int(depth_sampling_stride)
+        ul = self.voxel_length * UNIT
+        self.unit0 = [int(math.floor(float(b) / ul)) for b in bound_min]
+        hi = [int(math.floor(float(b) / ul)) for b in bound_max]
+        self.units = [h - l + 1 for l, h in zip(self.unit0, hi)]
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("TSDFVolume runs on the GPU only (no CPU fallback)")
+        n_units = self.units[0] * self.units[1] * self.units[2]
+        self.nvox = n_units * UNIT ** 3
+        self.tsdf = torch.zeros(self.nvox, dtype=torch.float32, device=self.device)
+        self.weight = torch.zeros(self.nvox, dtype=torch.float32, device=self.device)
+        self.color = torch.zeros(3, self.nvox, dtype=torch.float32, device=self.device)
+        self.touched = torch.zeros(n_units, dtype=torch.uint8, device=self.device)
+        self.allocated = torch.zeros(n_units, dtype=torch.uint8, device=self.device)
+        self._c = _lib.GaTsdfVolume((ctypes.c_int32 * 3)(*self.units), (ctypes.c_int32 * 3)(*self.unit0), self.voxel_length,
+                                    self.sdf_trunc, self.tsdf.data_ptr(), self.weight.data_ptr(), self.color.data_ptr(),
+                                    self.touched.data_ptr(), self.allocated.data_ptr())
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def integrate(self, rgb: torch.Tensor, depth: torch.Tensor, intrinsic, extrinsic, depth_trunc: float,
+                  alpha: Optional[torch.Tensor] = None, alpha_thres: float = 0.0):
+        """``volume.integrate(RGBDImage.create_from_color_and_depth(uint8(clip(rgb) * 255), depth, depth_trunc, depth_scale=1),
+        intrinsic, extrinsic)`` with ``depth[alpha < alpha_thres] = 0`` applied first (flow_matching_trainer.py:1371-1390).
+        rgb [3,H,W], depth [H,W] or [1,H,W], alpha likewise; intrinsic = (fx, fy, cx, cy); extrinsic 4x4 world->camera."""
+        rgb = rgb.detach().to(self.device, torch.float32).contiguous()
+        depth = depth.detach().to(self.device, torch.float32).reshape(depth.shape[-2], depth.shape[-1]).contiguous()
+        H, W = depth.shape
+        if rgb.shape != (3, H, W):
+            raise ValueError(f"rgb {tuple(rgb.shape)} does not match depth {tuple(depth.shape)}")
+        if alpha is not None:
+            alpha = alpha.detach().to(self.device, torch.float32).reshape(H, W).contiguous()
+        ext = np.asarray(extrinsic, dtype=np.float64).reshape(4, 4)
+        pose = np.linalg.inv(ext)
+        fx, fy, cx, cy = (float(v) for v in intrinsic)
+        fr = _lib.GaTsdfFrame(H, W, rgb.data_ptr(), depth.data_ptr(), alpha.data_ptr() if alpha is not None else None,
+                              float(alpha_thres), float(depth_trunc), fx, fy, cx, cy,
+                              (ctypes.c_double * 16)(*ext.reshape(-1).tolist()), (ctypes.c_double * 16)(*pose.reshape(-1).tolist()),
+                              self.stride)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ga_tsdf_integrate(ctypes.byref(self._c), ctypes.byref(fr), self._stream()), "ga_tsdf_integrate")
+
+    def extract_triangle_mesh(self):
+        """-> vertices [nv,3] float32 (world), vertex colours [nv,3] in [0,1], triangles [nt,3] int32, on the device."""
+        L = _lib.lib()
+        nbytes = int(L.ga_tsdf_mesh_scratch_bytes(ctypes.byref(self._c)))
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        counts = torch.zeros(2, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(L.ga_tsdf_mesh_count(ctypes.byref(self._c), scratch.data_ptr(), nbytes, counts.data_ptr(), self._stream()),
+                       "ga_tsdf_mesh_count")
+            nv, nt = (int(v) for v in counts.cpu().tolist())   # the one read-back: the size of the mesh
+            vertices = torch.empty(nv, 3, dtype=torch.float32, device=self.device)
+            colors = torch.empty(nv, 3, dtype=torch.float32, device=self.device)
+            triangles = torch.empty(nt, 3, dtype=torch.int32, device=self.device)
+            _lib.check(L.ga_tsdf_mesh_emit(ctypes.byref(self._c), scratch.data_ptr(), nbytes, nv, nt, vertices.data_ptr(),
+                                           colors.data_ptr(), triangles.data_ptr(), self._stream()), "ga_tsdf_mesh_emit")
+        return vertices, colors, triangles
+
+    def dense(self):
+        """(tsdf, weight, colour[3]) as [X, Y, Z] arrays on the host (unit-blocked storage undone): for tests and inspection."""
+        ux, uy, uz = self.units
+
+        def unblock(t):
+            return t.reshape(ux, uy, uz, UNIT, UNIT, UNIT).permute(0, 4, 1, 5, 2, 3).reshape(ux * UNIT, uy * UNIT, uz * UNIT).cpu().numpy()
+
+        return unblock(self.tsdf), unblock(self.weight), np.stack([unblock(self.color[c]) for c in range(3)])
+
+
+def extract_mesh_bounded(rgbmaps, depthmaps, alpha_maps, cam_pathes, aabb, alpha_thres: float = 0.08, image_size: int = 512,
+                         device="cuda"):
+    """flow_matching_trainer.py:1318-1395 with the aabb branch it always takes: voxel = radius / 160, sdf_trunc = 12 voxels,
+    per-camera depth_trunc = |campos - centre| + radius.  ``cam_pathes``: the reference's 3DGS-format camera dicts
+    (``cam_view``, ``cam_pos``, ``tanfov`` or ``projection_matrix``); maps indexed [i][0] as in the reference."""
+    aabb = np.asarray(aabb, dtype=np.float64).reshape(2, 3)
+    center = aabb.mean(0)
+    radius = float(np.linalg.norm(aabb[1] - aabb[0]) * 0.5)
+    voxel_size = radius / 160
+    sdf_trunc = voxel_size * 12
+    # every depth point within a camera's depth_trunc lies in the ball of `radius` about the centre or in front of it; the box
+    # of the dense volume is that ball plus the truncation band (Open3D would also open units further out: include/ga_tsdf.h)
+    volume = TSDFVolume(voxel_size, sdf_trunc, center - radius - sdf_trunc, center + radius + sdf_trunc, device=device)
+    for i, cam in enumerate(cam_pathes):
+        intr, ext = to_cam_open3d_compat(cam, image_size)
+        campos = torch.as_tensor(cam["cam_pos"]).detach().cpu().numpy().astype(np.float64).reshape(-1)[:3]
+        depth_trunc = float(np.linalg.norm(campos - center, axis=-1) + radius)
+        volume.integrate(rgbmaps[i][0], depthmaps[i][0], intr, ext, depth_trunc, alpha=alpha_maps[i][0], alpha_thres=alpha_thres)
+    return volume.extract_triangle_mesh()
+
+
+def post_process_mesh(vertices: np.ndarray, colors: np.ndarray, triangles: np.ndarray):
+    """utils/mesh_util.py:22-44 on host arrays: keep the (at most) ten largest connected triangle clusters and none below 50
+    triangles (clusters = triangles joined through shared edges, Open3D's cluster_connected_triangles), then drop
+    unreferenced vertices and degenerate triangles."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    t = np.asarray(triangles, dtype=np.int64)
+    if len(t) == 0:
+        return vertices[:0], colors[:0], t.astype(np.int32)
+    e = np.sort(np.concatenate([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]]), axis=1)
+    owner = np.tile(np.arange(len(t)), 3)
+    key = e[:, 0] * (int(t.max()) + 1) + e[:, 1]
+    order = np.argsort(key, kind="stable")
+    ks, ow = key[order], owner[order]
+    same = ks[1:] == ks[:-1]
+    graph = coo_matrix((np.ones(int(same.sum()), dtype=np.int8), (ow[:-1][same], ow[1:][same])), shape=(len(t), len(t)))
+    _, label = connected_components(graph, directed=False)
+    cluster_n = np.bincount(label)
+    cluster_to_keep = min(len(cluster_n), 10)
+    n_cluster = max(int(np.sort(cluster_n)[-cluster_to_keep]), 50)
+    t = t[cluster_n[label] >= n_cluster]
+    used = np.unique(t)
+    remap = np.full(len(vertices), -1, dtype=np.int64)
+    remap[used] = np.arange(len(used))
+    t = remap[t]
+    t = t[(t[:, 0] != t[:, 1]) & (t[:, 1] != t[:, 2]) & (t[:, 0] != t[:, 2])]
+    return vertices[used], colors[used], t.astype(np.int32)
+
+
+def rotation_matrix_x(theta_degrees: float) -> np.ndarray:
+    """flow_matching_trainer.py:67-75"""
+    th = np.radians(theta_degrees)
+    c, s = np.cos(th), np.sin(th)
+    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+
+
+def rotation_matrix_y(theta: float) -> np.ndarray:
+    """flow_matching_trainer.py (rotation about y by theta RADIANS, as the reference's helper takes it)"""
+    c, s = np.cos(theta), np.sin(theta)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+
+def write_obj(path: str, vertices: np.ndarray, colors: np.ndarray, triangles: np.ndarray):
+    """Wavefront OBJ with per-vertex colours (`v x y z r g b`), the form o3d.io.write_triangle_mesh gives a coloured mesh."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, "w") as f:
+        f.write("# GaussianAnything mesh export (TSDF fusion of the rendered views)\n")
+        for v, c in zip(np.asarray(vertices, dtype=np.float64), np.asarray(colors, dtype=np.float64)):
+            f.write("v %.6f %.6f %.6f %.6f %.6f %.6f\n" % (v[0], v[1], v[2], c[0], c[1], c[2]))
+        for t in np.asarray(triangles, dtype=np.int64) + 1:
+            f.write("f %d %d %d\n" % (t[0], t[1], t[2]))
+
+
+def export_mesh_from_2dgs(all_rgbs, all_depths, all_alphas, cam_pathes, mesh_output_path: str, image_size: int = 512, device="cuda"):
+    """flow_matching_trainer.py:1244-1315: fuse, write `<name>-mesh_raw.obj`, post-process, rotate (x by -90 degrees, then y by
+    pi) and write `<name>.obj`; returns the post-processed path.  ``mesh_output_path`` is the raw mesh's path
+    (must end in `_raw.obj`)."""
+    aabb = np.array([-0.45, -0.45, -0.45, 0.45, 0.45, 0.45]).reshape(2, 3) * 1.1
+    v, c, t = extract_mesh_bounded(all_rgbs, all_depths, all_alphas, cam_pathes, aabb, image_size=image_size, device=device)
+    v, c, t = v.cpu().numpy(), c.cpu().numpy(), t.cpu().numpy()
+    write_obj(mesh_output_path, v, c, t)
+    pv, pc, pt = post_process_mesh(v, c, t)
+    pv = pv.astype(np.float64) @ rotation_matrix_x(-90).T
+    pv = pv @ rotation_matrix_y(np.pi).T
+    post_path = mesh_output_path.replace("_raw.obj", ".obj")
+    write_obj(post_path, pv, pc, pt)
+    return post_path

@@ -318,11 +318,12 @@ def test_library_exports_every_declared_symbol():
     from gaussiananything_amd import _lib, dit_ops
     L = _lib.lib()
     declared = set()
-    for hdr in ("ga_surfel.h", "ga_dit.h", "ga_decode.h"):
+    for hdr in ("ga_surfel.h", "ga_dit.h", "ga_decode.h", "ga_tsdf.h"):
         src = open(os.path.join(ROOT, "include", hdr)).read()
         declared |= set(re.findall(r"^\s*(?:int|size_t|const char \*)\s*(ga_[a-z0-9_]+)\s*\(", src, flags=re.M))
     assert {"ga_surfel_forward", "ga_surfel_workspace_layout", "ga_dit_forward", "ga_gemm_bf16",
-            "ga_attention_bf16", "ga_tiny_attention", "ga_surfel_head", "ga_layernorm_modulate"} <= declared
+            "ga_attention_bf16", "ga_tiny_attention", "ga_surfel_head", "ga_layernorm_modulate", "ga_tsdf_integrate",
+            "ga_tsdf_mesh_count", "ga_tsdf_mesh_emit", "ga_tsdf_mesh_scratch_bytes"} <= declared
     for name in declared:
         assert hasattr(L, name), name
     assert b"surfel" in L.ga_surfel_version() and b"dit" in dit_ops.lib().ga_dit_version()
