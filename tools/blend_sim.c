@@ -119,6 +119,8 @@ void blend_sim(int H, int W_img, int ntiles_x, int ntiles_y, const uint32_t *ran
                 if (nch > MAXCH) continue;
                 memset(cnt, 0, sizeof(cnt));
                 int lastc[4][64];
+                static long proxy[4][64];   /* survivors of the first 8 chunks whether or not the pixel is still alive */
+                memset(proxy, 0, sizeof(proxy));
                 for (int w = 0; w < 4; ++w) for (int l = 0; l < 64; ++l) lastc[w][l] = -1;
                 double pairs = 0;
                 for (int j = sb; j < se; ++j) {
@@ -142,6 +144,7 @@ void blend_sim(int H, int W_img, int ntiles_x, int ntiles_y, const uint32_t *ran
                             int w, l;
                             if (map == 0) { w = (y >> 3) * 2 + (x >> 3); l = (y & 7) * 8 + (x & 7); }
                             else { w = (y & 1) * 2 + (x & 1); l = (y >> 1) * 8 + (x >> 1); }
+                            if (ch < 8 && ((colm >> x) & 1) && ((rowm >> y) & 1)) proxy[w][l]++;
                             if (j < walked) {
                                 /* the lane is alive at this entry: its wave has to stage this chunk */
                                 if (ch > lastc[w][l]) lastc[w][l] = ch;
@@ -155,12 +158,12 @@ void blend_sim(int H, int W_img, int ntiles_x, int ntiles_y, const uint32_t *ran
                     static uint16_t flat[256][MAXCH]; static int fl[256]; long tot[256]; int ord[256];
                     for (int w = 0; w < 4; ++w) for (int l = 0; l < 64; ++l) {
                         memcpy(flat[w * 64 + l], cnt[w][l], sizeof(uint16_t) * nch); fl[w * 64 + l] = lastc[w][l];
-                        long s_ = 0; for (int c = 0; c < nch; ++c) s_ += cnt[w][l][c]; tot[w * 64 + l] = s_; ord[w * 64 + l] = w * 64 + l;
+                        long s_ = 0; for (int c = 0; c < nch; ++c) s_ += cnt[w][l][c]; tot[w * 64 + l] = map >= 4 ? proxy[w][l] : s_; ord[w * 64 + l] = w * 64 + l;
                     }
                     for (int a = 1; a < 256; ++a) { int v = ord[a], b = a - 1; while (b >= 0 && tot[ord[b]] < tot[v]) { ord[b + 1] = ord[b]; --b; } ord[b + 1] = v; }
                     for (int r = 0; r < 256; ++r) {
                         int w, l;
-                        if (map == 2) { w = r / 64; l = r % 64; }           /* sorted groups */
+                        if (map == 2 || map == 4) { w = r / 64; l = r % 64; }           /* sorted groups (4: by the proxy) */
                         else { w = r % 4; l = r / 4; }                      /* map 3: round-robin (every wave sees the same mix) */
                         memcpy(cnt[w][l], flat[ord[r]], sizeof(uint16_t) * nch); lastc[w][l] = fl[ord[r]];
                     }

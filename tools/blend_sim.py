@@ -63,7 +63,13 @@ def main():
     P = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
     # instruction model (wave-level VALU instructions): per staged chunk, per trip, per entry slot
     CS, CT, CE = 110.0, 12.0, 73.0
-    configs = [("current: quadrants, window 2, kU 4, 4 seg >= 1024", dict(window=2, kU=4, map=0, seg_min=1024, nseg=4)),
+    configs = [("PROXY sorted groups, window 2 (cur/nxt), kU 4", dict(window=2, kU=4, map=4, seg_min=2048, nseg=8)),
+               ("PROXY sorted groups, window 8, kU 4", dict(window=8, kU=4, map=4, seg_min=2048, nseg=8)),
+               ("PROXY sorted groups + pointer scheme, window 8, kU 2", dict(window=-8, kU=2, map=4, seg_min=2048, nseg=8)),
+               ("ORACLE sorted groups, window 8, kU 4", dict(window=8, kU=4, map=2, seg_min=2048, nseg=8)),
+               ("ORACLE sorted groups, window 4, kU 4", dict(window=4, kU=4, map=2, seg_min=2048, nseg=8)),
+               ("PROXY sorted groups, window 4, kU 4", dict(window=4, kU=4, map=4, seg_min=2048, nseg=8)),
+               ("current: quadrants, window 2, kU 4, 4 seg >= 1024", dict(window=2, kU=4, map=0, seg_min=1024, nseg=4)),
                ("quadrants, window 1", dict(window=1, kU=4, map=0, seg_min=1024, nseg=4)),
                ("quadrants, window 3", dict(window=3, kU=4, map=0, seg_min=1024, nseg=4)),
                ("quadrants, window 4", dict(window=4, kU=4, map=0, seg_min=1024, nseg=4)),

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 MAIN = os.path.join(ROOT, "gaussiananything_amd", "lib", "libga_mi355.so")
 shutil.copy(MAIN, MAIN + ".bak")
-shutil.copy(os.path.join(ROOT, "tools", "_build", "libga_stamps.so"), MAIN)
+shutil.copy(os.path.join(ROOT, "tools", "_build", "libga_%s.so" % (sys.argv[2] if len(sys.argv) > 2 else "stamps")), MAIN)
 try:
     from gaussiananything_amd import synthetic
     from gaussiananything_amd.diff_surfel_rasterization import SurfelForwardPlan
@@ -25,7 +25,7 @@ try:
     nwords = (cap // 256 + 1) * 15 * 256
     scr = ws.section("seg_scratch", torch.int64, nwords)
     nt = 8 * 1024
-    seg_region = min(cap // 256, 256)
+    seg_region = min(cap // 256, 512)
     nwg = seg_region + nt
     scr[OFF:OFF + nwg * 16].zero_()
     plan.run(); torch.cuda.synchronize()
