@@ -447,21 +447,35 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
                   a->vt, a->vt_col0, a->vt ? (a->N - a->vt_col0) / 64 : 0, a->vt_ld, a->qk_w0, a->qk_w1, a->qk_cols0,
                   a->qk_cols1, a->emit_x, a->emit_ss, a->emit_ld, a->row_ss, a->row_ss_tiles,
                   a->row_ss_dim > 0 ? 1.0f / (float)a->row_ss_dim : 0.f, a->row_ss_eps};
-    // Tile / ring choice from the grid size (256 CUs):
-    //   > 256 workgroups of 128x128          -> 128-row tiles, 2-slot ring (64 KiB): two workgroups share a CU
-    //   <= 256 of them, but > 128             -> 128-row tiles, 4-slot ring (128 KiB): one workgroup per CU, deep look-ahead
-    //   <= 128 (the N = 1024 GEMMs at M=1536) -> 64-row tiles, 4-slot ring (96 KiB): twice the workgroups
-    //   <= 64  (the same at M = 768: one CFG half alone in the cross-attention) -> 32-row tiles: four times
-    const long long wg128 = (long long)((a->N + BN - 1) / BN) * ((a->M + 127) / 128);
-    int cfg = wg128 > 256 ? 0 : (wg128 > 128 ? 1 : (wg128 > 64 ? 2 : 3));
-#ifdef GA_TUNING  // tuning builds only
-    if (const char *e = getenv("GA_GEMM_CFG")) cfg = atoi(e) % 4;
+    // Tile / ring choice (256 CUs).  A workgroup tile is 128 weight rows x 32 MT activation rows (MT = 4, 3, 2, 1); its work is
+    // proportional to MT plus a tile-independent share (prologue, weight tile, epilogue: about one MT unit, tools/gemm_sweep.py) and
+    // the launch ends with the busiest CU, so the cost of a choice is ceil(workgroups / 256) * (MT + 1)
+    // (two co-resident workgroups share their CU's LDS and matrix pipes: no faster than one after the other).  Ties go to the
+    // larger tile (fewer operand bytes per flop).  Examples at N = 4096: M = 1536 -> 96-row tiles, 512 workgroups, exactly two
+    // per CU (128-row tiles: 384 workgroups, half the CUs carry two of them: 10 units against 8); M = 768 -> 96-row tiles, 256
+    // workgroups, exactly one per CU (128-row tiles: 192 workgroups of 5 units against 4).
+    //   more than 256 workgroups -> 2-slot ring (<= 64 KiB): two workgroups per CU hide each other's latency
+    //   otherwise                -> 4-slot ring: one workgroup per CU, three K-tiles of look-ahead
+    const long long ncols = (a->N + BN - 1) / BN;
+    int mt = 4;
+    long long best = -1;
+    for (int cand = 4; cand >= 1; --cand) {
+        const long long wgs = ncols * ((a->M + 32 * cand - 1) / (32 * cand));
+        const long long cost = ((wgs + 255) / 256) * (cand + 1);
+        if (best < 0 || cost < best) { best = cost; mt = cand; }
+    }
+    long long wgs = ncols * ((a->M + 32 * mt - 1) / (32 * mt));
+    int nst = wgs > 256 ? 2 : 4;
+#ifdef GA_TUNING  // tuning builds only: GA_GEMM_CFG = 10 * MT + ring slots
+    if (const char *e = getenv("GA_GEMM_CFG")) { const int c = atoi(e); if (c / 10 >= 1 && c / 10 <= 4 && (c % 10 == 2 || c % 10 == 4)) { mt = c / 10; nst = c % 10; } }
 #endif
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KiB of dynamic LDS has to be opted into once per kernel
 #define GA_ATTR(E)                                                                                                  \
         (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<E, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   4 * (BN + 128) * BK * 2);                                                          \
+        (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<E, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  4 * (BN + 96) * BK * 2);                                                           \
         (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<E, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   4 * (BN + 64) * BK * 2);                                                           \
         (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<E, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -470,19 +484,17 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
 #undef GA_ATTR
         attr_set = true;
     }
-#define GA_LAUNCH(E)                                                                                               \
-    if (cfg == 0)                                                                                                  \
-        hipLaunchKernelGGL((gemm_bf16_kernel<E, 2, 4>), dim3((a->N + BN - 1) / BN, (a->M + 127) / 128), dim3(256),  \
-                           2 * (BN + 128) * BK * 2, s, p);                                                          \
-    else if (cfg == 1)                                                                                             \
-        hipLaunchKernelGGL((gemm_bf16_kernel<E, 4, 4>), dim3((a->N + BN - 1) / BN, (a->M + 127) / 128), dim3(256),  \
-                           4 * (BN + 128) * BK * 2, s, p);                                                          \
-    else if (cfg == 2)                                                                                             \
-        hipLaunchKernelGGL((gemm_bf16_kernel<E, 4, 2>), dim3((a->N + BN - 1) / BN, (a->M + 63) / 64), dim3(256),    \
-                           4 * (BN + 64) * BK * 2, s, p);                                                           \
-    else                                                                                                           \
-        hipLaunchKernelGGL((gemm_bf16_kernel<E, 4, 1>), dim3((a->N + BN - 1) / BN, (a->M + 31) / 32), dim3(256),    \
-                           4 * (BN + 32) * BK * 2, s, p);
+#define GA_LAUNCH_MT(E, NSTV, MTV)                                                                                   \
+    hipLaunchKernelGGL((gemm_bf16_kernel<E, NSTV, MTV>), dim3((unsigned)ncols, (unsigned)((a->M + 32 * MTV - 1) / (32 * MTV))), \
+                       dim3(256), NSTV * (BN + 32 * MTV) * BK * 2, s, p)
+#define GA_LAUNCH(E)                                                                                                 \
+    if (nst == 2) {                                                                                                  \
+        if (mt == 4) GA_LAUNCH_MT(E, 2, 4); else if (mt == 3) GA_LAUNCH_MT(E, 2, 3);                                  \
+        else if (mt == 2) GA_LAUNCH_MT(E, 2, 2); else GA_LAUNCH_MT(E, 2, 1);                                          \
+    } else {                                                                                                         \
+        if (mt == 4) GA_LAUNCH_MT(E, 4, 4); else if (mt == 3) GA_LAUNCH_MT(E, 4, 3);                                  \
+        else if (mt == 2) GA_LAUNCH_MT(E, 4, 2); else GA_LAUNCH_MT(E, 4, 1);                                          \
+    }
     switch (a->epilogue) {
     case GA_GEMM_EPI_STORE_BF16: GA_LAUNCH(0) break;
     case GA_GEMM_EPI_GELU_BF16: GA_LAUNCH(1) break;
