@@ -72,7 +72,7 @@ class GaTsdfFrame(ctypes.Structure):
 
 EXPORTS = ("ga_surfel_version", "ga_surfel_workspace_layout", "ga_surfel_forward", "ga_surfel_postprocess",
            "ga_surfel_backward", "ga_surfel_backward_scratch_bytes",
-           "ga_tsdf_integrate", "ga_tsdf_mesh_scratch_bytes", "ga_tsdf_mesh_count", "ga_tsdf_mesh_emit")
+           "ga_tsdf_integrate", "ga_tsdf_mesh_scratch_bytes", "ga_tsdf_mesh_count", "ga_tsdf_mesh_emit", "ga_mesh_write_obj")
 
 _lib = None
 
@@ -114,6 +114,8 @@ def lib():
         L.ga_tsdf_mesh_scratch_bytes.argtypes = [ctypes.POINTER(GaTsdfVolume)]
         L.ga_tsdf_mesh_count.restype = ctypes.c_int
         L.ga_tsdf_mesh_count.argtypes = [ctypes.POINTER(GaTsdfVolume), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+        L.ga_mesh_write_obj.restype = ctypes.c_int
+        L.ga_mesh_write_obj.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
         L.ga_tsdf_mesh_emit.restype = ctypes.c_int
         L.ga_tsdf_mesh_emit.argtypes = [ctypes.POINTER(GaTsdfVolume), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_int64,
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]

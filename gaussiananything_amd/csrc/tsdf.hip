@@ -441,3 +441,34 @@ extern "C" int ga_tsdf_mesh_emit(const GaTsdfVolume *volume, void *scratch, size
     if (num_triangles > 0) hipLaunchKernelGGL(mc_triangles_kernel, dim3(units), dim3(256), 0, s, v, m, triangles, (int)num_triangles);
     return hipGetLastError() == hipSuccess ? GA_OK : GA_ERR_LAUNCH;
 }
+
+// host: Wavefront OBJ with per-vertex colours (`v x y z r g b`, `f a b c` one-based) -- what o3d.io.write_triangle_mesh writes
+// for the reference (flow_matching_trainer.py:1297, 1311).  Host arrays; returns 0, or GA_ERR_NULL_ARG / GA_ERR_LAUNCH (I/O).
+#include <cstdio>
+#include <vector>
+extern "C" int ga_mesh_write_obj(const char *path, const float *vertices, const float *colors, const int32_t *triangles,
+                                 int64_t num_vertices, int64_t num_triangles)
+{
+    if (!path || (num_vertices > 0 && !vertices) || (num_triangles > 0 && !triangles) || num_vertices < 0 || num_triangles < 0)
+        return GA_ERR_NULL_ARG;
+    FILE *f = std::fopen(path, "w");
+    if (!f) return GA_ERR_LAUNCH;
+    std::vector<char> buf(1 << 22);
+    std::setvbuf(f, buf.data(), _IOFBF, buf.size());
+    std::fputs("# GaussianAnything mesh export (TSDF fusion of the rendered views)\n", f);
+    for (int64_t i = 0; i < num_vertices; ++i) {
+        const float *v = vertices + 3 * i;
+        if (colors) {
+            const float *c = colors + 3 * i;
+            std::fprintf(f, "v %.6f %.6f %.6f %.6f %.6f %.6f\n", v[0], v[1], v[2], c[0], c[1], c[2]);
+        } else {
+            std::fprintf(f, "v %.6f %.6f %.6f\n", v[0], v[1], v[2]);
+        }
+    }
+    for (int64_t i = 0; i < num_triangles; ++i) {
+        const int32_t *t = triangles + 3 * i;
+        std::fprintf(f, "f %d %d %d\n", t[0] + 1, t[1] + 1, t[2] + 1);
+    }
+    const bool bad = std::ferror(f) != 0;
+    return (std::fclose(f) != 0 || bad) ? GA_ERR_LAUNCH : GA_OK;
+}

@@ -5,8 +5,8 @@ Mirrors the reference's mesh export of a generated object, function by function:
     FlowMatchingEngine_gs.extract_mesh_bounded    /root/reference/nsr/lsgm/flow_matching_trainer.py:1318-1395
     to_cam_open3d_compat, post_process_mesh       /root/reference/utils/mesh_util.py:80-110, 22-44
 with Open3D's ScalableTSDFVolume (CPU, third party) replaced by ``TSDFVolume`` (HIP kernels, csrc/tsdf.hip; dense over the
-bounding cube, which 288 GB of HBM afford).  Fusion and marching cubes run on the GPU; the connected-component filter of
-``post_process_mesh`` and the OBJ writer are host code over the (small) finished mesh, as in the reference.  There is no CPU
+bounding cube, which 288 GB of HBM afford).  Fusion, marching cubes and the connected-component filter of ``post_process_mesh`` run on the GPU; the OBJ
+writer is a host function of the library.  There is no CPU
 fallback: without the HIP library the calls raise."""
 import ctypes
 import math
@@ -140,33 +140,55 @@ def extract_mesh_bounded(rgbmaps, depthmaps, alpha_maps, cam_pathes, aabb, alpha
     return volume.extract_triangle_mesh()
 
 
-def post_process_mesh(vertices: np.ndarray, colors: np.ndarray, triangles: np.ndarray):
-    """utils/mesh_util.py:22-44 on host arrays: keep the (at most) ten largest connected triangle clusters and none below 50
-    triangles (clusters = triangles joined through shared edges, Open3D's cluster_connected_triangles), then drop
-    unreferenced vertices and degenerate triangles."""
-    from scipy.sparse import coo_matrix
-    from scipy.sparse.csgraph import connected_components
-    t = np.asarray(triangles, dtype=np.int64)
-    if len(t) == 0:
-        return vertices[:0], colors[:0], t.astype(np.int32)
-    e = np.sort(np.concatenate([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]]), axis=1)
-    owner = np.tile(np.arange(len(t)), 3)
-    key = e[:, 0] * (int(t.max()) + 1) + e[:, 1]
-    order = np.argsort(key, kind="stable")
-    ks, ow = key[order], owner[order]
-    same = ks[1:] == ks[:-1]
-    graph = coo_matrix((np.ones(int(same.sum()), dtype=np.int8), (ow[:-1][same], ow[1:][same])), shape=(len(t), len(t)))
-    _, label = connected_components(graph, directed=False)
-    cluster_n = np.bincount(label)
-    cluster_to_keep = min(len(cluster_n), 10)
-    n_cluster = max(int(np.sort(cluster_n)[-cluster_to_keep]), 50)
+def post_process_mesh(vertices, colors, triangles):
+    """utils/mesh_util.py:22-44: keep the (at most) ten largest connected triangle clusters and none below 50 triangles
+    (clusters = triangles joined through shared edges, Open3D's cluster_connected_triangles), then drop unreferenced vertices
+    and degenerate triangles.  Tensors in, tensors out, on the tensors' device (the mesh of a generated object has about a
+    million triangles: Open3D and a scipy restatement take half a second on the host for this; here the edge sort, the
+    min-label propagation with pointer jumping and the compaction are device-wide torch operations, a few milliseconds).
+    numpy arrays are accepted too (and returned as numpy)."""
+    if isinstance(vertices, np.ndarray):
+        dev = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+        out = post_process_mesh(torch.from_numpy(vertices).to(dev), torch.from_numpy(colors).to(dev), torch.from_numpy(triangles).to(dev))
+        return tuple(o.cpu().numpy() for o in out)
+    t = triangles.long()
+    nt, nv = t.shape[0], vertices.shape[0]
+    if nt == 0:
+        return vertices[:0], colors[:0], triangles[:0].to(torch.int32)
+    dev = t.device
+    ea, eb = torch.cat([t[:, 0], t[:, 1], t[:, 2]]), torch.cat([t[:, 1], t[:, 2], t[:, 0]])
+    key, order = torch.sort(torch.minimum(ea, eb) * nv + torch.maximum(ea, eb))
+    owner = torch.arange(nt, device=dev).repeat(3)[order]
+    same = key[1:] == key[:-1]
+    a, b = owner[:-1][same], owner[1:][same]          # triangles that share an edge
+    label = torch.arange(nt, device=dev, dtype=torch.int32)   # (32-bit labels: native atomic min)
+    for _ in range(100000):
+        la, lb = label[a], label[b]
+        act = la != lb       # a pair whose ends already share a label changes nothing in this round; leaving it out keeps
+        aa, bb, la, lb = a[act], b[act], la[act].long(), lb[act].long()   # the atomics off the big clusters' representatives
+        m = torch.minimum(la, lb).to(torch.int32)
+        # hook the smaller label under both triangles and under their current representatives (links trees, not only
+        # neighbours: logarithmically many rounds instead of one per edge of the longest chain), then jump pointers
+        new = label.scatter_reduce(0, la, m, "amin").scatter_reduce(0, lb, m, "amin")
+        new = new.scatter_reduce(0, aa, m, "amin").scatter_reduce(0, bb, m, "amin")
+        new = new[new.long()]
+        new = new[new.long()]
+        if torch.equal(new, label):
+            break
+        label = new
+    post_process_mesh.rounds = _ + 1
+    label = label.long()
+    cluster_n = torch.bincount(label, minlength=nt)    # only the clusters' smallest triangles carry a count
+    sizes = torch.sort(cluster_n[cluster_n > 0]).values
+    cluster_to_keep = min(int(sizes.numel()), 10)
+    n_cluster = max(int(sizes[-cluster_to_keep]), 50)
     t = t[cluster_n[label] >= n_cluster]
-    used = np.unique(t)
-    remap = np.full(len(vertices), -1, dtype=np.int64)
-    remap[used] = np.arange(len(used))
+    used = torch.unique(t)
+    remap = torch.full((nv,), -1, dtype=torch.long, device=dev)
+    remap[used] = torch.arange(used.numel(), device=dev)
     t = remap[t]
     t = t[(t[:, 0] != t[:, 1]) & (t[:, 1] != t[:, 2]) & (t[:, 0] != t[:, 2])]
-    return vertices[used], colors[used], t.astype(np.int32)
+    return vertices[used], colors[used], t.to(torch.int32)
 
 
 def rotation_matrix_x(theta_degrees: float) -> np.ndarray:
@@ -182,15 +204,17 @@ def rotation_matrix_y(theta: float) -> np.ndarray:
     return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
 
 
-def write_obj(path: str, vertices: np.ndarray, colors: np.ndarray, triangles: np.ndarray):
-    """Wavefront OBJ with per-vertex colours (`v x y z r g b`), the form o3d.io.write_triangle_mesh gives a coloured mesh."""
+def write_obj(path: str, vertices, colors, triangles):
+    """Wavefront OBJ with per-vertex colours (`v x y z r g b`), the form o3d.io.write_triangle_mesh gives a coloured mesh;
+    written by the library's host function ga_mesh_write_obj (1.6 M lines in a fraction of a second)."""
+    def host(x, dt):
+        if isinstance(x, torch.Tensor):
+            x = x.detach().cpu().numpy()
+        return np.ascontiguousarray(x, dtype=dt)
+    v, c, t = host(vertices, np.float32), host(colors, np.float32), host(triangles, np.int32)
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    with open(path, "w") as f:
-        f.write("# GaussianAnything mesh export (TSDF fusion of the rendered views)\n")
-        for v, c in zip(np.asarray(vertices, dtype=np.float64), np.asarray(colors, dtype=np.float64)):
-            f.write("v %.6f %.6f %.6f %.6f %.6f %.6f\n" % (v[0], v[1], v[2], c[0], c[1], c[2]))
-        for t in np.asarray(triangles, dtype=np.int64) + 1:
-            f.write("f %d %d %d\n" % (t[0], t[1], t[2]))
+    _lib.check(_lib.lib().ga_mesh_write_obj(os.fsencode(path), v.ctypes.data, c.ctypes.data, t.ctypes.data, v.shape[0], t.shape[0]),
+               "ga_mesh_write_obj")
 
 
 def export_mesh_from_2dgs(all_rgbs, all_depths, all_alphas, cam_pathes, mesh_output_path: str, image_size: int = 512, device="cuda"):
@@ -199,11 +223,10 @@ def export_mesh_from_2dgs(all_rgbs, all_depths, all_alphas, cam_pathes, mesh_out
     (must end in `_raw.obj`)."""
     aabb = np.array([-0.45, -0.45, -0.45, 0.45, 0.45, 0.45]).reshape(2, 3) * 1.1
     v, c, t = extract_mesh_bounded(all_rgbs, all_depths, all_alphas, cam_pathes, aabb, image_size=image_size, device=device)
-    v, c, t = v.cpu().numpy(), c.cpu().numpy(), t.cpu().numpy()
     write_obj(mesh_output_path, v, c, t)
     pv, pc, pt = post_process_mesh(v, c, t)
-    pv = pv.astype(np.float64) @ rotation_matrix_x(-90).T
-    pv = pv @ rotation_matrix_y(np.pi).T
+    rot = torch.from_numpy(rotation_matrix_y(np.pi) @ rotation_matrix_x(-90)).to(pv.device)   # x by -90 degrees, then y by pi
+    pv = (pv.double() @ rot.T).float()
     post_path = mesh_output_path.replace("_raw.obj", ".obj")
     write_obj(post_path, pv, pc, pt)
     return post_path

@@ -78,6 +78,12 @@ int ga_tsdf_mesh_count(const GaTsdfVolume *volume, void *scratch, size_t scratch
 int ga_tsdf_mesh_emit(const GaTsdfVolume *volume, void *scratch, size_t scratch_bytes, int64_t num_vertices, int64_t num_triangles,
                       float *vertices, float *colors, int32_t *triangles, void *stream);
 
+/* host: write a triangle mesh (HOST arrays: vertices [nv,3], colors [nv,3] in [0,1] or NULL, triangles [nt,3] zero-based) as
+ * Wavefront OBJ with per-vertex colours, replacing o3d.io.write_triangle_mesh (flow_matching_trainer.py:1297, 1311).
+ * GA_ERR_LAUNCH reports an I/O failure. */
+int ga_mesh_write_obj(const char *path, const float *vertices, const float *colors, const int32_t *triangles,
+                      int64_t num_vertices, int64_t num_triangles);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,13 +51,22 @@ def test_mesh_matches_the_oracle_vertex_by_vertex_and_triangle_by_triangle(gpu_d
     t, w, c = hvol.dense()
     ovol.tsdf[:], ovol.weight[:], ovol.color[:] = t, w, c
     ov, oc, ot = otsdf.extract_mesh(ovol)
-    hv, hc, ht = (x.cpu().numpy() for x in hvol.extract_triangle_mesh())
+    dv, dc, dt = hvol.extract_triangle_mesh()
+    hv, hc, ht = (x.cpu().numpy() for x in (dv, dc, dt))
     assert len(ot) > 2000
     assert hv.shape == ov.shape and ht.shape == ot.shape
     assert np.array_equal(ht, ot), "triangle index lists differ"
     assert float(np.abs(hv - ov).max()) <= 1e-6 and float(np.abs(hc - oc).max()) <= 1e-6
     r = np.linalg.norm(hv.astype(np.float64) - np.array([0.02, -0.01, 0.03]), axis=1)
     assert np.abs(r - 0.28).mean() < 0.004
+    # the connected-component filter on the device against the host restatement (scipy), with floaters added
+    fv = torch.tensor([[2, 2, 2], [2.1, 2, 2], [2, 2.1, 2], [2, 2, 2.1]], dtype=torch.float32, device=gpu_device)
+    ft = torch.tensor([[0, 1, 2], [0, 1, 3], [0, 2, 3], [1, 2, 3]], dtype=torch.int32, device=gpu_device) + dv.shape[0]
+    v2, c2, t2 = torch.cat([dv, fv]), torch.cat([dc, torch.zeros_like(fv)]), torch.cat([dt, ft])
+    pv, pc, pt = mesh.post_process_mesh(v2, c2, t2)
+    ov2, oc2, ot2 = otsdf.post_process_mesh(v2.cpu().numpy(), c2.cpu().numpy(), t2.cpu().numpy())
+    assert np.array_equal(pt.cpu().numpy(), ot2) and np.array_equal(pv.cpu().numpy(), ov2) and np.array_equal(pc.cpu().numpy(), oc2)
+    assert len(ot2) < len(t2)
 
 
 def test_partially_observed_volume_and_empty_volume(gpu_device):

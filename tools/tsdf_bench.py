@@ -49,10 +49,14 @@ def main():
                "fuse8_ms_wall": round((t2 - t1) * 1e3, 3), "fuse8_ms_device": round(ev[0].elapsed_time(ev[1]), 3),
                "mesh_ms": round((t3 - t2) * 1e3, 3), "vertices": int(v.shape[0]), "triangles": int(t.shape[0]),
                "integrate_bytes_per_frame_upper": opened * 4096 * 20 * 2}
+    for rep in range(3):
+        torch.cuda.synchronize(); tt = time.perf_counter()
+        pv, pc, pt = mesh.post_process_mesh(v, c, t)
+        torch.cuda.synchronize(); res["post_process_ms"] = round((time.perf_counter() - tt) * 1e3, 2)
+    res["post_triangles"] = int(pt.shape[0]); res["post_process_rounds"] = mesh.post_process_mesh.rounds
     tt = time.perf_counter()
-    pv, pc, pt = mesh.post_process_mesh(v.cpu().numpy(), c.cpu().numpy(), t.cpu().numpy())
-    res["post_process_host_ms"] = round((time.perf_counter() - tt) * 1e3, 1)
-    res["post_triangles"] = int(len(pt))
+    mesh.write_obj("/tmp/tsdf_bench_raw.obj", v, c, t)
+    res["write_obj_raw_ms"] = round((time.perf_counter() - tt) * 1e3, 1)
     print(json.dumps(res))
 
 
