@@ -436,6 +436,59 @@ def bench_decode(dev, cams, reps=5):
             "note": "random weights: timing and shapes are those of the release, the surfels are not a meaningful object"}
 
 
+def bench_backward(m, o, c, s, r, cams, H, W, dev, reps=8):
+    """forward + backward of the rasterizer through torch.autograd (ga_surfel_backward) on the bench workload."""
+    from gaussiananything_amd.diff_surfel_rasterization import rasterize_views
+    torch.manual_seed(0)
+    leaves = [t.detach().clone().requires_grad_(True) for t in (m, o, c, s, r)]
+    vm, pm = cams["cam_view"].to(dev), cams["cam_view_proj"].to(dev)
+    bg = torch.ones(3, device=dev)
+    wc = torch.rand(vm.shape[0], 3, H, W, device=dev)
+    wo = torch.rand(vm.shape[0], 7, H, W, device=dev) * 0.1
+    fwd, bwd = [], []
+    for k in range(reps + 2):
+        for t in leaves:
+            t.grad = None
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        color, _, allmap, _ = rasterize_views(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], vm, pm, bg, H, W)
+        e[1].record()
+        ((color * wc).sum() + (allmap * wo).sum()).backward()
+        e[2].record()
+        torch.cuda.synchronize()
+        if k >= 2:
+            fwd.append(e[0].elapsed_time(e[1])); bwd.append(e[1].elapsed_time(e[2]))
+    return {"forward_autograd_ms": round(float(np.median(fwd)), 4), "loss_plus_backward_ms": round(float(np.median(bwd)), 4),
+            "grads_finite": bool(all(torch.isfinite(t.grad).all() for t in leaves)),
+            "note": "forward through the autograd Function (own workspace per call); backward = ga_surfel_backward + the loss's "
+                    "elementwise kernels; per-kernel times: profiles/r2_backward_kernel_stats.txt"}
+
+
+def bench_mesh_export(g, cams, dev):
+    """the reference's mesh export (flow_matching_trainer.py:1244-1395) on 8 rendered 512^2 views of the bench scene."""
+    from gaussiananything_amd import mesh
+    from gaussiananything_amd.gs_surfel import GaussianRenderer2DGS
+    nv = int(cams["cam_view"].shape[0])
+    rnd = GaussianRenderer2DGS(512, nv, {})
+    cv, cvp, cp = (cams[k][None].to(dev) for k in ("cam_view", "cam_view_proj", "cam_pos"))
+    out = rnd.render(g[None].to(dev), cv, cvp, cp, cams["tanfov"])
+    rgbs, depths, alphas = ([out[k][0, i][None] for i in range(nv)] for k in ("image", "depth", "alpha"))
+    cam_pathes = [{"cam_view": cams["cam_view"][i], "cam_pos": cams["cam_pos"][i], "tanfov": cams["tanfov"]} for i in range(nv)]
+    aabb = np.array([-0.45, -0.45, -0.45, 0.45, 0.45, 0.45]).reshape(2, 3) * 1.1
+    res = {}
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        v, c, t = mesh.extract_mesh_bounded(rgbs, depths, alphas, cam_pathes, aabb, device=dev)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        pv, pc, pt = mesh.post_process_mesh(v, c, t)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        res = {"fuse_and_extract_ms": round((t1 - t0) * 1e3, 3), "post_process_ms": round((t2 - t1) * 1e3, 3),
+               "views": nv, "vertices": int(v.shape[0]), "triangles": int(t.shape[0]), "post_triangles": int(pt.shape[0])}
+    res["note"] = ("volume allocation (0.87 GB zero-fill) + 8 x ga_tsdf_integrate + marching cubes, then the device connected-component "
+                   "filter; per-phase times: profiles/r2_tsdf_bench.json; Open3D on the CPU in the reference")
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -450,6 +503,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed HIP-vs-oracle check of the bench workload")
     ap.add_argument("--no-dit", action="store_true", help="skip the DiT/SiT denoiser and cascade sections of the report")
     ap.add_argument("--no-cascade", action="store_true", help="skip the cascaded-sample section (BASELINE configs[3]/[4])")
+    ap.add_argument("--no-extras", action="store_true", help="skip the rasterizer-backward and mesh-export sections (SURVEY 8(f)-4)")
     ap.add_argument("--dit-nfe", type=int, default=20)
     a = ap.parse_args()
 
@@ -603,6 +657,9 @@ def main():
             out["attention"] = bench_attention(dev)
             out["decode"] = bench_decode(dev, cams)
             out["conditioner"] = bench_conditioner(dev)
+        if world == 1 and not a.no_extras and not a.no_dit:   # (--no-dit is the quick rasterizer-only mode of the tools)
+            out["backward"] = bench_backward(m, o, c, s, r, cams, H, W, dev)
+            out["mesh_export"] = bench_mesh_export(g, cams, dev)
     # ---- BASELINE configs[3] / [4]: one cascaded sample per GPU, every rank takes part -------------------------------
     if not a.no_dit and not a.no_cascade:
         del plan
