@@ -107,3 +107,27 @@ def test_post_process_keeps_large_clusters_only_and_obj_writer(tmp_path):
     assert sum(l.startswith("v ") for l in lines) == len(v) and sum(l.startswith("f ") for l in lines) == len(t)
     assert np.allclose(mesh.rotation_matrix_x(-90) @ np.array([0, 1, 0]), [0, 0, -1]) and np.allclose(
         mesh.rotation_matrix_y(np.pi) @ np.array([1, 0, 0]), [-1, 0, 0], atol=1e-12)
+
+
+def test_camera_conversion_and_post_processing_against_the_reference_s_own_functions():
+    """tests/golden/mesh_cam_ref.npz: produced by running /root/reference/utils/mesh_util.py (to_cam_open3d_compat,
+    post_process_mesh) itself, see tests/golden/make_mesh_golden.py."""
+    import torch
+    from gaussiananything_amd import cameras, mesh, synthetic
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "mesh_cam_ref.npz"))
+    cams = synthetic.eval_cameras(8)
+    for i in range(8):
+        c = {"cam_view": cams["cam_view"][i], "cam_pos": cams["cam_pos"][i], "tanfov": cams["tanfov"]}
+        intr, ext = mesh.to_cam_open3d_compat(c, 512)
+        assert intr == tuple(z["intrinsics"][i][:4]), (intr, z["intrinsics"][i])
+        assert np.array_equal(ext, z["extrinsics"][i])
+    # ... and the branch that takes the reference's projection matrix
+    fov = cameras.focal2fov(float(cams["poses"][0][16]), 1)
+    pm = cameras.getProjectionMatrix(0.01, 100.0, fov, fov).transpose(0, 1)
+    intr2, ext2 = mesh.to_cam_open3d_compat({"cam_view": cams["cam_view"][0], "projection_matrix": pm}, 512)
+    assert intr2 == tuple(z["intrinsics"][0][:4]) and np.array_equal(ext2, z["extrinsics"][0])
+    pv, pc, pt = mesh.post_process_mesh(torch.from_numpy(z["pp_vertices"]), torch.zeros(len(z["pp_vertices"]), 3),
+                                        torch.from_numpy(z["pp_triangles"]))
+    assert np.array_equal(pt.numpy(), z["pp_out_triangles"]) and np.array_equal(pv.numpy(), z["pp_out_vertices"])
+    ov, oc, ot = otsdf.post_process_mesh(z["pp_vertices"], np.zeros((len(z["pp_vertices"]), 3), np.float32), z["pp_triangles"])
+    assert np.array_equal(ot, z["pp_out_triangles"]) and np.array_equal(ov, z["pp_out_vertices"])
