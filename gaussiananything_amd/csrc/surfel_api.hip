@@ -39,7 +39,7 @@ int ga_surfel_workspace_layout(int32_t num_points, int32_t num_views, int32_t im
     const size_t nv = (size_t)d.N * d.V, nt = (size_t)d.V * d.tiles, cap = (size_t)capacity;
     size_t off = 0;
     out->status = off;      off += align256(GA_STATUS_WORDS * sizeof(int64_t));
-    out->seg_sync = off;    off += align256(4 * (cap / 1024 + 1) * 4);
+    out->seg_sync = off;    off += align256(8 * (cap / 1024 + 1) * 4);
     out->tile_count = off;  off += align256(nt * 4);
     out->tile_start = off;  off += align256((nt + 1) * 4);
     out->tile_cursor = off; off += align256(nt * 4);

@@ -81,6 +81,8 @@ struct __attribute__((aligned(16))) Ring {
     uint32_t stamp[kItemChunks];   // k + 1 once chunk k of the item is in slot k % kItemChunks
     uint32_t done[4];              // unsegmented lists of more than kItemChunks chunks only: chunks finished by consumer q
     uint32_t work;                 // work item of this workgroup (ticket broadcast)
+    uint32_t sat;                  // segmented tile: nsegs - k of the earliest segment k known to end every pixel's walk (0: none)
+    uint32_t sat_waves[2];         // quadrants of this segment whose pixels are all finished after pass 1 / pass 2
 };
 
 __device__ __forceinline__ uint32_t lds_load(const uint32_t *p)
@@ -431,8 +433,43 @@ struct BlendArgs {
     int flags;
 };
 
+// A segment's quadrant has published what it has to: count it; the last one of the tile's segments to arrive adds the partial
+// sums in list order (with the cross terms of the depth distortion) and writes the pixels.  The loop ends at the first segment
+// after which every pixel of the quadrant is finished: later segments may have left without partial sums (see `sat`).
+__device__ __forceinline__ void finish_segment(const BlendArgs &k, const Dims &dm, int lane, uint32_t pos, uint32_t work0,
+                                               uint32_t wstride, uint32_t nsegs, int px, int v, int pxi, int pyi, bool inside, uint32_t *arrive)
+{
+    uint32_t arrived = 0;
+    if (lane == 0) arrived = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    arrived = __builtin_amdgcn_readfirstlane(arrived);
+    if (arrived != nsegs - 1) return;
+    PixelAcc r = fresh_pixel(1.0f);
+    bool dead = !inside;
+    for (uint32_t s2 = 0; s2 < nsegs; ++s2) {
+        if (__builtin_amdgcn_ballot_w64(!dead) == 0) break;
+        const unsigned long long *q = k.seg_scratch + (size_t)(work0 + s2 * wstride) * kSegFloats + 256 + px;
+        float tt[14];
+#pragma unroll
+        for (int f = 0; f < 14; ++f) tt[f] = xwg_load(q + f * 256, k.epoch);
+        if (!dead) {
+            const float Wk = tt[13] - tt[11];
+            r.N2C0.y += tt[0]; r.C12.x += tt[1]; r.C12.y += tt[2];
+            r.N01.x += tt[3]; r.N01.y += tt[4]; r.N2C0.x += tt[5];
+            r.Dp += tt[6];
+            r.dist += tt[9] + r.M.y * Wk - 2.0f * r.M.x * tt[7];
+            r.M.x += tt[7];
+            r.M.y += tt[8];
+            if (tt[10] >= 0.0f) r.median = tt[10];
+            r.T = tt[11];
+            dead = tt[12] != 0.0f;
+        }
+    }
+    if (inside) write_pixel(r, k.bg, dm, v, pxi, pyi, k.out_color, k.out_others);
+}
+
 __device__ __forceinline__ void blend_item(Ring &ring, const BlendArgs &k, const Dims &dm, int lane, int wave, uint32_t pos,
-                                           const uint4 sched, uint32_t seg, uint32_t nsegs, uint32_t work, Stats &st)
+                                           const uint4 sched, uint32_t seg, uint32_t nsegs, uint32_t work, uint32_t wstride,
+                                           Stats &st)
 {
     const uint32_t *__restrict__ point_list = k.point_list;
     const float *__restrict__ record = k.record;
@@ -454,6 +491,22 @@ __device__ __forceinline__ void blend_item(Ring &ring, const BlendArgs &k, const
     const bool last_seg = seg + 1 == nsegs;
     const float4 *rec4 = reinterpret_cast<const float4 *>(record) + (size_t)v * dm.N * (kRec / 4);
     const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
+
+    // SATURATED TILE.  Once every pixel of the tile has ended its walk inside segment k (the stop rule fired, or the
+    // segment's own transmittance product is already below it), the segments after k contribute nothing: a segment that
+    // finds this out before it starts (ring.sat, read once per workgroup) publishes a zero transmittance for the segments
+    // that may still multiply it in, counts itself as arrived and leaves -- no staging, no walk.  On an opaque object most
+    // of a long list lies behind the surface (1 M surfels x 8 views x 512^2, lists of up to 52 060 entries: blend 3.38 -> 2.38 ms).
+    if (nsegs > 1 && ring.sat != 0 && seg > nsegs - ring.sat) {
+        if (tx * kTile + (wave & 1) * 8 >= dm.W || ty * kTile + (wave >> 1) * 8 >= dm.H) return;   // quadrant outside the image
+        const int col = (wave & 1) * 8 + (lane & 7), row = (wave >> 1) * 8 + (lane >> 3);
+        const int pxi = tx * kTile + col, pyi = ty * kTile + row;
+        const int px = wave * 64 + lane;
+        if (!last_seg) xwg_store(seg_scratch + (size_t)work * kSegFloats + px, 0.0f, epoch);
+        finish_segment(k, dm, lane, pos, work - seg * wstride, wstride, nsegs, px, v, pxi, pyi, pxi < dm.W && pyi < dm.H,
+                       seg_sync + 8 * (size_t)pos + wave);
+        return;
+    }
 
     // my share of the staging (the others wait for it, so even a quadrant outside the image does it)
     Duty duty;
@@ -487,18 +540,22 @@ __device__ __forceinline__ void blend_item(Ring &ring, const BlendArgs &k, const
         else consume<true, false>(ring, c, nch, a, done, st, flags, duty);
         if (inside) write_pixel(a, bg, dm, v, pxi, pyi, out_color, out_others);
     } else {
-        const uint32_t work0 = work - seg;                      // work item of segment 0 of this tile
+        const uint32_t work0 = work - seg * wstride;            // work item of segment 0 of this tile (segment k: + k * wstride)
         const int px = wave * 64 + lane;                        // pixel index inside the scratch records
-        uint32_t *arrive = seg_sync + 4 * (size_t)pos + wave;
+        uint32_t *arrive = seg_sync + 8 * (size_t)pos + wave;
+        uint32_t *satw = seg_sync + 8 * (size_t)pos + 4;     // nsegs - k of the earliest saturating segment k (atomic max)
         unsigned long long *mine = seg_scratch + (size_t)work * kSegFloats;
         if (!last_seg) {   // pass 1: transmittance of my segment (nobody needs that of the last one)
             bool d1 = !inside;
             consume<false, false>(ring, c, nch, a, d1, st, flags, duty);
             xwg_store(mine + px, a.T, epoch);
+            // every pixel of my quadrant is finished by this segment alone; the fourth quadrant to say so marks the tile
+            if (__builtin_amdgcn_ballot_w64(!d1) == 0 && lane == 0 && atomicAdd(&ring.sat_waves[0], 1u) == 3u)
+                __hip_atomic_fetch_max(satw, nsegs - seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // transmittance on entering my segment: product over the lower segments (they started before me: tickets)
         float P = 1.0f;
-        for (uint32_t k = 0; k < seg; ++k) P *= xwg_load(seg_scratch + (size_t)(work0 + k) * kSegFloats + px, epoch);
+        for (uint32_t k = 0; k < seg; ++k) P *= xwg_load(seg_scratch + (size_t)(work0 + k * wstride) * kSegFloats + px, epoch);
         // pass 2: the sequential blend of my segment, entered with the global transmittance
         a = fresh_pixel(P);
         done = done || P < 0.0001f;  // T never falls below 1e-4 in the sequential loop: it stopped before this segment
@@ -509,32 +566,10 @@ __device__ __forceinline__ void blend_item(Ring &ring, const BlendArgs &k, const
                                 a.median, a.T, done ? 1.0f : 0.0f, P};
 #pragma unroll
         for (int f = 0; f < 14; ++f) xwg_store(o + f * 256, part[f], epoch);
-        uint32_t arrived = 0;
-        if (lane == 0) arrived = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        arrived = __builtin_amdgcn_readfirstlane(arrived);
-        if (arrived == nsegs - 1) {   // the last segment to finish this quadrant adds the partial sums in list order
-            PixelAcc r = fresh_pixel(1.0f);
-            bool dead = false;
-            for (uint32_t k = 0; k < nsegs; ++k) {
-                const unsigned long long *q = seg_scratch + (size_t)(work0 + k) * kSegFloats + 256 + px;
-                float tt[14];
-#pragma unroll
-                for (int f = 0; f < 14; ++f) tt[f] = xwg_load(q + f * 256, epoch);
-                if (!dead) {
-                    const float Wk = tt[13] - tt[11];
-                    r.N2C0.y += tt[0]; r.C12.x += tt[1]; r.C12.y += tt[2];
-                    r.N01.x += tt[3]; r.N01.y += tt[4]; r.N2C0.x += tt[5];
-                    r.Dp += tt[6];
-                    r.dist += tt[9] + r.M.y * Wk - 2.0f * r.M.x * tt[7];
-                    r.M.x += tt[7];
-                    r.M.y += tt[8];
-                    if (tt[10] >= 0.0f) r.median = tt[10];
-                    r.T = tt[11];
-                    dead = tt[12] != 0.0f;
-                }
-            }
-            if (inside) write_pixel(r, bg, dm, v, pxi, pyi, out_color, out_others);
-        }
+        // ... or every pixel has ended its walk by the end of this segment (the exact, global statement)
+        if (__builtin_amdgcn_ballot_w64(!done) == 0 && lane == 0 && atomicAdd(&ring.sat_waves[1], 1u) == 3u)
+            __hip_atomic_fetch_max(satw, nsegs - seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        finish_segment(k, dm, lane, pos, work0, wstride, nsegs, px, v, pxi, pyi, inside, arrive);
     }
 }
 
@@ -588,9 +623,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
             // start at 0)
             int b = kSegClass;
             while (b < 32 && seg_table[2 * b + 1] > work) ++b;
+            // inside a class the work items run segment-major (segment 0 of all its tiles, then segment 1, ...): a tile's later
+            // segments start late enough to find the tile saturated, and still only ever wait for lower tickets
             const uint32_t nsegs = seg_count(b), rel = work - seg_table[2 * b + 1];
-            const uint32_t pos = seg_table[2 * b] + rel / nsegs;
-            blend_item(ring, k, dm, lane, wave, pos, k.tile_order[pos], rel % nsegs, nsegs, work, st);
+            const uint32_t ntile = seg_table[2 * (b - 1)] - seg_table[2 * b];
+            const uint32_t pos = seg_table[2 * b] + rel % ntile;
+            if (threadIdx.x == 0) {   // one reading of the tile's saturation word for the whole workgroup
+                ring.sat = __hip_atomic_load(k.seg_sync + 8 * (size_t)pos + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ring.sat_waves[0] = 0; ring.sat_waves[1] = 0;
+            }
+            __syncthreads();
+            blend_item(ring, k, dm, lane, wave, pos, k.tile_order[pos], rel / ntile, nsegs, work, ntile, st);
             __syncthreads();   // everybody has left the item: the LDS image and the ticket word may be overwritten
         }
     } else {
@@ -601,7 +644,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
         if (threadIdx.x < kItemChunks) ring.stamp[threadIdx.x] = 0;
         if (threadIdx.x < 4) ring.done[threadIdx.x] = 0;
         __syncthreads();
-        blend_item(ring, k, dm, lane, wave, pos, my_sched, 0u, 1u, 0u, st);
+        blend_item(ring, k, dm, lane, wave, pos, my_sched, 0u, 1u, 0u, 0u, st);
     }
     if ((k.flags & GA_SURFEL_FLAG_STATS) && lane == 0) {
         atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_ITERS), (unsigned long long)st.iters);

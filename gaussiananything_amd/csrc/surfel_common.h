@@ -54,7 +54,7 @@ struct Dims {
 
 struct Workspace {
     int64_t *status;
-    uint32_t *seg_sync;   // [4 * ntile_cap] arrival counters per (segmented tile, quadrant)
+    uint32_t *seg_sync;   // [8 * ntile_cap] per segmented tile: arrival counters of the four quadrants, saturation word
     uint32_t *seg_table;  // [2 * 40] per class b: (first tile_order slot, first segment work item)
     unsigned long long *seg_scratch;   // (value, launch epoch) words, see surfel_blend.hip
     uint32_t *tile_count, *tile_start, *tile_cursor;

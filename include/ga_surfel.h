@@ -83,8 +83,8 @@ typedef struct GaSurfelForwardArgs {
  * (rect, tile ranges, sorted point list) straight out of the workspace through these offsets. */
 typedef struct GaSurfelWorkspaceLayout {
     size_t status;      /* int64[GA_STATUS_WORDS]                                                  */
-    size_t seg_sync;    /* uint32[4*(capacity/1024+1)] per (segmented tile, quadrant) arrival counters of the segmented
-                           blend; cleared with the status words */
+    size_t seg_sync;    /* uint32[8*(capacity/1024+1)] per segmented tile: four per-quadrant arrival counters and the
+                           saturation word of the segmented blend; cleared with the status words */
     size_t tile_count;  /* uint32[V*tiles]   entries per (view, tile)                             */
     size_t tile_start;  /* uint32[V*tiles+1] exclusive scan of tile_count                         */
     size_t tile_cursor; /* uint32[V*tiles]   scratch of the fill pass                             */
