@@ -153,7 +153,7 @@ typedef struct GaSurfelBackwardArgs {
 size_t ga_surfel_backward_scratch_bytes(const GaSurfelForwardArgs *fwd);   /* 0: bad shape */
 int ga_surfel_backward(const GaSurfelBackwardArgs *args, void *stream);
 
-/* host: library identification, e.g. "ga_mi355 surfel gfx950 r1" */
+/* host: library identification, e.g. "ga_mi355 surfel gfx950 r2" */
 const char *ga_surfel_version(void);
 
 #ifdef __cplusplus
