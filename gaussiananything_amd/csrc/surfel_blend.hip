@@ -582,6 +582,9 @@ __device__ __forceinline__ void blend_item(Ring &ring, const BlendArgs &k, const
 #ifndef GA_BLEND_WAVES
 #define GA_BLEND_WAVES 3
 #endif
+#ifndef GA_BLEND_XCD_RUNS
+#define GA_BLEND_XCD_RUNS 3   // log2 of the run length (0: off)
+#endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WAVES, GA_BLEND_WAVES))) void surfel_blend_kernel(BlendArgs k, Dims dm, int ntiles,
                                                            uint32_t seg_region,
                                                            const uint32_t *__restrict__ seg_table,
@@ -589,7 +592,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
 {
     __shared__ Ring ring;
     // (requested before the status words are looked at: on overflow the entry is stale but the slot exists)
-    const uint4 my_sched = k.tile_order[blockIdx.x >= seg_region ? blockIdx.x - seg_region : 0u];
+    // schedule slot of a tile workgroup: runs of 2^GA_BLEND_XCD_RUNS consecutive slots -- tiles of one view and one pair of tile rows that
+    // fall into the same length class (the order the tile scan leaves inside a class) -- go to workgroups eight apart, i.e.
+    // to ONE XCD (workgroup ids are dealt round-robin to the eight XCDs), whose L2 then serves the records neighbouring tiles
+    // share; a transposition inside blocks of 8 runs, so the longest-first order and the balance between XCDs stay
+    uint32_t tslot = blockIdx.x >= seg_region ? blockIdx.x - seg_region : 0u;
+#if GA_BLEND_XCD_RUNS
+    {
+        constexpr uint32_t kRun = 1u << GA_BLEND_XCD_RUNS, kBlock = 8u * kRun;   // run length, slots per transposed block
+        if ((tslot | (kBlock - 1u)) < (uint32_t)ntiles) tslot = (tslot & ~(kBlock - 1u)) | ((tslot & 7u) * kRun) | ((tslot / 8u) & (kRun - 1u));
+    }
+#endif
+    const uint4 my_sched = k.tile_order[tslot];
     const int64_t overflow = status[GA_STATUS_OVERFLOW], nlong64 = status[GA_STATUS_LONG_TILES];
     const int64_t segwork64 = status[GA_STATUS_SEG_WORK];
     if (overflow) return;
@@ -639,7 +653,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
     } else {
         // schedule slot = block index: no dependence on the status words (one load latency less before the first record
         // arrives); the slots of the segmented tiles lead the schedule and belong to the segment region
-        const uint32_t pos = blockIdx.x - seg_region;
+        const uint32_t pos = tslot;
         if (pos < nlong) return;
         if (my_sched.z == 0) {   // empty list (more than half of the tiles at BASELINE configs[1]): background pixels, nothing else
             const int v = (int)(my_sched.x / (uint32_t)dm.tiles), tile = (int)(my_sched.x - (uint32_t)v * dm.tiles);
