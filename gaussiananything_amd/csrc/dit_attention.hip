@@ -48,6 +48,9 @@ __device__ unsigned long long g_attn_stamps[8 * 16 * 16];
 
 constexpr int KB = 64, HD = 64;
 constexpr int TILE = KB * HD;  // elements of one staged tile (8 KiB)
+#ifndef GA_ATTN_HEAD_MAJOR
+#define GA_ATTN_HEAD_MAJOR 1
+#endif
 #ifndef GA_ATTN_ABLATE
 #define GA_ATTN_ABLATE 0   // tools/attn_ablate.sh builds timing-only variants with phases removed (wrong results)
 #endif
@@ -91,7 +94,13 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: uniform branches
     const int ks = wave / NW, wq = wave - ks * NW, tg = tid - ks * GT;
     const int g = lane >> 4, c16 = lane & 15;
+#if GA_ATTN_HEAD_MAJOR
+    // grid (heads * batch, query tiles): the workgroups of one (batch, head) have ids heads * batch apart -- a multiple of 8 for
+    // the DiT's 12 / 16 heads x even batch -- so they sit on ONE XCD and share its L2 copy of the head's K / V^T
+    const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads, q0 = blockIdx.y * QB + wq * 16;
+#else
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB + wq * 16;
+#endif
     const int Lq = a.Lq, Lk = a.Lk;
     uint16_t *sK = smem + ks * 6 * TPS * TILE, *sV = sK + 3 * TPS * TILE;
 
@@ -393,7 +402,11 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
 template <int NW, int KS>
 static void launch_attention(const GaAttentionArgs &a, hipStream_t s)
 {
+#if GA_ATTN_HEAD_MAJOR
+    const dim3 grid(a.heads * a.batch, (a.Lq + NW * 16 - 1) / (NW * 16), 1);
+#else
     const dim3 grid((a.Lq + NW * 16 - 1) / (NW * 16), a.heads, a.batch);
+#endif
     if (a.k_norm_weight) hipLaunchKernelGGL((attention_fwd_kernel<NW, KS, true>), grid, dim3(NW * KS * 64), 0, s, a);
     else hipLaunchKernelGGL((attention_fwd_kernel<NW, KS, false>), grid, dim3(NW * KS * 64), 0, s, a);
 }
