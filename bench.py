@@ -122,7 +122,7 @@ def bench_attention(dev, reps=50):
         out[name] = {"us": round(us, 2), "tflops": round(fl / (us * 1e-6) / 1e12, 1),
                      "frac_of_bf16_mfma_peak": round(fl / (us * 1e-6) / 1e12 / 2500.0, 4)}
     out["note"] = ("launches on torch's current stream, timed with events on that stream; MFMA-busy counters of the same kernels: "
-                   "profiles/r1f_attention_pmc.txt (the kernel is unchanged since)")
+                   "profiles/r1f_attention_pmc.txt (the kernel body is unchanged since; round 2 made the grid head-major)")
     return out
 
 
