@@ -131,3 +131,35 @@ def test_camera_conversion_and_post_processing_against_the_reference_s_own_funct
     assert np.array_equal(pt.numpy(), z["pp_out_triangles"]) and np.array_equal(pv.numpy(), z["pp_out_vertices"])
     ov, oc, ot = otsdf.post_process_mesh(z["pp_vertices"], np.zeros((len(z["pp_vertices"]), 3), np.float32), z["pp_triangles"])
     assert np.array_equal(ot, z["pp_out_triangles"]) and np.array_equal(ov, z["pp_out_vertices"])
+
+
+def test_random_fields_give_closed_meshes_through_every_ambiguous_case():
+    """White-noise signs put every one of the 256 cube cases, including all ambiguous faces, next to every other: the derived
+    table must still give a surface without cracks -- every mesh edge that is not on the volume's outer faces is shared by
+    exactly two triangles, with opposite directions."""
+    rng = np.random.default_rng(7)
+    vol = otsdf.Volume((2, 2, 2), (0, 0, 0), 1.0, 1.0)
+    vol.tsdf[:] = rng.uniform(-1, 1, vol.tsdf.shape).astype(np.float32)
+    vol.weight[:] = 1
+    vol.allocated[:] = True
+    v, c, t = otsdf.extract_mesh(vol)
+    cases = set()
+    ins = vol.tsdf < 0
+    R = 32
+    cs = np.zeros((R - 1,) * 3, np.int32)
+    for i in range(8):
+        o = (i & 1, (i >> 1) & 1, (i >> 2) & 1)
+        cs |= ins[o[0]:R - 1 + o[0], o[1]:R - 1 + o[1], o[2]:R - 1 + o[2]].astype(np.int32) << i
+    assert len(np.unique(cs)) >= 250                                  # (practically all of the 256 cases occur)
+    assert len(t) > 50000
+    e = np.concatenate([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]])
+    und = np.sort(e, axis=1)
+    uniq, inv, cnt = np.unique(und, axis=0, return_inverse=True, return_counts=True)
+    lo, hi = 0.5, R - 0.5                                             # voxel centres span [0.5, 31.5]
+    on_face = lambda p: (np.isclose(p, lo) | np.isclose(p, hi)).any(axis=1)
+    boundary_edge = on_face(v[uniq[:, 0]]) & on_face(v[uniq[:, 1]])
+    assert (cnt[~boundary_edge] == 2).all() and (cnt <= 2).all()
+    # orientation: an interior edge is traversed once in each direction
+    direction = np.where(e[:, 0] < e[:, 1], 1, -1)
+    balance = np.bincount(inv.reshape(-1), weights=direction, minlength=len(uniq))
+    assert (balance[~boundary_edge] == 0).all()

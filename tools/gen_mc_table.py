@@ -11,8 +11,9 @@ table is the classic 256 x 16 one, which cannot be reproduced from memory).  The
 * on every face the intersected edges are joined in pairs; a face with two diagonal inside corners (the ambiguous case) cuts
   the inside corners off separately -- a rule that depends only on the face's four signs, so neighbouring cubes agree and the
   surface is closed;
-* the face segments chain into closed loops; every loop is triangulated as a fan from its smallest edge id and oriented so
-  that the normal points from the inside (negative) to the outside (positive) corners.
+* the face segments chain into closed loops; every loop is triangulated -- as a fan from its smallest edge id unless that lays a
+  diagonal or a whole triangle into a cube face, in which case the triangulation with the fewest such diagonals is taken --
+  and oriented so that the normal points from the inside (negative) to the outside (positive) corners.
 
 The vertices of the mesh (zero crossings on intersected edges of valid cubes) do not depend on this table; only the choice
 of diagonals inside a cube does."""
@@ -58,6 +59,53 @@ def faces():
 FACES = faces()
 
 
+def edge_faces(e):
+    """the (axis, side) cube faces that contain edge e"""
+    c0, c1 = EDGE_CORNERS[e]
+    return {(a, int(CORNER[c0][a])) for a in range(3) if CORNER[c0][a] == CORNER[c1][a]}
+
+
+def _triangulations(idx):
+    """all triangulations of the polygon idx[0..n-1] (index tuples)"""
+    if len(idx) < 3:
+        return [[]]
+    if len(idx) == 3:
+        return [[tuple(idx)]]
+    out = []
+    for k in range(1, len(idx) - 1):      # the triangle on edge (idx[0], idx[-1]) has apex idx[k]
+        for left in _triangulations(idx[:k + 1]):
+            for right in _triangulations(idx[k:]):
+                out.append(left + [(idx[0], idx[k], idx[-1])] + right)
+    return out
+
+
+def best_triangulation(loop):
+    """Triangulate the loop (edge ids in cyclic order) without laying triangle edges -- let alone whole triangles -- into a
+    cube face where that can be avoided: a diagonal inside a face is matched by nothing in the neighbouring cube (or by the
+    neighbour's own such diagonal: an edge with four triangles).  First choice among equals: the fan from loop[0]."""
+    n = len(loop)
+    poly_edges = {frozenset((loop[i], loop[(i + 1) % n])) for i in range(n)}
+
+    def cost(tris):
+        c = 0
+        for t in tris:
+            if len(set.intersection(*(edge_faces(loop[i]) for i in t))) > 0:
+                c += 100                                           # a triangle lying in a cube face
+            for a, b in ((t[0], t[1]), (t[1], t[2]), (t[2], t[0])):
+                if frozenset((loop[a], loop[b])) not in poly_edges and edge_faces(loop[a]) & edge_faces(loop[b]):
+                    c += 1                                         # (counted from both sides) a diagonal inside a cube face
+        return c
+
+    fan = [(0, k, k + 1) for k in range(1, n - 1)]
+    best, best_cost = fan, cost(fan)
+    if best_cost:
+        for tris in _triangulations(list(range(n))):
+            cc = cost(tris)
+            if cc < best_cost:
+                best, best_cost = tris, cc
+    return [(loop[a], loop[b], loop[c]) for a, b, c in best]
+
+
 def case_triangles(case):
     inside = [(case >> i) & 1 for i in range(8)]
     adj = {}
@@ -92,7 +140,7 @@ def case_triangles(case):
             seen.add(step)
             prev, cur = cur, step
         pts = {e: (CORNER[EDGE_CORNERS[e][0]] + CORNER[EDGE_CORNERS[e][1]]) / 2.0 for e in loop}
-        fan = [(loop[0], loop[k], loop[k + 1]) for k in range(1, len(loop) - 1)]
+        fan = best_triangulation(loop)
         score = 0.0
         for a, b, c in fan:
             n = np.cross(pts[b] - pts[a], pts[c] - pts[a])
