@@ -489,6 +489,21 @@ def bench_mesh_export(g, cams, dev):
     return res
 
 
+def self_launch(n, argv):
+    """Re-execute this script as `n` ranks of one node: python -m torch.distributed.run --nnodes=1 --nproc-per-node n ...
+    (rank 0 prints the JSON line on the inherited stdout).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL across processes)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -507,11 +522,30 @@ def main():
     ap.add_argument("--dit-nfe", type=int, default=20)
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU through torch.distributed.run,
+        # the launch line the driver uses) instead of silently running one rank and reporting n_gpus = 1
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        a.gpus = world
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    launch_only = os.environ.get("GA_BENCH_LAUNCH_ONLY")   # CPU test of the launcher: rendezvous (gloo), report, leave
+    if launch_only:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        assert dist.get_world_size() == a.gpus
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_only": True, "n_gpus": dist.get_world_size(), "ranks_seen": int(t.item())}), flush=True)
+        dist.destroy_process_group()
+        return
+    if not torch.cuda.is_available() or local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs cuda:{local_rank}, this node shows {torch.cuda.device_count()} GPU(s); "
+                         "there is no CPU path")
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     dist = None
@@ -519,6 +553,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"bench.py: RCCL process group has {dist.get_world_size()} ranks, --gpus {a.gpus} was asked")
 
     from gaussiananything_amd import synthetic
     from gaussiananything_amd.diff_surfel_rasterization import SurfelForwardPlan
@@ -597,7 +633,8 @@ def main():
         value = n * v * a.steps * world / dt / 1e6
         out = {
             "metric": "Msplats/s rasterize (full forward: preprocess+binning+sort+blend)",
-            "value": round(value, 2), "unit": "Msplats/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": round(value, 2), "unit": "Msplats/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+            "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: {n} {a.scene}-scene surfel Gaussians x {v} posed {H}x{W} "

@@ -1,0 +1,481 @@
+// tools/gemm_lab.hip -- standalone test bed for the K loop / tile geometry of the DiT bf16 GEMM (gfx950).
+//
+//   C[m][n] = sum_k A[m][k] * W[n][k] + bias[n]   (A [M,K], W [N,K] bf16 K-contiguous, fp32 accumulate, bf16 store)
+//
+// One templated kernel, many instantiations, one process: every variant is checked against a naive fp32 kernel on the
+// full output and timed with HIP events on the launch stream, with the weight operand rotated through more copies than
+// the Infinity Cache holds ("cold": what a DiT evaluation sees -- 600 MB of weights per evaluation) and with one copy
+// ("warm").  Nothing here is product code; the winning structure moves into gaussiananything_amd/csrc/dit_gemm.hip.
+//
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/_build/gemm_lab tools/gemm_lab.hip
+// run (GPU box): tools/_build/gemm_lab [filter-substring]
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <type_traits>
+#include <vector>
+
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+struct P {
+    int M, N, K;
+    const uint16_t *A, *W;
+    const float *bias;
+    uint16_t *out;
+    long long lda, ldo;
+};
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
+
+__device__ __forceinline__ float gelu_erf(float v)
+{
+    const float x = fabsf(v) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);
+    const float erf_abs = 1.0f - poly * t * e;
+    return 0.5f * (v + fabsf(v) * erf_abs);
+}
+
+__device__ __forceinline__ void glds16(const uint16_t *gsrc, uint16_t *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+template <int MF> struct AccT;
+template <> struct AccT<16> { using T = f32x4; };
+template <> struct AccT<32> { using T = f32x16; };
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+#define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+// MF: MFMA edge (16: v_mfma_f32_16x16x32_bf16, 32: v_mfma_f32_32x32x16_bf16); WM x WN waves; FM x FN fragments per wave;
+// NST ring slots; PIPE 0: all fragment reads of a K-tile, then its MFMAs; 1: k-step software pipeline (fragments of the next
+// k-step requested before the MFMAs of the current one, tile hand-over inside the last k-step); EPI 0 bias, 1 bias + GELU
+template <int MF, int WM, int WN, int FM, int FN, int NST, int PIPE, int EPI, int R>
+__global__ __launch_bounds__(64 * WM * WN) void lab_kernel(P p)
+{
+    using acc_t = typename AccT<MF>::T;
+    constexpr int NW = WM * WN, BM = WM * FM * MF, BN = WN * FN * MF, BK = 64;
+    constexpr int KS = MF == 16 ? 2 : 4;   // k-steps per K-tile
+    constexpr int CPK = 8 / KS;            // 16-byte chunks per k-step
+    constexpr int ROWS = BN + BM;
+    static_assert(ROWS % (8 * NW) == 0, "DMA rows must divide among the waves");
+    constexpr int DPT = ROWS / 8 / NW;     // DMA instructions per wave per K-tile
+    constexpr int SLOT = ROWS * BK;        // elements per ring slot
+    static_assert((NST - 2) * DPT <= 63, "vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave / WM, wm = wave % WM;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int M = p.M, N = p.N, K = p.K;
+    const int nk = K / BK;
+
+    // DMA sources: instruction i of this wave fills rows q*8 .. q*8+7 of the slot image [W rows | A rows], q = i*NW + wave
+    const uint16_t *src[DPT];
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+        const int row = (i * NW + wave) * 8 + (lane >> 3);
+        if (row < BN) {
+            const int sw = MF == 16 ? (row & 7) : ((row >> 1) & 7);
+            src[i] = p.W + (size_t)min(n0 + row, N - 1) * K + ((lane & 7) ^ sw) * 8;
+        } else {
+            const int r = row - BN;
+            const int sw = MF == 16 ? (r & 7) : ((r >> 1) & 7);
+            src[i] = p.A + (size_t)min(m0 + r, M - 1) * p.lda + ((lane & 7) ^ sw) * 8;
+        }
+    }
+    acc_t acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+#pragma unroll
+            for (int r = 0; r < (MF == 16 ? 4 : 16); ++r) acc[i][j][r] = 0.f;
+
+    const int lrow = lane & (MF - 1), lg = lane / MF;
+    const int lsw = MF == 16 ? (lrow & 7) : ((lrow >> 1) & 7);
+    // element offset of this lane's 16-byte piece inside a row-major [rows][64] tile, k-step 0: row*64 + ((lg ^ lsw) * 8);
+    // k-step ks flips the chunk bits by ks*CPK
+    const int lane_off = lrow * BK + ((lg ^ lsw) * 8);
+
+    auto stage = [&](auto bufc, int kt) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value;
+        uint16_t *base = smem + BUF * SLOT;
+#pragma unroll
+        for (int i = 0; i < DPT; ++i) glds16(src[i] + (size_t)kt * BK, base + (i * NW + wave) * 8 * BK);
+    };
+    auto read_frags = [&](auto bufc, auto ksc, bf16x8(&fw)[FN], bf16x8(&fa)[FM]) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value, ks = decltype(ksc)::value;
+        const uint16_t *bw = smem + BUF * SLOT, *ba = bw + BN * BK;
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+            fw[i] = *reinterpret_cast<const bf16x8 *>(bw + (wn * FN + i) * MF * BK + (lane_off ^ (ks * CPK * 8)));
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+            fa[j] = *reinterpret_cast<const bf16x8 *>(ba + (wm * FM + j) * MF * BK + (lane_off ^ (ks * CPK * 8)));
+    };
+    auto mfmas = [&](const bf16x8(&fw)[FN], const bf16x8(&fa)[FM]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                if constexpr (MF == 16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+            }
+    };
+    // K loop.  nk = (main iterations) * NST + L, L = NST + R (R = nk % NST, template parameter): the last L tiles are peeled so
+    // that every slot index, wait count and "is there still a tile to request" is a compile-time constant and the steady-state
+    // loop body is ONE basic block (run-time branches make hipcc drain lgkmcnt at every block boundary).
+    constexpr int L = NST + R;
+    const int n_main = (nk - L) / NST;
+    // prologue: NST-1 tiles in flight (nk >= NST-1 required by the host)
+    static_for<0, NST - 1>([&](auto bc) __attribute__((always_inline)) { stage(bc, decltype(bc)::value); });
+
+    if constexpr (PIPE == 0) {
+        auto tile = [&](auto bc, int kt, auto stagec, auto flyc) __attribute__((always_inline)) {
+            constexpr int b = decltype(bc)::value;
+            WAIT_VM(decltype(flyc)::value * DPT);
+            __builtin_amdgcn_s_barrier();
+            if constexpr (decltype(stagec)::value) stage(std::integral_constant<int, (b + NST - 1) % NST>{}, kt + NST - 1);
+            bf16x8 fw[KS][FN], fa[KS][FM];
+            static_for<0, KS>([&](auto ksc) __attribute__((always_inline)) {
+                read_frags(bc, ksc, fw[decltype(ksc)::value], fa[decltype(ksc)::value]);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) mfmas(fw[ks], fa[ks]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        int kt = 0;
+        for (int it = 0; it < n_main; ++it) {
+            static_for<0, NST>([&](auto bc) __attribute__((always_inline)) {
+                tile(bc, kt + decltype(bc)::value, std::true_type{}, std::integral_constant<int, NST - 2>{});
+            });
+            kt += NST;
+        }
+        static_for<0, L>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr bool st = i <= R;                       // tile kt+i+NST-1 exists
+            constexpr int fly = st ? NST - 2 : L - 1 - i;     // issued tiles younger than this one
+            tile(std::integral_constant<int, i % NST>{}, kt + i, std::integral_constant<bool, st>{}, std::integral_constant<int, fly>{});
+        });
+    } else {
+        static_assert(NST >= 3, "the k-step pipeline hands over to a tile requested one tile earlier");
+        bf16x8 fw[2][FN], fa[2][FM];
+        // PIPE 2: the fragment reads are inline asm and the waits are counted by hand (hipcc on gfx950 only ever emits
+        // lgkmcnt(0), which would wait for the reads just issued for the NEXT k-step as well)
+        const uint32_t lds0 = (uint32_t)(size_t)(const __attribute__((address_space(3))) uint16_t *)smem;
+        uint32_t aw[KS][2], aa[KS][2];   // byte addresses: [k-step][slot pair]
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                aw[ks][h] = lds0 + 2 * (h * 2 * SLOT + wn * FN * MF * BK + (lane_off ^ (ks * CPK * 8)));
+                aa[ks][h] = lds0 + 2 * (h * 2 * SLOT + BN * BK + wm * FM * MF * BK + (lane_off ^ (ks * CPK * 8)));
+            }
+        auto read2 = [&](auto bufc, auto ksc, bf16x8(&w)[FN], bf16x8(&a)[FM]) __attribute__((always_inline)) {
+            constexpr int BUF = decltype(bufc)::value, ks = decltype(ksc)::value;
+            if constexpr (PIPE == 1) read_frags(bufc, ksc, w, a);
+            else {
+                static_assert(2 * ((BUF & 1) * SLOT + ((FN > FM ? FN : FM) - 1) * MF * BK) < 65536, "ds_read offset field");
+                const uint32_t adw = aw[ks][BUF >> 1], ada = aa[ks][BUF >> 1];
+#pragma unroll
+                for (int i = 0; i < FN; ++i)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w[i]) : "v"(adw), "n"(2 * ((BUF & 1) * SLOT + i * MF * BK)));
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[j]) : "v"(ada), "n"(2 * ((BUF & 1) * SLOT + j * MF * BK)));
+            }
+        };
+        // all LDS reads except the NEWEST `newer` have returned; the fragments pass through the asm so that their users cannot
+        // be scheduled above the wait
+        auto wait2 = [&](auto newerc, bf16x8(&w)[FN], bf16x8(&a)[FM]) __attribute__((always_inline)) {
+            if constexpr (PIPE == 2) {
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w[0]) : "n"(decltype(newerc)::value));
+#pragma unroll
+                for (int i = 1; i < FN; ++i) asm volatile("" : "+v"(w[i]));
+#pragma unroll
+                for (int j = 0; j < FM; ++j) asm volatile("" : "+v"(a[j]));
+            }
+        };
+        WAIT_VM((NST - 2) * DPT);
+        __builtin_amdgcn_s_barrier();
+        read2(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, fw[0], fa[0]);
+        // HO: 0 last tile (nothing follows), 1 hand over to the next tile without a request, 2 hand over and request tile kt+NST-1
+        auto tile = [&](auto bc, int kt, auto hoc, auto flyc) __attribute__((always_inline)) {
+            constexpr int b = decltype(bc)::value, HO = decltype(hoc)::value;
+            static_for<0, KS>([&](auto ksc) __attribute__((always_inline)) {
+                constexpr int ks = decltype(ksc)::value;
+                constexpr bool more = ks + 1 < KS || HO > 0;
+                if constexpr (ks + 1 < KS) {
+                    read2(bc, std::integral_constant<int, ks + 1>{}, fw[(ks + 1) & 1], fa[(ks + 1) & 1]);
+                } else if constexpr (HO > 0) {
+                    // tile kt+1 must have landed for every wave; everyone has left tile kt-1, whose slot takes tile kt+NST-1
+                    WAIT_VM(decltype(flyc)::value * DPT);
+                    __builtin_amdgcn_s_barrier();
+                    if constexpr (HO == 2) stage(std::integral_constant<int, (b + NST - 1) % NST>{}, kt + NST - 1);
+                    read2(std::integral_constant<int, (b + 1) % NST>{}, std::integral_constant<int, 0>{}, fw[0], fa[0]);
+                }
+                wait2(std::integral_constant<int, more ? FN + FM : 0>{}, fw[ks & 1], fa[ks & 1]);
+                mfmas(fw[ks & 1], fa[ks & 1]);
+                if constexpr (PIPE == 1) {
+                    // pin the issue order: the next k-step's fragment reads go out BEFORE this k-step's MFMAs
+                    if constexpr (more) __builtin_amdgcn_sched_group_barrier(0x100, FN + FM, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, FN * FM, 0);
+                }
+            });
+        };
+        int kt = 0;
+        for (int it = 0; it < n_main; ++it) {
+            static_for<0, NST>([&](auto bc) __attribute__((always_inline)) {
+                tile(bc, kt + decltype(bc)::value, std::integral_constant<int, 2>{}, std::integral_constant<int, NST - 3>{});
+            });
+            kt += NST;
+        }
+        static_for<0, L>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int HO = i == L - 1 ? 0 : (i <= R ? 2 : 1);
+            constexpr int fly = HO == 2 ? NST - 3 : (L - i - 2 > 0 ? L - i - 2 : 0);   // issued tiles younger than kt+1
+            tile(std::integral_constant<int, i % NST>{}, kt + i, std::integral_constant<int, HO>{}, std::integral_constant<int, fly>{});
+        });
+    }
+
+    // epilogue: bias (+ GELU), 16-byte bf16 stores after a lane-pair exchange
+    const int nbase = n0 + wn * FN * MF, mbase = m0 + wm * FM * MF;
+    if constexpr (MF == 16) {
+        const int g = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int m = mbase + j * 16 + (lane & 15);
+#pragma unroll
+            for (int q = 0; q < FN / 2; ++q) {
+                float w[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * q][j][r]), __float_as_uint(acc[2 * q + 1][j][r]), false, false);
+                    w[r] = __uint_as_float(sw[0]);
+                    w[4 + r] = __uint_as_float(sw[1]);
+                }
+                const int n = nbase + q * 32 + (g & 1) * 16 + (g >> 1) * 8;
+                if (m >= M || n >= N) continue;
+                const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + n), b1 = *reinterpret_cast<const float4 *>(p.bias + n + 4);
+                w[0] += b0.x; w[1] += b0.y; w[2] += b0.z; w[3] += b0.w; w[4] += b1.x; w[5] += b1.y; w[6] += b1.z; w[7] += b1.w;
+                if (EPI == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w[e] = gelu_erf(w[e]);
+                }
+                *reinterpret_cast<uint4 *>(p.out + (size_t)m * p.ldo + n) =
+                    make_uint4(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]), pack_bf16x2(w[4], w[5]), pack_bf16x2(w[6], w[7]));
+            }
+        }
+    } else {
+        const int h = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int m = mbase + j * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int pq = 0; pq < 2; ++pq) {   // quads (2pq, 2pq+1) -> 8 consecutive columns from i*32 + (2pq+h)*8
+                    float w[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][(2 * pq) * 4 + r]),
+                                                                         __float_as_uint(acc[i][j][(2 * pq + 1) * 4 + r]), false, false);
+                        w[r] = __uint_as_float(sw[0]);
+                        w[4 + r] = __uint_as_float(sw[1]);
+                    }
+                    const int n = nbase + i * 32 + (2 * pq + h) * 8;
+                    if (m >= M || n >= N) continue;
+                    const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + n), b1 = *reinterpret_cast<const float4 *>(p.bias + n + 4);
+                    w[0] += b0.x; w[1] += b0.y; w[2] += b0.z; w[3] += b0.w; w[4] += b1.x; w[5] += b1.y; w[6] += b1.z; w[7] += b1.w;
+                    if (EPI == 1) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) w[e] = gelu_erf(w[e]);
+                    }
+                    *reinterpret_cast<uint4 *>(p.out + (size_t)m * p.ldo + n) =
+                        make_uint4(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]), pack_bf16x2(w[4], w[5]), pack_bf16x2(w[6], w[7]));
+                }
+        }
+    }
+}
+
+// ---- reference + harness -------------------------------------------------------------------------------------------
+__global__ void ref_kernel(P p, float *ref, int epi)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (n >= p.N) return;
+    float s = 0.f;
+    for (int k = 0; k < p.K; ++k)
+        s += __uint_as_float((uint32_t)p.A[(size_t)m * p.lda + k] << 16) * __uint_as_float((uint32_t)p.W[(size_t)n * p.K + k] << 16);
+    s += p.bias[n];
+    if (epi == 1) s = 0.5f * s * (1.0f + erff(s * 0.70710678118654752f));
+    ref[(size_t)m * p.N + n] = s;
+}
+
+__global__ void cmp_kernel(const uint16_t *out, const float *ref, size_t n, unsigned *bad, float *maxerr)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float o = __uint_as_float((uint32_t)out[i] << 16), r = ref[i];
+    const float err = fabsf(o - r), tol = 0.02f + 0.012f * fabsf(r);
+    if (!(err <= tol)) atomicAdd(bad, 1u);
+    atomicMax(reinterpret_cast<unsigned *>(maxerr), __float_as_uint(err));
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
+
+struct Shape { int M, N, K; const char *name; };
+struct Bufs {
+    uint16_t *A, *W, *out; float *bias, *ref; unsigned *bad; float *maxerr;
+    int wcopies; size_t wstride;
+};
+static const char *g_filter = nullptr;
+static int g_iters = 200;
+
+template <int MF, int WM, int WN, int FM, int FN, int NST, int PIPE, int EPI, int R>
+static void run_variant_r(const char *name, const Shape &s, Bufs &b)
+{
+    if (g_filter && !strstr(name, g_filter)) return;
+    constexpr int BM = WM * FM * MF, BN = WN * FN * MF;
+    constexpr size_t lds = (size_t)NST * (BM + BN) * 64 * 2;
+    auto kern = lab_kernel<MF, WM, WN, FM, FN, NST, PIPE, EPI, R>;
+    CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    P p{s.M, s.N, s.K, b.A, b.W, b.bias, b.out, s.K, s.N};
+    const dim3 grid((s.N + BN - 1) / BN, (s.M + BM - 1) / BM), block(64 * WM * WN);
+    // correctness on the full output
+    CK(hipMemset(b.out, 0xff, (size_t)s.M * s.N * 2));
+    CK(hipMemset(b.bad, 0, 4)); CK(hipMemset(b.maxerr, 0, 4));
+    hipLaunchKernelGGL(kern, grid, block, lds, 0, p);
+    CK(hipGetLastError());
+    ref_kernel<<<dim3((s.N + 255) / 256, s.M), 256>>>(p, b.ref, EPI);
+    const size_t n = (size_t)s.M * s.N;
+    cmp_kernel<<<(unsigned)((n + 255) / 256), 256>>>(b.out, b.ref, n, b.bad, b.maxerr);
+    CK(hipDeviceSynchronize());
+    unsigned bad; float maxerr;
+    CK(hipMemcpy(&bad, b.bad, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&maxerr, b.maxerr, 4, hipMemcpyDeviceToHost));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float us[2];
+    for (int mode = 0; mode < 2; ++mode) {   // 0 cold weights (rotating copies), 1 warm
+        const int copies = mode == 0 ? b.wcopies : 1;
+        for (int it = 0; it < 10; ++it) { P q = p; q.W = b.W + (size_t)(it % copies) * b.wstride; hipLaunchKernelGGL(kern, grid, block, lds, 0, q); }
+        CK(hipEventRecord(e0));
+        for (int it = 0; it < g_iters; ++it) { P q = p; q.W = b.W + (size_t)(it % copies) * b.wstride; hipLaunchKernelGGL(kern, grid, block, lds, 0, q); }
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        us[mode] = ms * 1e3f / g_iters;
+    }
+    const double fl = 2.0 * s.M * s.N * s.K;
+    printf("%-34s %-18s grid %4d lds %6zu  cold %7.2f us %7.1f TF | warm %7.2f us %7.1f TF | %s maxerr %.3g\n", name, s.name,
+           grid.x * grid.y, lds, us[0], fl / us[0] / 1e6, us[1], fl / us[1] / 1e6, bad ? "WRONG" : "ok", maxerr);
+    fflush(stdout);
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+}
+
+template <int MF, int WM, int WN, int FM, int FN, int NST, int PIPE, int EPI>
+static void run_variant(const char *name, const Shape &s, Bufs &b)
+{
+    const int nk = s.K / 64, r = nk % NST;
+    if (nk < 2 * NST) { return; }
+    if (r == 0) run_variant_r<MF, WM, WN, FM, FN, NST, PIPE, EPI, 0>(name, s, b);
+    else if (r == 1) { if constexpr (NST > 1) run_variant_r<MF, WM, WN, FM, FN, NST, PIPE, EPI, 1 % NST>(name, s, b); }
+    else if (r == 2) { if constexpr (NST > 2) run_variant_r<MF, WM, WN, FM, FN, NST, PIPE, EPI, 2 % NST>(name, s, b); }
+    else printf("%s: nk %% NST = %d not instantiated\n", name, r);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1) g_filter = argv[1];
+    if (argc > 2) g_iters = atoi(argv[2]);
+    const Shape shapes[] = {{1536, 4096, 1024, "fc1 1536x4096x1024"}, {1536, 3072, 1024, "qkv 1536x3072x1024"},
+                            {1536, 1024, 4096, "fc2 1536x1024x4096"}, {1536, 1024, 1024, "proj 1536x1024x1024"},
+                            {768, 1024, 1024, "caq 768x1024x1024"},   {6144, 4096, 1024, "fc1x4 6144x4096x1024"}};
+    const size_t maxA = (size_t)6144 * 4096, maxW = (size_t)4096 * 4096, maxO = (size_t)6144 * 4096;
+    Bufs b;
+    b.wcopies = 40;   // 40 x 8 MiB > the 256 MiB Infinity Cache
+    b.wstride = (size_t)4096 * 1024;
+    CK(hipMalloc(&b.A, maxA * 2)); CK(hipMalloc(&b.W, b.wstride * b.wcopies * 2)); CK(hipMalloc(&b.out, maxO * 2));
+    CK(hipMalloc(&b.bias, 4096 * 4)); CK(hipMalloc(&b.ref, maxO * 4)); CK(hipMalloc(&b.bad, 4)); CK(hipMalloc(&b.maxerr, 4));
+    {
+        std::vector<uint16_t> h(maxA);
+        uint32_t st = 12345u;
+        auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
+        for (auto &v : h) v = f2bf(rnd());
+        CK(hipMemcpy(b.A, h.data(), maxA * 2, hipMemcpyHostToDevice));
+        std::vector<uint16_t> w(b.wstride);
+        for (auto &v : w) v = f2bf(rnd() * 0.05f);
+        for (int c = 0; c < b.wcopies; ++c) CK(hipMemcpy(b.W + c * b.wstride, w.data(), b.wstride * 2, hipMemcpyHostToDevice));
+        std::vector<float> bi(4096);
+        for (auto &v : bi) v = rnd();
+        CK(hipMemcpy(b.bias, bi.data(), 4096 * 4, hipMemcpyHostToDevice));
+    }
+    (void)maxW;
+    for (const Shape &s : shapes) {
+        if (getenv("LAB_SHAPE") && !strstr(s.name, getenv("LAB_SHAPE"))) continue;
+        const int E = 0;
+        //            MF WM WN FM FN NST PIPE EPI
+        run_variant<16, 2, 2, 4, 4, 4, 0, E>("m16 128x128 4w nst4 batch", s, b);
+        run_variant<16, 2, 2, 4, 4, 2, 0, E>("m16 128x128 4w nst2 batch", s, b);
+        run_variant<16, 2, 2, 3, 4, 2, 0, E>("m16  96x128 4w nst2 batch", s, b);
+        run_variant<16, 2, 2, 6, 4, 4, 0, E>("m16 192x128 4w nst4 batch", s, b);
+        run_variant<16, 2, 2, 6, 4, 3, 0, E>("m16 192x128 4w nst3 batch", s, b);
+        run_variant<16, 2, 2, 6, 4, 4, 1, E>("m16 192x128 4w nst4 pipe", s, b);
+        run_variant<16, 2, 2, 6, 4, 3, 1, E>("m16 192x128 4w nst3 pipe", s, b);
+        run_variant<16, 2, 2, 4, 4, 4, 1, E>("m16 128x128 4w nst4 pipe", s, b);
+        run_variant<32, 2, 2, 3, 2, 4, 0, E>("m32 192x128 4w nst4 batch", s, b);
+        run_variant<32, 2, 2, 3, 2, 4, 1, E>("m32 192x128 4w nst4 pipe", s, b);
+        run_variant<32, 2, 2, 3, 2, 4, 2, E>("m32 192x128 4w nst4 asm", s, b);
+        run_variant<16, 2, 2, 6, 4, 4, 2, E>("m16 192x128 4w nst4 asm", s, b);
+        run_variant<32, 2, 2, 2, 2, 4, 2, E>("m32 128x128 4w nst4 asm", s, b);
+        run_variant<32, 4, 2, 2, 2, 3, 2, E>("m32 256x128 8w nst3 asm", s, b);
+        run_variant<32, 2, 4, 3, 1, 4, 2, E>("m32 192x128 8w(96x32) nst4 asm", s, b);
+        run_variant<16, 4, 2, 3, 4, 4, 2, E>("m16 192x128 8w(48x64) nst4 asm", s, b);
+        run_variant<32, 2, 2, 4, 2, 3, 2, E>("m32 256x128 4w nst3 asm", s, b);
+        run_variant<32, 2, 2, 3, 2, 3, 1, E>("m32 192x128 4w nst3 pipe", s, b);
+        run_variant<32, 2, 2, 2, 2, 4, 1, E>("m32 128x128 4w nst4 pipe", s, b);
+        run_variant<32, 2, 2, 2, 2, 2, 0, E>("m32 128x128 4w nst2 batch", s, b);
+        run_variant<32, 2, 2, 4, 2, 3, 1, E>("m32 256x128 4w nst3 pipe", s, b);
+        run_variant<32, 2, 2, 3, 3, 3, 1, E>("m32 192x192 4w nst3 pipe", s, b);
+        run_variant<32, 2, 2, 4, 4, 2, 0, E>("m32 256x256 4w nst2 batch", s, b);
+        run_variant<32, 4, 2, 2, 2, 3, 1, E>("m32 256x128 8w nst3 pipe", s, b);
+        run_variant<32, 4, 2, 2, 2, 3, 0, E>("m32 256x128 8w nst3 batch", s, b);
+        run_variant<32, 2, 4, 3, 1, 4, 1, E>("m32 192x128 8w(96x32) nst4 pipe", s, b);
+        run_variant<32, 2, 4, 4, 2, 2, 0, E>("m32 256x256 8w nst2 batch", s, b);
+        run_variant<16, 4, 2, 3, 4, 4, 1, E>("m16 192x128 8w(48x64) nst4 pipe", s, b);
+        run_variant<16, 4, 2, 3, 4, 4, 0, E>("m16 192x128 8w(48x64) nst4 batch", s, b);
+        run_variant<32, 2, 2, 3, 2, 4, 1, 1>("m32 192x128 4w nst4 pipe GELU", s, b);
+        run_variant<16, 2, 2, 3, 4, 2, 0, 1>("m16  96x128 4w nst2 batch GELU", s, b);
+    }
+    return 0;
+}
