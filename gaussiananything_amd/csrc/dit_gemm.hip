@@ -21,6 +21,8 @@
 // ds_read_b128 lane groups).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "dit_common.h"
 
 namespace gadit {
@@ -89,24 +91,25 @@ __device__ __forceinline__ void pair_exchange(const f32x4 &a, const f32x4 &b, fl
 }
 
 // residual-stream operands of the gated-accumulate epilogue in the exchanged layout, fetched before the K loop
+// (mrow0 / ncol0: first row / column of the WAVE's part of the tile)
 template <int MT>
 struct ResidualPrefetch {
     f32x4 x[MT][2][2], gate[MT][2][2];
 };
 
-template <int MT>
-__device__ __forceinline__ void residual_prefetch(const GemmP &p, ResidualPrefetch<MT> &pf, int m0, int n0, int wn, int wm, int lane)
+template <int MT, int NQ = 2>
+__device__ __forceinline__ void residual_prefetch(const GemmP &p, ResidualPrefetch<MT> &pf, int mrow0, int ncol0, int lane)
 {
     const int g = lane >> 4;
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-        const int m = min(m0 + wm * (MT * 16) + j * 16 + (lane & 15), p.M - 1);
+        const int m = min(mrow0 + j * 16 + (lane & 15), p.M - 1);
         const float *gate_row = p.gate ? p.gate + (size_t)(m / p.rows_per_batch) * p.gate_stride : nullptr;
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                const int n = min(n0 + wn * 64 + q * 32 + (g & 1) * 16 + (g >> 1) * 8 + hh * 4, p.N - 4);
+                const int n = min(ncol0 + q * 32 + (g & 1) * 16 + (g >> 1) * 8 + hh * 4, p.N - 4);
                 const float4 xv = *reinterpret_cast<const float4 *>(static_cast<const float *>(p.out) + (size_t)m * p.ldo + n);
                 pf.x[j][q][hh] = f32x4{xv.x, xv.y, xv.z, xv.w};
                 float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -123,11 +126,11 @@ struct RowSsPrefetch {
 };
 
 template <int MT>
-__device__ __forceinline__ void rowss_prefetch(const GemmP &p, RowSsPrefetch<MT> &pf, int m0, int wm, int lane)
+__device__ __forceinline__ void rowss_prefetch(const GemmP &p, RowSsPrefetch<MT> &pf, int mrow0, int lane)
 {
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-        const int m = min(m0 + wm * (MT * 16) + j * 16 + (lane & 15), p.M - 1);
+        const int m = min(mrow0 + j * 16 + (lane & 15), p.M - 1);
         const float *rp = p.row_ss + (size_t)m * p.row_ss_tiles;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -140,30 +143,37 @@ __device__ __forceinline__ void rowss_prefetch(const GemmP &p, RowSsPrefetch<MT>
     }
 }
 
-template <int EPI, int MT, bool PRE, bool RSSPRE>
-__device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[4][MT], const ResidualPrefetch<MT> *pre,
-                                              const RowSsPrefetch<MT> *rss, int m0, int n0, int wn, int wm, int lane)
+// FN = 16-column fragments per wave: 4 (the wave's 64 columns are one attention head / one emit_ss group) or 2 (32 columns: no
+// per-head RMSNorm, no V^T store; the row sums of squares of a 64-column group are returned in `emit_part` for the caller to
+// combine across the two waves of the group)
+template <int EPI, int MT, int FN, bool PRE, bool RSSPRE>
+__device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[FN][MT], const ResidualPrefetch<MT> *pre,
+                                              const RowSsPrefetch<MT> *rss, int mrow0, int ncol0, int lane, float *emit_part = nullptr,
+                                              const f32x4 *bias_pre = nullptr, const f32x4 *qkw_pre = nullptr)
 {
+    static_assert(FN == 4 || FN == 2, "a wave owns 64 or 32 columns");
     const int M = p.M, N = p.N;
-    // epilogue: lane holds acc[i][j][r] = C[m = m0 + wm*MT*16 + j*16 + (lane&15)][n = n0 + wn*64 + i*16 + (lane>>4)*4 + r];
-    // the 64 columns of a wave are one attention head: its 64 values of row m sit in 4 fragments x 4 lane-groups x 4
+    // epilogue: lane holds acc[i][j][r] = C[m = mrow0 + j*16 + (lane&15)][n = ncol0 + i*16 + (lane>>4)*4 + r];
+    // with FN = 4 the 64 columns of a wave are one attention head: its 64 values of row m sit in 4 fragments x 4 lane-groups x 4
     // registers, so the per-head RMSNorm is an in-lane sum plus two xor-shuffles
-    const int nhead = n0 + wn * 64, g = lane >> 4;
+    const int nhead = ncol0, g = lane >> 4;
     const float *qkw = nullptr;
-    if (EPI == GA_GEMM_EPI_STORE_BF16) {
+    if (EPI == GA_GEMM_EPI_STORE_BF16 && FN == 4) {
         if (nhead < p.qk_cols0) qkw = p.qk_w0;
         else if (nhead < p.qk_cols1) qkw = p.qk_w1;
     }
-    const bool to_vt = EPI == GA_GEMM_EPI_STORE_BF16 && p.vt && nhead >= p.vt_col0;  // wave-uniform (vt_col0 % 64 == 0)
+    const bool to_vt = EPI == GA_GEMM_EPI_STORE_BF16 && FN == 4 && p.vt && nhead >= p.vt_col0;  // wave-uniform (vt_col0 % 64 == 0)
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-        const int m = m0 + wm * (MT * 16) + j * 16 + (lane & 15);
-        f32x4 v[4];
+        const int m = mrow0 + j * 16 + (lane & 15);
+        f32x4 v[FN];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < FN; ++i) {
             const int n = nhead + i * 16 + g * 4;
             v[i] = acc[i][j];
-            if (p.bias && n < N) {
+            if (bias_pre) {                       // requested before the K loop (zero without a bias)
+                v[i][0] += bias_pre[i][0]; v[i][1] += bias_pre[i][1]; v[i][2] += bias_pre[i][2]; v[i][3] += bias_pre[i][3];
+            } else if (p.bias && n < N) {
                 const float4 b = *reinterpret_cast<const float4 *>(p.bias + n);
                 v[i][0] += b.x; v[i][1] += b.y; v[i][2] += b.z; v[i][3] += b.w;
             }
@@ -182,24 +192,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[4][MT
             }
             const float rs = rsqrtf(tot * p.row_ss_inv_dim + p.row_ss_eps);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { v[i][0] *= rs; v[i][1] *= rs; v[i][2] *= rs; v[i][3] *= rs; }
+            for (int i = 0; i < FN; ++i) { v[i][0] *= rs; v[i][1] *= rs; v[i][2] *= rs; v[i][3] *= rs; }
         }
-        if (EPI == GA_GEMM_EPI_STORE_BF16 && qkw) {  // wave-uniform
+        if (EPI == GA_GEMM_EPI_STORE_BF16 && FN == 4 && qkw) {  // wave-uniform
             float ss = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+            for (int i = 0; i < FN; ++i) ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
             ss += __shfl_xor(ss, 16, 64);
             ss += __shfl_xor(ss, 32, 64);
             const float rs = rsqrtf(ss * (1.0f / 64.0f) + 1e-5f);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 w = *reinterpret_cast<const float4 *>(qkw + i * 16 + g * 4);
+            for (int i = 0; i < FN; ++i) {
+                float4 w;
+                if (qkw_pre) w = make_float4(qkw_pre[i][0], qkw_pre[i][1], qkw_pre[i][2], qkw_pre[i][3]);
+                else w = *reinterpret_cast<const float4 *>(qkw + i * 16 + g * 4);
                 v[i][0] *= rs * w.x; v[i][1] *= rs * w.y; v[i][2] *= rs * w.z; v[i][3] *= rs * w.w;
             }
         }
         if (EPI == GA_GEMM_EPI_GELU_BF16) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < FN; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[i][r] = gelu_erf(v[i][r]);
         }
@@ -210,7 +222,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[4][MT
             if (m >= M) continue;
             const int b = m / p.rows_per_batch, tok = m - b * p.rows_per_batch;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < FN; ++i) {
                 const int n = nhead + i * 16 + g * 4;
                 if (n >= N) continue;
                 uint16_t *dst = p.vt + ((size_t)b * p.heads * 64 + (n - p.vt_col0)) * p.vt_ld + tok;
@@ -219,9 +231,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[4][MT
             }
             continue;
         }
-        float emit_acc = 0.f;  // this lane's share of sum x_new^2 over the wave's 64 columns of row m
+        float emit_acc = 0.f;  // this lane's share of sum x_new^2 over the wave's columns of row m
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < FN / 2; ++q) {
             float w[8];
             pair_exchange(v[2 * q], v[2 * q + 1], w);   // every lane takes part, also rows m >= M
             const int n = nhead + q * 32 + (g & 1) * 16 + (g >> 1) * 8;
@@ -276,7 +288,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[4][MT
         if (EPI == GA_GEMM_EPI_RESIDUAL && p.emit_ss) {  // kernel-uniform: the four lanes of a row add up in a fixed order
             emit_acc += __shfl_xor(emit_acc, 16, 64);
             emit_acc += __shfl_xor(emit_acc, 32, 64);
-            if (g == 0 && m < M && nhead < N) p.emit_ss[(size_t)m * (N >> 6) + (nhead >> 6)] = emit_acc;
+            if (FN == 4) {
+                if (g == 0 && m < M && nhead < N) p.emit_ss[(size_t)m * (N >> 6) + (nhead >> 6)] = emit_acc;
+            } else if (g == 0) emit_part[j * 16 + (lane & 15)] = emit_acc;   // half a group: the caller adds the two waves up
         }
     }
 }
@@ -319,10 +333,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
     // extra VGPRs are free
     constexpr bool PRE = EPI == GA_GEMM_EPI_RESIDUAL && NST >= 4;
     ResidualPrefetch<PRE ? MT : 1> pre;
-    if (PRE) residual_prefetch<MT>(p, reinterpret_cast<ResidualPrefetch<MT> &>(pre), m0, n0, wn, wm, lane);
+    const int mrow0 = m0 + wm * (MT * 16), ncol0 = n0 + wn * 64;
+    if (PRE) residual_prefetch<MT>(p, reinterpret_cast<ResidualPrefetch<MT> &>(pre), mrow0, ncol0, lane);
     constexpr bool RSS = EPI == GA_GEMM_EPI_STORE_BF16 && NST >= 4;   // not in the 2-workgroups-per-CU configuration (VGPR budget 256)
     RowSsPrefetch<RSS ? MT : 1> rss;
-    if (RSS && p.row_ss) rowss_prefetch<MT>(p, reinterpret_cast<RowSsPrefetch<MT> &>(rss), m0, wm, lane);
+    if (RSS && p.row_ss) rowss_prefetch<MT>(p, reinterpret_cast<RowSsPrefetch<MT> &>(rss), mrow0, lane);
 
     const int frow = lane & 15, g = lane >> 4;
     const int nk = K / BK;
@@ -386,8 +401,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
 
     GA_STAGE(0, 0);
     if (GA_GEMM_ABLATE == 32) {  // launch + prologue + epilogue only
-        gemm_epilogue<EPI, MT, PRE, RSS>(p, acc, reinterpret_cast<const ResidualPrefetch<MT> *>(&pre),
-                                reinterpret_cast<const RowSsPrefetch<MT> *>(&rss), m0, n0, wn, wm, lane);
+        gemm_epilogue<EPI, MT, 4, PRE, RSS>(p, acc, reinterpret_cast<const ResidualPrefetch<MT> *>(&pre),
+                                reinterpret_cast<const RowSsPrefetch<MT> *>(&rss), mrow0, ncol0, lane);
         return;
     }
     if (NST > 2 && nk > 1) GA_STAGE(1 % NST, 1);
@@ -409,8 +424,245 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
         if (t == 12345.f) static_cast<float *>(p.out)[tid] = t;
         return;
     }
-    gemm_epilogue<EPI, MT, PRE, RSS>(p, acc, reinterpret_cast<const ResidualPrefetch<MT> *>(&pre),
-                                reinterpret_cast<const RowSsPrefetch<MT> *>(&rss), m0, n0, wn, wm, lane);
+    gemm_epilogue<EPI, MT, 4, PRE, RSS>(p, acc, reinterpret_cast<const ResidualPrefetch<MT> *>(&pre),
+                                reinterpret_cast<const RowSsPrefetch<MT> *>(&rss), mrow0, ncol0, lane);
+}
+
+// ---- round 3: the ring kernel -------------------------------------------------------------------------------------------
+// What the test bed (tools/gemm_lab.hip: every variant checked on the full output, timed with cold weights) showed at the
+// DiT shapes, M = 1536 rows:
+//   * all tilings of the wide GEMMs (fc1, qkv) sit between 17 and 25 us: the aggregate L2 -> CU operand stream saturates at
+//     about 16 TB/s (21-26 B/clk/CU with every CU loading), so time ~ total operand bytes through the L1s, i.e. the tile with
+//     the fewest bytes per flop that still puts one workgroup on every CU wins: 192 x 128 (256 / 192 workgroups);
+//   * one wave per SIMD leaves the matrix pipe idle whenever that wave waits (barrier, DMA issue, fragment latency): EIGHT waves
+//     (4 x 2, wave tile 48 x 64) on the 192 x 128 tile beat four waves of 96 x 64 by 10 % although they read more LDS bytes;
+//   * hipcc on gfx950 only ever emits `s_waitcnt lgkmcnt(0)`, so a software pipeline written in HIP waits for the fragment reads
+//     it has just issued for the NEXT k-step: the reads are inline asm here and the waits are counted by hand (lgkmcnt(7));
+//   * the K loop has no run-time branch: the ring slot, the wait count and "is there a tile left to request" are compile-time
+//     constants of a peeled tail, so the steady state is one basic block (every block boundary costs an lgkmcnt(0) drain);
+//   * the N = 1024 GEMMs (proj, fc2, cross-attention q / out) were latency-bound with a 2-slot ring: 96 x 64 and 64 x 64 tiles
+//     with FOUR slots run proj in 6.7 us (was 11.6), fc2 in 24 us (was 33), the M = 768 projections in 5.3 us (was 9).
+//   * measured without gain: 32x32x16 MFMAs, 256 x 128 / 256 x 256 / 192 x 192 tiles, 8-slot rings, padded row pitches
+//     (no channel camping), weights stored as contiguous 1 KiB DMA blocks (3-6 % on cold weights only), output staged through
+//     LDS into whole 256-byte rows (the store tail of a GEMM is the L2 write-back at the kernel boundary, not coalescing).
+// WM x WN waves, each FM x FN fragments of 16 x 16; ring of NST slots of (BN + BM) x 64 bf16; PIPE 0: all fragment reads of a
+// K-tile in one batch, then its MFMAs; PIPE 2: k-step software pipeline with asm reads.  Requires K % (64 NST) == 0, K >= 128 NST.
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+#define GA_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+template <int EPI, int WM, int WN, int FM, int FN, int NST, int PIPE>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
+{
+    constexpr int NW = WM * WN, BM = WM * FM * 16, BNT = WN * FN * 16;
+    constexpr int KS = 2, CPK = 4;            // k-steps of 32 per K-tile, 16-byte chunks per k-step
+    constexpr int ROWS = BNT + BM;
+    static_assert(ROWS % (8 * NW) == 0, "DMA rows must divide among the waves");
+    constexpr int DPT = ROWS / 8 / NW;        // DMA instructions per wave per K-tile
+    constexpr int SLOT = ROWS * BK;           // elements per ring slot
+    static_assert((NST - 2) * DPT <= 63, "vmcnt range");
+    static_assert(NST >= 3 || PIPE == 0, "the k-step pipeline hands over to a tile requested one tile earlier");
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave / WM, wm = wave % WM;
+    const int n0 = blockIdx.x * BNT, m0 = blockIdx.y * BM;
+    const int M = p.M, N = p.N, K = p.K;
+    const int nk = K / BK;
+
+    // DMA sources: instruction i of this wave fills rows q*8 .. q*8+7 of the slot image [W rows | A rows], q = i*NW + wave;
+    // slot (row, s) of the 128-byte row receives global chunk s ^ (row & 7)
+    const uint16_t *src[DPT];
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+        const int row = (i * NW + wave) * 8 + (lane >> 3);
+        if (row < BNT) src[i] = p.W + (size_t)min(n0 + row, N - 1) * K + ((lane & 7) ^ (row & 7)) * 8;
+        else src[i] = p.A + (size_t)min(m0 + row - BNT, M - 1) * p.lda + ((lane & 7) ^ ((row - BNT) & 7)) * 8;
+    }
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int lrow = lane & 15, lg = lane >> 4;
+    // element offset of this lane's 16-byte piece inside a row-major [rows][64] tile at k-step 0; k-step ks flips bit 2 of the chunk
+    const int lane_off = lrow * BK + ((lg ^ (lrow & 7)) * 8);
+    const int mrow0 = m0 + wm * FM * 16, ncol0 = n0 + wn * FN * 16;
+
+    auto stage = [&](auto bufc, int kt) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value;
+        uint16_t *base = smem + BUF * SLOT;
+#pragma unroll
+        for (int i = 0; i < DPT; ++i) glds16(src[i] + (size_t)kt * BK, base + (i * NW + wave) * 8 * BK);
+    };
+    auto mfmas = [&](const bf16x8(&fw)[FN], const bf16x8(&fa)[FM]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+    };
+    // Epilogue operands requested before the K loop (they are older than every DMA, so the counted vmcnt waits still mean what
+    // they say): bias, per-head norm weights, the consumer's row sums, and -- where the registers are there (the 4-wave tiles) --
+    // the residual rows and gates.  Without this the epilogue starts with a dependent L2 / HBM round trip per operand.
+    f32x4 bias_pre[FN], qkw_pre[FN];
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+        bias_pre[i] = qkw_pre[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            const float4 b = *reinterpret_cast<const float4 *>(p.bias + min(ncol0 + i * 16 + lg * 4, N - 4));
+            bias_pre[i] = f32x4{b.x, b.y, b.z, b.w};
+        }
+    }
+    if (EPI == GA_GEMM_EPI_STORE_BF16 && FN == 4) {
+        const float *qkw = ncol0 < p.qk_cols0 ? p.qk_w0 : (ncol0 < p.qk_cols1 ? p.qk_w1 : nullptr);
+        if (qkw) {
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const float4 w = *reinterpret_cast<const float4 *>(qkw + i * 16 + lg * 4);
+                qkw_pre[i] = f32x4{w.x, w.y, w.z, w.w};
+            }
+        }
+    }
+    constexpr bool PRE = EPI == GA_GEMM_EPI_RESIDUAL && NW == 4;      // 8-wave tile: 256-register budget, no room
+    ResidualPrefetch<PRE ? FM : 1> pre;
+    if (PRE) residual_prefetch<FM, FN / 2>(p, reinterpret_cast<ResidualPrefetch<FM> &>(pre), mrow0, ncol0, lane);
+    constexpr bool RSS = EPI == GA_GEMM_EPI_STORE_BF16;
+    RowSsPrefetch<RSS ? FM : 1> rss;
+    if (RSS && p.row_ss) rowss_prefetch<FM>(p, reinterpret_cast<RowSsPrefetch<FM> &>(rss), mrow0, lane);
+
+    // nk = n_main * NST + NST: the last NST tiles are peeled (compile-time slot, wait count, request-or-not)
+    const int n_main = nk / NST - 1;
+    static_for<0, NST - 1>([&](auto bc) __attribute__((always_inline)) { stage(bc, decltype(bc)::value); });
+
+    if constexpr (PIPE == 0) {
+        auto tile = [&](auto bc, int kt, auto stagec, auto flyc) __attribute__((always_inline)) {
+            constexpr int b = decltype(bc)::value;
+            GA_WAIT_VM(decltype(flyc)::value * DPT);
+            __builtin_amdgcn_s_barrier();   // everyone's part of tile kt landed; everyone left tile kt-1
+            if constexpr (decltype(stagec)::value) stage(std::integral_constant<int, (b + NST - 1) % NST>{}, kt + NST - 1);
+            const uint16_t *bw = smem + b * SLOT, *ba = bw + BNT * BK;
+            bf16x8 fw[KS][FN], fa[KS][FM];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int i = 0; i < FN; ++i)
+                    fw[ks][i] = *reinterpret_cast<const bf16x8 *>(bw + (wn * FN + i) * 16 * BK + (lane_off ^ (ks * CPK * 8)));
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+                    fa[ks][j] = *reinterpret_cast<const bf16x8 *>(ba + (wm * FM + j) * 16 * BK + (lane_off ^ (ks * CPK * 8)));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) mfmas(fw[ks], fa[ks]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        int kt = 0;
+        for (int it = 0; it < n_main; ++it) {
+            static_for<0, NST>([&](auto bc) __attribute__((always_inline)) {
+                tile(bc, kt + decltype(bc)::value, std::true_type{}, std::integral_constant<int, NST - 2>{});
+            });
+            kt += NST;
+        }
+        static_for<0, NST>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr bool st = i == 0;                        // tile kt+i+NST-1 exists
+            constexpr int fly = st ? NST - 2 : NST - 1 - i;    // issued tiles younger than this one
+            tile(ic, kt + i, std::integral_constant<bool, st>{}, std::integral_constant<int, fly>{});
+        });
+    } else {
+        bf16x8 fw[2][FN], fa[2][FM];
+        const uint32_t lds0 = (uint32_t)(size_t)(const __attribute__((address_space(3))) uint16_t *)smem;
+        uint32_t aw[KS][(NST + 1) / 2], aa[KS][(NST + 1) / 2];   // byte addresses: [k-step][slot pair] (ds_read offsets are 16 bit)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int h = 0; h < (NST + 1) / 2; ++h) {
+                aw[ks][h] = lds0 + 2 * (h * 2 * SLOT + wn * FN * 16 * BK + (lane_off ^ (ks * CPK * 8)));
+                aa[ks][h] = lds0 + 2 * (h * 2 * SLOT + BNT * BK + wm * FM * 16 * BK + (lane_off ^ (ks * CPK * 8)));
+            }
+        auto read2 = [&](auto bufc, auto ksc, bf16x8(&w)[FN], bf16x8(&a)[FM]) __attribute__((always_inline)) {
+            constexpr int BUF = decltype(bufc)::value, ks = decltype(ksc)::value;
+            static_assert(2 * ((BUF & 1) * SLOT + ((FN > FM ? FN : FM) - 1) * 16 * BK) < 65536, "ds_read offset field");
+            const uint32_t adw = aw[ks][BUF >> 1], ada = aa[ks][BUF >> 1];
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w[i]) : "v"(adw), "n"(2 * ((BUF & 1) * SLOT + i * 16 * BK)));
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[j]) : "v"(ada), "n"(2 * ((BUF & 1) * SLOT + j * 16 * BK)));
+        };
+        // all LDS reads except the NEWEST `newer` have returned; the fragments pass through the asm so that their users cannot be
+        // scheduled above the wait
+        auto wait2 = [&](auto newerc, bf16x8(&w)[FN], bf16x8(&a)[FM]) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w[0]) : "n"(decltype(newerc)::value));
+#pragma unroll
+            for (int i = 1; i < FN; ++i) asm volatile("" : "+v"(w[i]));
+#pragma unroll
+            for (int j = 0; j < FM; ++j) asm volatile("" : "+v"(a[j]));
+        };
+        GA_WAIT_VM((NST - 2) * DPT);
+        __builtin_amdgcn_s_barrier();
+        read2(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, fw[0], fa[0]);
+        // HO: 0 last tile, 1 hand over to the next tile without a request, 2 hand over and request tile kt+NST-1
+        auto tile = [&](auto bc, int kt, auto hoc, auto flyc) __attribute__((always_inline)) {
+            constexpr int b = decltype(bc)::value, HO = decltype(hoc)::value;
+            static_for<0, KS>([&](auto ksc) __attribute__((always_inline)) {
+                constexpr int ks = decltype(ksc)::value;
+                constexpr bool more = ks + 1 < KS || HO > 0;
+                if constexpr (ks + 1 < KS) {
+                    read2(bc, std::integral_constant<int, ks + 1>{}, fw[(ks + 1) & 1], fa[(ks + 1) & 1]);
+                } else if constexpr (HO > 0) {
+                    // tile kt+1 must have landed for every wave; everyone has left tile kt-1, whose slot takes tile kt+NST-1
+                    GA_WAIT_VM(decltype(flyc)::value * DPT);
+                    __builtin_amdgcn_s_barrier();
+                    if constexpr (HO == 2) stage(std::integral_constant<int, (b + NST - 1) % NST>{}, kt + NST - 1);
+                    read2(std::integral_constant<int, (b + 1) % NST>{}, std::integral_constant<int, 0>{}, fw[0], fa[0]);
+                }
+                wait2(std::integral_constant<int, more ? FN + FM : 0>{}, fw[ks & 1], fa[ks & 1]);
+                mfmas(fw[ks & 1], fa[ks & 1]);
+            });
+        };
+        int kt = 0;
+        for (int it = 0; it < n_main; ++it) {
+            static_for<0, NST>([&](auto bc) __attribute__((always_inline)) {
+                tile(bc, kt + decltype(bc)::value, std::integral_constant<int, 2>{}, std::integral_constant<int, NST - 3>{});
+            });
+            kt += NST;
+        }
+        static_for<0, NST>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int HO = i == NST - 1 ? 0 : (i == 0 ? 2 : 1);
+            constexpr int fly = HO == 2 ? NST - 3 : (NST - i - 2 > 0 ? NST - i - 2 : 0);   // issued tiles younger than kt+1
+            tile(ic, kt + i, std::integral_constant<int, HO>{}, std::integral_constant<int, fly>{});
+        });
+    }
+
+    if constexpr (FN == 4) {
+        gemm_epilogue<EPI, FM, 4, PRE, RSS>(p, acc, reinterpret_cast<const ResidualPrefetch<FM> *>(&pre),
+                                            reinterpret_cast<const RowSsPrefetch<FM> *>(&rss), mrow0, ncol0, lane, nullptr, bias_pre, qkw_pre);
+    } else {
+        // 32-column waves: the two waves of a 64-column group add their row sums of squares through LDS (the ring is idle now)
+        static_assert(WN == 2, "a 64-column tile is two 32-column waves");
+        float *part = reinterpret_cast<float *>(smem) + (wn * WM + wm) * FM * 16;
+        const bool emit = EPI == GA_GEMM_EPI_RESIDUAL && p.emit_ss;   // kernel-uniform
+        if (emit) __syncthreads();
+        gemm_epilogue<EPI, FM, 2, PRE, RSS>(p, acc, reinterpret_cast<const ResidualPrefetch<FM> *>(&pre),
+                                            reinterpret_cast<const RowSsPrefetch<FM> *>(&rss), mrow0, ncol0, lane, part, bias_pre, qkw_pre);
+        if (emit) {
+            __syncthreads();
+            const float *all = reinterpret_cast<const float *>(smem);
+            if (tid < BM && m0 + tid < M) p.emit_ss[(size_t)(m0 + tid) * (N >> 6) + (n0 >> 6)] = all[tid] + all[BM + tid];
+        }
+    }
 }
 
 // A register-FIFO variant of this kernel (global_load_dwordx4 into D = 4 / 8 K-tiles of VGPRs, ds_write into a double
@@ -456,6 +708,57 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
     // workgroups, exactly one per CU (128-row tiles: 192 workgroups of 5 units against 4).
     //   more than 256 workgroups -> 2-slot ring (<= 64 KiB): two workgroups per CU hide each other's latency
     //   otherwise                -> 4-slot ring: one workgroup per CU, three K-tiles of look-ahead
+    // Round 3: the ring kernel where its K loop applies (K a multiple of 256, at least 512).  Tile by how many workgroups it puts
+    // on the 256 CUs (tools/gemm_lab.hip, tools/gemm_sweep.py): 192 x 128 / 8 waves when that fills at least 5/8 of the chip
+    // (fc1, qkv, everything at M >= 6144), else 96 x 64 (proj, fc2: 256 workgroups at M = 1536), else 64 x 64 (the M = 768
+    // cross-attention projections).  The 96 x 64 tile has 32-column waves: not for the per-head q/k norm or the V^T store.
+    {
+        const int nk = a->K / BK;
+        const long long wg_big = (long long)((a->N + 127) / 128) * ((a->M + 191) / 192);
+        const long long wg_mid = (long long)((a->N + 63) / 64) * ((a->M + 95) / 96);
+        const long long wg_small = (long long)((a->N + 63) / 64) * ((a->M + 63) / 64);
+        const bool wave64 = a->vt || a->qk_cols0 || a->qk_cols1;
+        int ring = 0;
+        if (nk % 4 == 0 && nk >= 8) {
+            if (wg_big >= 160) ring = 1;
+            else if (!wave64 && wg_mid >= 200) ring = 2;
+            else if (wg_small >= 96) ring = 3;
+        }
+#ifdef GA_TUNING  // tuning builds only: GA_GEMM_RING = 0 old kernel, 1 / 2 / 3 force a ring tile
+        if (const char *e = getenv("GA_GEMM_RING")) { const int c = atoi(e); if (c == 0 || (nk % 4 == 0 && nk >= 8 && c >= 1 && c <= 3 && !(c == 2 && wave64))) ring = c; }
+#endif
+        if (ring) {
+            static bool ring_attr_set = false;
+            if (!ring_attr_set) {
+#define GA_RATTR(E)                                                                                                       \
+                (void)hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 4, 2, 3, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 320 * BK * 2); \
+                (void)hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 2, 2, 3, 2, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 160 * BK * 2); \
+                (void)hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 4, 1, 1, 4, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * BK * 2);
+                GA_RATTR(0) GA_RATTR(1) GA_RATTR(2) GA_RATTR(3)
+#undef GA_RATTR
+                ring_attr_set = true;
+            }
+#define GA_RLAUNCH(E)                                                                                                     \
+            if (ring == 1)                                                                                                \
+                hipLaunchKernelGGL((gemm_ring_kernel<E, 4, 2, 3, 4, 4, 2>), dim3((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 191) / 192)), \
+                                   dim3(512), 4 * 320 * BK * 2, s, p);                                                    \
+            else if (ring == 2)                                                                                           \
+                hipLaunchKernelGGL((gemm_ring_kernel<E, 2, 2, 3, 2, 4, 0>), dim3((unsigned)((a->N + 63) / 64), (unsigned)((a->M + 95) / 96)), \
+                                   dim3(256), 4 * 160 * BK * 2, s, p);                                                    \
+            else                                                                                                          \
+                hipLaunchKernelGGL((gemm_ring_kernel<E, 4, 1, 1, 4, 4, 0>), dim3((unsigned)((a->N + 63) / 64), (unsigned)((a->M + 63) / 64)), \
+                                   dim3(256), 4 * 128 * BK * 2, s, p);
+            switch (a->epilogue) {
+            case GA_GEMM_EPI_STORE_BF16: GA_RLAUNCH(0) break;
+            case GA_GEMM_EPI_GELU_BF16: GA_RLAUNCH(1) break;
+            case GA_GEMM_EPI_RESIDUAL: GA_RLAUNCH(2) break;
+            case GA_GEMM_EPI_STORE_F32: GA_RLAUNCH(3) break;
+            default: return GA_DIT_ERR_BAD_SHAPE;
+            }
+#undef GA_RLAUNCH
+            return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
+        }
+    }
     const long long ncols = (a->N + BN - 1) / BN;
     int mt = 4;
     long long best = -1;

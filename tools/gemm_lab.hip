@@ -31,7 +31,8 @@ struct P {
     const uint16_t *A, *W;
     const float *bias;
     uint16_t *out;
-    long long lda, ldo;
+    long long lda, ldo, ldw;
+    int wtiled;   // 1: W stored as [N/8][K/64][8][64] (every DMA instruction reads 1 KiB of consecutive bytes)
 };
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
@@ -76,7 +77,7 @@ __device__ __forceinline__ void static_for(F &&f)
 // MF: MFMA edge (16: v_mfma_f32_16x16x32_bf16, 32: v_mfma_f32_32x32x16_bf16); WM x WN waves; FM x FN fragments per wave;
 // NST ring slots; PIPE 0: all fragment reads of a K-tile, then its MFMAs; 1: k-step software pipeline (fragments of the next
 // k-step requested before the MFMAs of the current one, tile hand-over inside the last k-step); EPI 0 bias, 1 bias + GELU
-template <int MF, int WM, int WN, int FM, int FN, int NST, int PIPE, int EPI, int R>
+template <int MF, int WM, int WN, int FM, int FN, int NST, int PIPE, int EPI, int R, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN) void lab_kernel(P p)
 {
     using acc_t = typename AccT<MF>::T;
@@ -95,20 +96,26 @@ __global__ __launch_bounds__(64 * WM * WN) void lab_kernel(P p)
     const int wn = wave / WM, wm = wave % WM;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
     const int M = p.M, N = p.N, K = p.K;
-    const int nk = K / BK;
+    // ABL (timing-only ablations, wrong results): 1 no output stores, 2 every workgroup reads the A rows of tile 0, 4 ... the W rows
+    // of tile 0, 8 no MFMAs, 16 no DMA after the prologue, 32 only the last NST + R K-tiles
+    const int nk = (ABL & 32) ? NST + R : K / BK;
+    const int n0w = (ABL & 4) ? 0 : n0, m0a = (ABL & 2) ? 0 : m0;
 
     // DMA sources: instruction i of this wave fills rows q*8 .. q*8+7 of the slot image [W rows | A rows], q = i*NW + wave
     const uint16_t *src[DPT];
+    int kstep[DPT];
 #pragma unroll
     for (int i = 0; i < DPT; ++i) {
         const int row = (i * NW + wave) * 8 + (lane >> 3);
+        kstep[i] = (row < BN && p.wtiled) ? 512 : BK;
         if (row < BN) {
             const int sw = MF == 16 ? (row & 7) : ((row >> 1) & 7);
-            src[i] = p.W + (size_t)min(n0 + row, N - 1) * K + ((lane & 7) ^ sw) * 8;
+            if (p.wtiled) src[i] = p.W + (size_t)((n0w + row) >> 3) * (K / 64) * 512 + (row & 7) * 64 + ((lane & 7) ^ sw) * 8;
+            else src[i] = p.W + (size_t)min(n0w + row, N - 1) * p.ldw + ((lane & 7) ^ sw) * 8;
         } else {
             const int r = row - BN;
             const int sw = MF == 16 ? (r & 7) : ((r >> 1) & 7);
-            src[i] = p.A + (size_t)min(m0 + r, M - 1) * p.lda + ((lane & 7) ^ sw) * 8;
+            src[i] = p.A + (size_t)min(m0a + r, M - 1) * p.lda + ((lane & 7) ^ sw) * 8;
         }
     }
     acc_t acc[FN][FM];
@@ -128,8 +135,9 @@ __global__ __launch_bounds__(64 * WM * WN) void lab_kernel(P p)
     auto stage = [&](auto bufc, int kt) __attribute__((always_inline)) {
         constexpr int BUF = decltype(bufc)::value;
         uint16_t *base = smem + BUF * SLOT;
+        if ((ABL & 16) && kt >= NST - 1) return;
 #pragma unroll
-        for (int i = 0; i < DPT; ++i) glds16(src[i] + (size_t)kt * BK, base + (i * NW + wave) * 8 * BK);
+        for (int i = 0; i < DPT; ++i) glds16(src[i] + (size_t)kt * kstep[i], base + (i * NW + wave) * 8 * BK);
     };
     auto read_frags = [&](auto bufc, auto ksc, bf16x8(&fw)[FN], bf16x8(&fa)[FM]) __attribute__((always_inline)) {
         constexpr int BUF = decltype(bufc)::value, ks = decltype(ksc)::value;
@@ -146,7 +154,8 @@ __global__ __launch_bounds__(64 * WM * WN) void lab_kernel(P p)
         for (int i = 0; i < FN; ++i)
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
-                if constexpr (MF == 16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+                if constexpr ((ABL & 8) != 0) acc[i][j][0] += __builtin_bit_cast(float, (int)fw[i][0] ^ (int)fa[j][0]);
+                else if constexpr (MF == 16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
                 else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
             }
     };
@@ -192,11 +201,11 @@ __global__ __launch_bounds__(64 * WM * WN) void lab_kernel(P p)
         // PIPE 2: the fragment reads are inline asm and the waits are counted by hand (hipcc on gfx950 only ever emits
         // lgkmcnt(0), which would wait for the reads just issued for the NEXT k-step as well)
         const uint32_t lds0 = (uint32_t)(size_t)(const __attribute__((address_space(3))) uint16_t *)smem;
-        uint32_t aw[KS][2], aa[KS][2];   // byte addresses: [k-step][slot pair]
+        uint32_t aw[KS][(NST + 1) / 2], aa[KS][(NST + 1) / 2];   // byte addresses: [k-step][slot pair]
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < (NST + 1) / 2; ++h) {
                 aw[ks][h] = lds0 + 2 * (h * 2 * SLOT + wn * FN * MF * BK + (lane_off ^ (ks * CPK * 8)));
                 aa[ks][h] = lds0 + 2 * (h * 2 * SLOT + BN * BK + wm * FM * MF * BK + (lane_off ^ (ks * CPK * 8)));
             }
@@ -268,6 +277,7 @@ __global__ __launch_bounds__(64 * WM * WN) void lab_kernel(P p)
     }
 
     // epilogue: bias (+ GELU), 16-byte bf16 stores after a lane-pair exchange
+    if (EPI >= 2) __syncthreads();
     const int nbase = n0 + wn * FN * MF, mbase = m0 + wm * FM * MF;
     if constexpr (MF == 16) {
         const int g = lane >> 4;
@@ -284,15 +294,26 @@ __global__ __launch_bounds__(64 * WM * WN) void lab_kernel(P p)
                     w[4 + r] = __uint_as_float(sw[1]);
                 }
                 const int n = nbase + q * 32 + (g & 1) * 16 + (g >> 1) * 8;
-                if (m >= M || n >= N) continue;
+                if (m >= M || n >= N || ((ABL & 1) && acc[0][0][0] != 12345.678f)) continue;
                 const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + n), b1 = *reinterpret_cast<const float4 *>(p.bias + n + 4);
                 w[0] += b0.x; w[1] += b0.y; w[2] += b0.z; w[3] += b0.w; w[4] += b1.x; w[5] += b1.y; w[6] += b1.z; w[7] += b1.w;
-                if (EPI == 1) {
+                if (EPI == 1 || EPI == 3) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) w[e] = gelu_erf(w[e]);
                 }
-                *reinterpret_cast<uint4 *>(p.out + (size_t)m * p.ldo + n) =
-                    make_uint4(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]), pack_bf16x2(w[4], w[5]), pack_bf16x2(w[6], w[7]));
+                const uint4 pk = make_uint4(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]), pack_bf16x2(w[4], w[5]), pack_bf16x2(w[6], w[7]));
+                if (EPI >= 2) *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(smem) + (size_t)(m - m0) * (BN * 2 + 32) + (n - n0) * 2) = pk;
+                else *reinterpret_cast<uint4 *>(p.out + (size_t)m * p.ldo + n) = pk;
+            }
+        }
+        if (EPI >= 2) {   // staged store: the tile leaves through LDS in whole 256-byte rows
+            __syncthreads();
+            constexpr int CPR = BN * 2 / 16;
+            for (int idx = tid; idx < BM * CPR; idx += 64 * NW) {
+                const int row = idx / CPR, c = idx % CPR;
+                const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(smem) + (size_t)row * (BN * 2 + 32) + c * 16);
+                if (m0 + row < M && n0 + c * 8 < N && !((ABL & 1) && acc[0][0][0] != 12345.678f))
+                    *reinterpret_cast<uint4 *>(p.out + (size_t)(m0 + row) * p.ldo + n0 + c * 8) = v;
             }
         }
     } else {
@@ -313,7 +334,7 @@ __global__ __launch_bounds__(64 * WM * WN) void lab_kernel(P p)
                         w[4 + r] = __uint_as_float(sw[1]);
                     }
                     const int n = nbase + i * 32 + (2 * pq + h) * 8;
-                    if (m >= M || n >= N) continue;
+                    if (m >= M || n >= N || ((ABL & 1) && acc[0][0][0] != 12345.678f)) continue;
                     const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + n), b1 = *reinterpret_cast<const float4 *>(p.bias + n + 4);
                     w[0] += b0.x; w[1] += b0.y; w[2] += b0.z; w[3] += b0.w; w[4] += b1.x; w[5] += b1.y; w[6] += b1.z; w[7] += b1.w;
                     if (EPI == 1) {
@@ -334,17 +355,17 @@ __global__ void ref_kernel(P p, float *ref, int epi)
     if (n >= p.N) return;
     float s = 0.f;
     for (int k = 0; k < p.K; ++k)
-        s += __uint_as_float((uint32_t)p.A[(size_t)m * p.lda + k] << 16) * __uint_as_float((uint32_t)p.W[(size_t)n * p.K + k] << 16);
+        s += __uint_as_float((uint32_t)p.A[(size_t)m * p.lda + k] << 16) * __uint_as_float((uint32_t)(p.wtiled ? p.W[(size_t)(n >> 3) * (p.K / 64) * 512 + (size_t)(k >> 6) * 512 + (n & 7) * 64 + (k & 63)] : p.W[(size_t)n * p.ldw + k]) << 16);
     s += p.bias[n];
-    if (epi == 1) s = 0.5f * s * (1.0f + erff(s * 0.70710678118654752f));
+    if (epi == 1 || epi == 3) s = 0.5f * s * (1.0f + erff(s * 0.70710678118654752f));
     ref[(size_t)m * p.N + n] = s;
 }
 
-__global__ void cmp_kernel(const uint16_t *out, const float *ref, size_t n, unsigned *bad, float *maxerr)
+__global__ void cmp_kernel(const uint16_t *out, const float *ref, size_t n, unsigned *bad, float *maxerr, int N, long long ldo)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float o = __uint_as_float((uint32_t)out[i] << 16), r = ref[i];
+    const float o = __uint_as_float((uint32_t)out[(i / N) * ldo + (i % N)] << 16), r = ref[i];
     const float err = fabsf(o - r), tol = 0.02f + 0.012f * fabsf(r);
     if (!(err <= tol)) atomicAdd(bad, 1u);
     atomicMax(reinterpret_cast<unsigned *>(maxerr), __float_as_uint(err));
@@ -360,26 +381,26 @@ struct Bufs {
     int wcopies; size_t wstride;
 };
 static const char *g_filter = nullptr;
-static int g_iters = 200;
+static int g_iters = 200, g_pada = 0, g_padw = 0, g_pado = 0, g_wtiled = 0;
 
-template <int MF, int WM, int WN, int FM, int FN, int NST, int PIPE, int EPI, int R>
+template <int MF, int WM, int WN, int FM, int FN, int NST, int PIPE, int EPI, int R, int ABL = 0>
 static void run_variant_r(const char *name, const Shape &s, Bufs &b)
 {
     if (g_filter && !strstr(name, g_filter)) return;
     constexpr int BM = WM * FM * MF, BN = WN * FN * MF;
     constexpr size_t lds = (size_t)NST * (BM + BN) * 64 * 2;
-    auto kern = lab_kernel<MF, WM, WN, FM, FN, NST, PIPE, EPI, R>;
+    auto kern = lab_kernel<MF, WM, WN, FM, FN, NST, PIPE, EPI, R, ABL>;
     CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    P p{s.M, s.N, s.K, b.A, b.W, b.bias, b.out, s.K, s.N};
+    P p{s.M, s.N, s.K, b.A, b.W, b.bias, b.out, s.K + g_pada, s.N + g_pado, s.K + g_padw, g_wtiled};
     const dim3 grid((s.N + BN - 1) / BN, (s.M + BM - 1) / BM), block(64 * WM * WN);
     // correctness on the full output
-    CK(hipMemset(b.out, 0xff, (size_t)s.M * s.N * 2));
+    CK(hipMemset(b.out, 0xff, (size_t)s.M * (s.N + g_pado) * 2));
     CK(hipMemset(b.bad, 0, 4)); CK(hipMemset(b.maxerr, 0, 4));
     hipLaunchKernelGGL(kern, grid, block, lds, 0, p);
     CK(hipGetLastError());
     ref_kernel<<<dim3((s.N + 255) / 256, s.M), 256>>>(p, b.ref, EPI);
     const size_t n = (size_t)s.M * s.N;
-    cmp_kernel<<<(unsigned)((n + 255) / 256), 256>>>(b.out, b.ref, n, b.bad, b.maxerr);
+    cmp_kernel<<<(unsigned)((n + 255) / 256), 256>>>(b.out, b.ref, n, b.bad, b.maxerr, s.N, p.ldo);
     CK(hipDeviceSynchronize());
     unsigned bad; float maxerr;
     CK(hipMemcpy(&bad, b.bad, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&maxerr, b.maxerr, 4, hipMemcpyDeviceToHost));
@@ -397,6 +418,8 @@ static void run_variant_r(const char *name, const Shape &s, Bufs &b)
         us[mode] = ms * 1e3f / g_iters;
     }
     const double fl = 2.0 * s.M * s.N * s.K;
+    if (ABL) bad = 0;
+    printf("pad a%d w%d o%d wt%d ", g_pada, g_padw, g_pado, g_wtiled);
     printf("%-34s %-18s grid %4d lds %6zu  cold %7.2f us %7.1f TF | warm %7.2f us %7.1f TF | %s maxerr %.3g\n", name, s.name,
            grid.x * grid.y, lds, us[0], fl / us[0] / 1e6, us[1], fl / us[1] / 1e6, bad ? "WRONG" : "ok", maxerr);
     fflush(stdout);
@@ -414,6 +437,33 @@ static void run_variant(const char *name, const Shape &s, Bufs &b)
     else printf("%s: nk %% NST = %d not instantiated\n", name, r);
 }
 
+template <int MF, int WM, int WN, int FM, int FN, int NST, int PIPE, int ABL>
+static void run_abl(const char *name, const Shape &s, Bufs &b)
+{
+    if ((s.K / 64) % NST) return;
+    char nm[96];
+    snprintf(nm, sizeof nm, "%s abl%d", name, ABL);
+    run_variant_r<MF, WM, WN, FM, FN, NST, PIPE, 0, 0, ABL>(nm, s, b);
+}
+template <int MF, int WM, int WN, int FM, int FN, int NST, int PIPE>
+static void run_abls(const char *name, const Shape &s, Bufs &b)
+{
+    run_abl<MF, WM, WN, FM, FN, NST, PIPE, 0>(name, s, b);
+    run_abl<MF, WM, WN, FM, FN, NST, PIPE, 1>(name, s, b);
+    run_abl<MF, WM, WN, FM, FN, NST, PIPE, 2>(name, s, b);
+    run_abl<MF, WM, WN, FM, FN, NST, PIPE, 4>(name, s, b);
+    run_abl<MF, WM, WN, FM, FN, NST, PIPE, 6>(name, s, b);
+    run_abl<MF, WM, WN, FM, FN, NST, PIPE, 7>(name, s, b);
+    run_abl<MF, WM, WN, FM, FN, NST, PIPE, 8>(name, s, b);
+    run_abl<MF, WM, WN, FM, FN, NST, PIPE, 16>(name, s, b);
+    run_abl<MF, WM, WN, FM, FN, NST, PIPE, 17>(name, s, b);
+    run_abl<MF, WM, WN, FM, FN, NST, PIPE, 24>(name, s, b);
+    run_abl<MF, WM, WN, FM, FN, NST, PIPE, 25>(name, s, b);
+    run_abl<MF, WM, WN, FM, FN, NST, PIPE, 32>(name, s, b);
+    run_abl<MF, WM, WN, FM, FN, NST, PIPE, 33>(name, s, b);
+    run_abl<MF, WM, WN, FM, FN, NST, PIPE, 57>(name, s, b);
+}
+
 int main(int argc, char **argv)
 {
     if (argc > 1) g_filter = argv[1];
@@ -421,10 +471,14 @@ int main(int argc, char **argv)
     const Shape shapes[] = {{1536, 4096, 1024, "fc1 1536x4096x1024"}, {1536, 3072, 1024, "qkv 1536x3072x1024"},
                             {1536, 1024, 4096, "fc2 1536x1024x4096"}, {1536, 1024, 1024, "proj 1536x1024x1024"},
                             {768, 1024, 1024, "caq 768x1024x1024"},   {6144, 4096, 1024, "fc1x4 6144x4096x1024"}};
-    const size_t maxA = (size_t)6144 * 4096, maxW = (size_t)4096 * 4096, maxO = (size_t)6144 * 4096;
+    if (getenv("LAB_PADA")) g_pada = atoi(getenv("LAB_PADA"));
+    if (getenv("LAB_PADW")) g_padw = atoi(getenv("LAB_PADW"));
+    if (getenv("LAB_PADO")) g_pado = atoi(getenv("LAB_PADO"));
+    if (getenv("LAB_WTILED")) g_wtiled = atoi(getenv("LAB_WTILED"));
+    const size_t maxA = (size_t)6144 * (4096 + 512), maxW = (size_t)4096 * 4096, maxO = (size_t)6144 * (4096 + 512);
     Bufs b;
     b.wcopies = 40;   // 40 x 8 MiB > the 256 MiB Infinity Cache
-    b.wstride = (size_t)4096 * 1024;
+    b.wstride = (size_t)4096 * (1024 + 512);
     CK(hipMalloc(&b.A, maxA * 2)); CK(hipMalloc(&b.W, b.wstride * b.wcopies * 2)); CK(hipMalloc(&b.out, maxO * 2));
     CK(hipMalloc(&b.bias, 4096 * 4)); CK(hipMalloc(&b.ref, maxO * 4)); CK(hipMalloc(&b.bad, 4)); CK(hipMalloc(&b.maxerr, 4));
     {
@@ -444,6 +498,78 @@ int main(int argc, char **argv)
     for (const Shape &s : shapes) {
         if (getenv("LAB_SHAPE") && !strstr(s.name, getenv("LAB_SHAPE"))) continue;
         const int E = 0;
+        if (getenv("LAB_WN1")) {
+            run_variant<16, 2, 2, 3, 2, 4, 0, E>("m16  96x64 4w(48x32) nst4 batch", s, b);
+            run_variant<16, 2, 1, 3, 4, 4, 0, E>("m16  96x64 2w(48x64) nst4 batch", s, b);
+            run_variant<16, 2, 1, 3, 4, 4, 2, E>("m16  96x64 2w(48x64) nst4 asm", s, b);
+            run_variant<16, 4, 1, 2, 4, 4, 0, E>("m16 128x64 4w(32x64) nst4 batch", s, b);
+            run_variant<16, 4, 1, 2, 4, 4, 2, E>("m16 128x64 4w(32x64) nst4 asm", s, b);
+            run_variant<16, 4, 1, 1, 4, 4, 0, E>("m16  64x64 4w(16x64) nst4 batch", s, b);
+            run_variant<16, 4, 1, 1, 4, 4, 2, E>("m16  64x64 4w(16x64) nst4 asm", s, b);
+            run_variant<16, 2, 1, 2, 4, 4, 0, E>("m16  64x64 2w(32x64) nst4 batch", s, b);
+            run_variant<16, 2, 1, 2, 4, 4, 2, E>("m16  64x64 2w(32x64) nst4 asm", s, b);
+            run_variant<16, 4, 1, 3, 4, 4, 2, E>("m16 192x64 4w(48x64) nst4 asm", s, b);
+            run_variant<16, 2, 2, 2, 2, 4, 0, E>("m16  64x64 4w(32x32) nst4 batch", s, b);
+            continue;
+        }
+        if (getenv("LAB_BEST")) {
+            run_variant<16, 4, 2, 3, 4, 4, 2, E>("m16 192x128 8w(48x64) nst4 asm", s, b);
+            run_variant<16, 2, 2, 3, 2, 4, 0, E>("m16  96x64 4w nst4 batch", s, b);
+            run_variant<16, 2, 2, 3, 2, 4, 2, E>("m16  96x64 4w nst4 asm", s, b);
+            run_variant<16, 2, 2, 2, 2, 4, 0, E>("m16  64x64 4w nst4 batch", s, b);
+            run_variant<16, 2, 2, 3, 4, 2, 0, E>("m16  96x128 4w nst2 batch", s, b);
+            continue;
+        }
+        if (getenv("LAB_DEEP")) {
+            run_variant<16, 2, 2, 3, 2, 4, 0, E>("m16  96x64 4w nst4 batch", s, b);
+            run_variant<16, 2, 2, 3, 2, 8, 0, E>("m16  96x64 4w nst8 batch", s, b);
+            run_variant<16, 2, 2, 3, 2, 8, 2, E>("m16  96x64 4w nst8 asm", s, b);
+            run_variant<16, 2, 2, 2, 2, 8, 0, E>("m16  64x64 4w nst8 batch", s, b);
+            run_variant<16, 2, 2, 2, 2, 8, 2, E>("m16  64x64 4w nst8 asm", s, b);
+            run_variant<16, 2, 2, 4, 2, 4, 0, E>("m16 128x64 4w nst4 batch", s, b);
+            run_variant<16, 2, 2, 4, 2, 4, 2, E>("m16 128x64 4w nst4 asm", s, b);
+            run_variant<16, 2, 2, 3, 4, 4, 0, E>("m16  96x128 4w nst4 batch", s, b);
+            run_variant<16, 2, 2, 3, 4, 4, 2, E>("m16  96x128 4w nst4 asm", s, b);
+            run_variant<16, 4, 2, 3, 2, 4, 2, E>("m16 192x64 8w nst4 asm", s, b);
+            continue;
+        }
+        if (getenv("LAB_SMALL")) {
+            run_variant<16, 2, 2, 3, 4, 2, 0, E>("m16  96x128 4w nst2 batch", s, b);
+            run_variant<16, 2, 2, 3, 2, 4, 2, E>("m16  96x64 4w nst4 asm", s, b);
+            run_variant<16, 2, 2, 3, 2, 4, 0, E>("m16  96x64 4w nst4 batch", s, b);
+            run_variant<16, 2, 2, 3, 2, 2, 0, E>("m16  96x64 4w nst2 batch", s, b);
+            run_variant<16, 2, 2, 2, 2, 4, 2, E>("m16  64x64 4w nst4 asm", s, b);
+            run_variant<16, 2, 2, 2, 2, 4, 0, E>("m16  64x64 4w nst4 batch", s, b);
+            run_variant<16, 2, 2, 2, 2, 2, 0, E>("m16  64x64 4w nst2 batch", s, b);
+            run_variant<16, 2, 2, 2, 4, 4, 2, E>("m16  64x128 4w nst4 asm", s, b);
+            run_variant<16, 2, 2, 2, 4, 4, 0, E>("m16  64x128 4w nst4 batch", s, b);
+            run_variant<16, 2, 2, 2, 4, 2, 0, E>("m16  64x128 4w nst2 batch", s, b);
+            run_variant<16, 4, 2, 1, 2, 4, 2, E>("m16  64x64 8w nst4 asm", s, b);
+            run_variant<16, 4, 2, 2, 2, 4, 2, E>("m16 128x64 8w nst4 asm", s, b);
+            run_variant<16, 4, 2, 1, 4, 4, 2, E>("m16  64x128 8w nst4 asm", s, b);
+            run_variant<16, 1, 2, 3, 2, 4, 2, E>("m16  48x64 2w nst4 asm", s, b);
+            run_variant<16, 1, 2, 3, 2, 4, 0, E>("m16  48x64 2w nst4 batch", s, b);
+            run_variant<16, 2, 2, 1, 2, 4, 2, E>("m16  32x64 4w nst4 asm", s, b);
+            continue;
+        }
+        if (getenv("LAB_FEW")) {
+            run_variant<16, 4, 2, 3, 4, 4, 2, E>("m16 192x128 8w(48x64) nst4 asm", s, b);
+            run_variant<16, 4, 2, 3, 4, 4, 2, 2>("m16 192x128 8w(48x64) nst4 asm STAGED", s, b);
+            run_variant<16, 4, 2, 3, 4, 4, 2, 1>("m16 192x128 8w(48x64) nst4 asm GELU", s, b);
+            run_variant<16, 4, 2, 3, 4, 4, 2, 3>("m16 192x128 8w(48x64) nst4 asm GELU STAGED", s, b);
+            run_variant<16, 2, 2, 3, 4, 2, 0, 2>("m16  96x128 4w nst2 batch STAGED", s, b);
+            run_variant<16, 2, 2, 3, 4, 2, 0, E>("m16  96x128 4w nst2 batch", s, b);
+            run_variant<32, 2, 2, 3, 2, 4, 2, E>("m32 192x128 4w nst4 asm", s, b);
+            run_variant<16, 2, 2, 4, 4, 2, 0, E>("m16 128x128 4w nst2 batch", s, b);
+            run_variant<32, 4, 2, 2, 2, 3, 2, E>("m32 256x128 8w nst3 asm", s, b);
+            continue;
+        }
+        if (getenv("LAB_ABL")) {
+            run_abls<16, 4, 2, 3, 4, 4, 2>("m16 192x128 8w(48x64) nst4 asm", s, b);
+            run_abls<16, 2, 2, 3, 4, 2, 0>("m16  96x128 4w nst2 batch", s, b);
+            run_abls<32, 2, 2, 3, 2, 4, 2>("m32 192x128 4w nst4 asm", s, b);
+            continue;
+        }
         //            MF WM WN FM FN NST PIPE EPI
         run_variant<16, 2, 2, 4, 4, 4, 0, E>("m16 128x128 4w nst4 batch", s, b);
         run_variant<16, 2, 2, 4, 4, 2, 0, E>("m16 128x128 4w nst2 batch", s, b);
