@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libga_mi355.so")
 
 GA_OK = 0
 GA_STATUS_NUM_RENDERED, GA_STATUS_OVERFLOW, GA_STATUS_MAX_TILE, GA_STATUS_WORDS = 0, 1, 2, 16
+GA_STATUS_SEG_WORK = 9
+GA_SEG_EPOCH_WORD = 96   # csrc/surfel_common.h: kSegEpochWord
 GA_SURFEL_RECORD_FLOATS = 24
 GA_SURFEL_STAGE_EVENTS = 5
 _ERR = {-1: "GA_ERR_NULL_ARG", -2: "GA_ERR_BAD_SHAPE", -3: "GA_ERR_WORKSPACE", -4: "GA_ERR_LAUNCH"}
@@ -30,7 +32,7 @@ class GaSurfelForwardArgs(ctypes.Structure):
         ("viewmatrix", ctypes.c_void_p), ("projmatrix", ctypes.c_void_p), ("bg", ctypes.c_void_p),
         ("out_color", ctypes.c_void_p), ("out_others", ctypes.c_void_p), ("radii", ctypes.c_void_p),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t), ("capacity", ctypes.c_int64),
-        ("stage_events", ctypes.POINTER(ctypes.c_void_p)),
+        ("stage_events", ctypes.POINTER(ctypes.c_void_p)), ("seg_capacity", ctypes.c_int64),
     ]
 
 
@@ -70,7 +72,7 @@ class GaTsdfFrame(ctypes.Structure):
                 ("extrinsic", ctypes.c_double * 16), ("pose", ctypes.c_double * 16), ("depth_sampling_stride", ctypes.c_int32)]
 
 
-EXPORTS = ("ga_surfel_version", "ga_surfel_workspace_layout", "ga_surfel_forward", "ga_surfel_postprocess",
+EXPORTS = ("ga_surfel_version", "ga_surfel_workspace_layout", "ga_surfel_workspace_layout2", "ga_surfel_forward", "ga_surfel_postprocess",
            "ga_surfel_backward", "ga_surfel_backward_scratch_bytes",
            "ga_tsdf_integrate", "ga_tsdf_mesh_scratch_bytes", "ga_tsdf_mesh_count", "ga_tsdf_mesh_emit", "ga_mesh_write_obj")
 
@@ -100,6 +102,9 @@ def lib():
         L.ga_surfel_workspace_layout.restype = ctypes.c_int
         L.ga_surfel_workspace_layout.argtypes = [ctypes.c_int32] * 4 + [ctypes.c_int64,
                                                                        ctypes.POINTER(GaSurfelWorkspaceLayout)]
+        L.ga_surfel_workspace_layout2.restype = ctypes.c_int
+        L.ga_surfel_workspace_layout2.argtypes = [ctypes.c_int32] * 4 + [ctypes.c_int64, ctypes.c_int64,
+                                                                        ctypes.POINTER(GaSurfelWorkspaceLayout)]
         L.ga_surfel_forward.restype = ctypes.c_int
         L.ga_surfel_forward.argtypes = [ctypes.POINTER(GaSurfelForwardArgs), ctypes.c_void_p]
         L.ga_surfel_backward.restype = ctypes.c_int

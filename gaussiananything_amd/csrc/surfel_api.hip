@@ -31,10 +31,16 @@ const char *ga_surfel_version(void) { return "ga_mi355 surfel gfx950 r2"; }
 int ga_surfel_workspace_layout(int32_t num_points, int32_t num_views, int32_t image_height, int32_t image_width,
                                int64_t capacity, GaSurfelWorkspaceLayout *out)
 {
+    return ga_surfel_workspace_layout2(num_points, num_views, image_height, image_width, capacity, 0, out);
+}
+
+int ga_surfel_workspace_layout2(int32_t num_points, int32_t num_views, int32_t image_height, int32_t image_width,
+                                int64_t capacity, int64_t seg_capacity, GaSurfelWorkspaceLayout *out)
+{
     ga::Dims d;
     if (!out) return GA_ERR_NULL_ARG;
     if (!make_dims(num_points, num_views, image_height, image_width, &d) || capacity < 0 ||
-        capacity > 0xFFFFFFFFll)
+        capacity > 0xFFFFFFFFll || seg_capacity < 0 || seg_capacity > 0xFFFFFFll)
         return GA_ERR_BAD_SHAPE;
     const size_t nv = (size_t)d.N * d.V, nt = (size_t)d.V * d.tiles, cap = (size_t)capacity;
     size_t off = 0;
@@ -50,8 +56,8 @@ int ga_surfel_workspace_layout(int32_t num_points, int32_t num_views, int32_t im
     out->record = off;      off += align256(nv * ga::kRec * 4);
     out->keys = off;        off += align256(cap * 8);
     out->point_list = off;  off += align256(cap * 4);
-    out->seg_table = off;   off += align256(2 * 40 * 4);
-    out->seg_scratch = off; off += align256((cap / 256 + 1) * (size_t)ga::kSegFloats * 8);
+    out->seg_table = off;   off += align256(ga::kSegTableWords * 4);   /* 2 x 40 class entries + the launch epoch word */
+    out->seg_scratch = off; off += align256((size_t)ga::seg_items(capacity, seg_capacity) * (size_t)ga::kSegFloats * 8);
     out->total_bytes = off;
     return GA_OK;
 }
@@ -62,7 +68,7 @@ int ga_surfel_forward(const GaSurfelForwardArgs *a, void *stream_v)
     ga::Dims d;
     if (!make_dims(a->num_points, a->num_views, a->image_height, a->image_width, &d)) return GA_ERR_BAD_SHAPE;
     GaSurfelWorkspaceLayout L;
-    const int rc = ga_surfel_workspace_layout(d.N, d.V, d.H, d.W, a->capacity, &L);
+    const int rc = ga_surfel_workspace_layout2(d.N, d.V, d.H, d.W, a->capacity, a->seg_capacity, &L);
     if (rc != GA_OK) return rc;
     if (!a->viewmatrix || !a->projmatrix || !a->bg || !a->out_color || !a->out_others || !a->workspace)
         return GA_ERR_NULL_ARG;

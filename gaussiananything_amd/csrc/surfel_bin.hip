@@ -41,7 +41,7 @@ __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(const uint32_t *
                                                                 uint32_t *__restrict__ tile_cursor,
                                                                 uint4 *__restrict__ tile_order,
                                                                 uint4 *__restrict__ run_table, int n,
-                                                                int64_t capacity, uint32_t *__restrict__ seg_table,
+                                                                int64_t capacity, int64_t seg_capacity, uint32_t *__restrict__ seg_table,
                                                                 int64_t *__restrict__ status)
 {
     __shared__ uint32_t wt[kScanPer * 16], wt_ex[kScanPer * 16];
@@ -136,6 +136,7 @@ __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(const uint32_t *
             constexpr int kBigBucket = 32 - __builtin_clz((unsigned)kSortCap + 1u);
             if (b == kBigBucket) nbig_s = sx;
         }
+        uint32_t seg_wx = 0;
         {   // segmented blend: a tile of class b >= kSegClass becomes seg_count(b) work items; the classes are laid out
             // longest first, so lane order is work order.  seg_table[b] = (first tile_order slot, first work item)
             const uint32_t segs = (lane < kClasses && b >= kSegClass) ? pop * (uint32_t)seg_count(b) : 0u;
@@ -153,6 +154,12 @@ __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(const uint32_t *
                     status[GA_STATUS_SEG_WORK] = (int64_t)wx;
                 }
             }
+            seg_wx = wx;
+            if (lane == 0) {   // a new epoch for this launch's exchange words (never 0; any start value will do)
+                uint32_t e = seg_table[kSegEpochWord] + 1u;
+                if (e == 0u) e = 1u;
+                seg_table[kSegEpochWord] = e;
+            }
         }
         uint64_t total = lane < 16 ? wide_tot[lane] : 0ull;
         uint32_t mx = lane < 16 ? wave_max[lane] : 0u;
@@ -161,10 +168,14 @@ __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(const uint32_t *
             total += __shfl_down(total, o, 64);
             mx = max(mx, (uint32_t)__shfl_down(mx, o, 64));
         }
+        // segment work items of this launch (the inclusive scan value of lane 32 - kSegClass, class kSegClass being the last
+        // segmented one): more than the exchange scratch holds is an overflow like D > capacity -- nothing is rendered, the
+        // host reads GA_STATUS_SEG_WORK and grows seg_capacity
+        const uint32_t seg_total = __shfl(seg_wx, 32 - kSegClass, 64);
         if (lane == 0) {
             tile_start[n] = (uint32_t)total;
             status[GA_STATUS_NUM_RENDERED] = (int64_t)total;
-            status[GA_STATUS_OVERFLOW] = (total > (uint64_t)capacity || total > 0xFFFFFFFFull) ? 1 : 0;
+            status[GA_STATUS_OVERFLOW] = (total > (uint64_t)capacity || total > 0xFFFFFFFFull || (int64_t)seg_total > seg_capacity) ? 1 : 0;
             status[GA_STATUS_MAX_TILE] = (int64_t)mx;
         }
     }
@@ -572,7 +583,7 @@ void launch_binning(const GaSurfelForwardArgs &a, const Dims &d, const Workspace
 {
     const int nt = d.V * d.tiles;
     hipLaunchKernelGGL(surfel_tile_scan_kernel, dim3(1), dim3(1024), 0, s, ws.tile_count, ws.tile_start,
-                       ws.tile_cursor, ws.tile_order, ws.run_table, nt, a.capacity, ws.seg_table, ws.status);
+                       ws.tile_cursor, ws.tile_order, ws.run_table, nt, a.capacity, seg_items(a.capacity, a.seg_capacity), ws.seg_table, ws.status);
     const dim3 grid((unsigned)((d.N + 256 * kBinSplats - 1) / (256 * kBinSplats)), (unsigned)d.V);
     if (d.tiles <= kLdsTiles)
         hipLaunchKernelGGL(surfel_fill_kernel<true>, grid, dim3(256), 2 * d.tiles * sizeof(uint32_t), s, ws.rect,

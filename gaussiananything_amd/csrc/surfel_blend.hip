@@ -6,7 +6,7 @@
 // MI355X-first formulation, not the CUDA block-cooperative one.  The kernel is bound by VALU issue and LDS bandwidth
 // (profiles/r1f_pmc.txt: 75 M wave instructions per launch, LDS 83 % busy, HBM far from its roof), so everything here is
 // about instructions and LDS bytes per useful (pixel, splat) pair:
-//   * WORK ITEM = one 16x16 tile, or one SEGMENT (256..512 list entries) of a tile whose list has >= 1024 entries; the
+//   * WORK ITEM = one 16x16 tile, or one SEGMENT (256..512 list entries) of a tile whose list has >= 2048 entries; the
 //     16x16 granularity is part of the semantics (the tile rect decides which pixels a splat may touch).
 //   * WORKGROUP = four wavefronts, one per 8x8 pixel quadrant; all four share ONE LDS image of the item's list.
 //   * STAGING (lanes = entries, 64 list entries = one chunk): gather the 96-byte records, test every entry's conservative
@@ -98,7 +98,8 @@ __device__ __forceinline__ void lds_store(uint32_t *p, uint32_t v)
 // 1 340 segments), while plain agent-scope stores to different addresses are not ordered with respect to each other on
 // their way to memory.  So every exchanged value is SELF-VALIDATING: one 64-bit agent-scope store (sc1: bypasses the L2)
 // of (value, epoch of this launch), which the reader polls until the epoch matches -- no fence, no flag, no ordering
-// assumption.  The epoch is a per-launch number from the host, so words left by earlier launches never match.
+// assumption.  The epoch is a per-launch number the tile scan bumps in the workspace (seg_table[kSegEpochWord]: also under HIP-graph
+// replay, where a kernel argument would be frozen), so words left by earlier launches never match.
 __device__ __forceinline__ void xwg_store(unsigned long long *p, float v, uint32_t epoch)
 {
     __hip_atomic_store(p, ((unsigned long long)epoch << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -624,6 +625,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
 #endif
     if (blockIdx.x < seg_region) {
         if (blockIdx.x >= segwork) return;   // more workgroups than work items: whole workgroups leave
+        BlendArgs ks = k;
+        ks.epoch = seg_table[kSegEpochWord];   // this launch's epoch (written by the tile scan, a kernel boundary ago)
         for (;;) {
             if (threadIdx.x == 0)
                 ring.work = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_SEG_TICKET), 1ull);
@@ -647,7 +650,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
                 ring.sat_waves[0] = 0; ring.sat_waves[1] = 0;
             }
             __syncthreads();
-            blend_item(ring, k, dm, lane, wave, pos, k.tile_order[pos], rel / ntile, nsegs, work, ntile, st);
+            blend_item(ring, ks, dm, lane, wave, pos, k.tile_order[pos], rel / ntile, nsegs, work, ntile, st);
             __syncthreads();   // everybody has left the item: the LDS image and the ticket word may be overwritten
         }
     } else {
@@ -680,11 +683,8 @@ void launch_blend(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &
     // a segmented tile of class b holds >= 2^(b-1) entries and takes seg_count(b) = 2^(b-9) = 2^(b-1) / 256 work items
     constexpr uint32_t kSegWGs = 512;   // two of the three workgroup slots of a CU; beyond that they loop
     const uint32_t seg_region = (uint32_t)std::min<int64_t>(a.capacity / 256, kSegWGs);
-    static std::atomic<uint32_t> launches{0};
-    uint32_t epoch = ++launches;
-    if (epoch == 0) epoch = ++launches;   // 0 is what a fresh workspace may hold
     const BlendArgs k{ws.tile_order, ws.point_list, ws.record, a.bg, ws.seg_sync, ws.seg_scratch, a.out_color, a.out_others,
-                      epoch, a.flags};
+                      0u /* the segment workgroups read the launch epoch from the workspace */, a.flags};
     hipLaunchKernelGGL(surfel_blend_kernel, dim3(seg_region + (unsigned)nt), dim3(256), 0, s, k, d, nt, seg_region,
                        ws.seg_table, ws.status);
 }

@@ -45,6 +45,17 @@ constexpr int kItemChunks = 8;
 constexpr int kSegClass = GA_SEG_CLASS;
 constexpr int kLongList = 1 << (GA_SEG_CLASS - 1);
 __host__ __device__ constexpr uint32_t seg_count(int b) { return b < kSegClass ? 1u : (1u << (b - 9)); }
+// launch epoch of the cross-workgroup exchange words: a DEVICE word (seg_table[kSegEpochWord], behind the 2 x 40 table entries) that
+// the tile scan bumps once per launch and the per-launch memset does not touch -- a host-side counter passed as a kernel
+// argument is frozen under HIP-graph replay, and words of the previous replay would validate
+// (tile, segment) work items the exchange scratch holds: the caller's seg_capacity, or by default 1/8 of the worst case
+// capacity / 256 (every entry in a list of 2048 or more) plus a floor; the tile scan reports more as an overflow
+__host__ __device__ constexpr int64_t seg_items(int64_t capacity, int64_t seg_capacity)
+{
+    return seg_capacity > 0 ? seg_capacity : capacity / 2048 + 128;
+}
+constexpr int kSegEpochWord = 96;
+constexpr int kSegTableWords = 128;
 constexpr int kSegFloats = 15 * 256;     // scratch words per segment: transmittance + 14 partial sums for 256 pixels
 constexpr int kSortCap = GA_SURFEL_SORT_RUN;         // per-tile entries sorted in one LDS pass (16 KiB of u64 keys: 8+ workgroups per CU)
 

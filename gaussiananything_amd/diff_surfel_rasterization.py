@@ -11,6 +11,7 @@ launch sequence); the per-view ``GaussianRasterizer`` call is a V=1 special case
 from __future__ import annotations
 
 import ctypes
+import os
 from collections import OrderedDict
 import warnings
 from typing import NamedTuple, Optional
@@ -39,20 +40,29 @@ class GaussianRasterizationSettings(NamedTuple):
 class SurfelWorkspace:
     """Caller-owned device scratch for ``ga_surfel_forward`` (the C-ABI allocates nothing).
 
-    ``capacity`` is the number of binned (tile, splat) entries the buffers can hold.  The device reports the real count
-    D and an overflow flag in ``status``; on overflow nothing was rendered and the caller grows the workspace and
-    re-runs (``rasterize_views`` does that).
+    ``capacity`` is the number of binned (tile, splat) entries the buffers can hold, ``seg_capacity`` the number of
+    (tile, segment) work items of the segmented blend (lists of 2048 entries or more) its exchange scratch holds (0 = the
+    library's default, capacity / 2048 + 128; the worst case is capacity / 256).  The device reports the real counts and an
+    overflow flag in ``status``; on overflow nothing was rendered and the caller grows the workspace and re-runs
+    (``rasterize_views`` does that; ``grown`` sizes the replacement).
     """
 
-    def __init__(self, device, num_points, num_views, height, width, capacity):
+    def __init__(self, device, num_points, num_views, height, width, capacity, seg_capacity=0):
         self.key = (num_points, num_views, height, width)
+        self.device = device
         self.capacity = int(capacity)
+        self.seg_capacity = int(seg_capacity)
+        self.seg_items = self.seg_capacity if self.seg_capacity > 0 else self.capacity // 2048 + 128
         self.layout = _lib.GaSurfelWorkspaceLayout()
-        _lib.check(_lib.lib().ga_surfel_workspace_layout(num_points, num_views, height, width, self.capacity,
-                                                         ctypes.byref(self.layout)), "ga_surfel_workspace_layout")
+        _lib.check(_lib.lib().ga_surfel_workspace_layout2(num_points, num_views, height, width, self.capacity,
+                                                          self.seg_capacity, ctypes.byref(self.layout)),
+                   "ga_surfel_workspace_layout2")
         self.buffer = torch.empty(self.layout.total_bytes + 256, dtype=torch.uint8, device=device)
         self.offset = (-self.buffer.data_ptr()) % 256
         self.ptr = self.buffer.data_ptr() + self.offset
+        # launch epoch of the segmented blend's exchange words: any start value will do, but recycled device memory may still
+        # hold words of an earlier workspace -- start somewhere random so that they only match by a 2^-32 coincidence
+        self.section("seg_table", torch.int32, 128)[_lib.GA_SEG_EPOCH_WORD] = int.from_bytes(os.urandom(4), "little") - (1 << 31)
 
     def section(self, name, dtype, count):
         """Typed view of one workspace section (tests read the integer artefacts through this)."""
@@ -63,17 +73,37 @@ class SurfelWorkspace:
     def status(self):
         return self.section("status", torch.int64, _lib.GA_STATUS_WORDS)
 
+    def grown(self, st):
+        """A replacement workspace for the counts an overflowed launch reported in its status words ``st`` (host tensor)."""
+        need, seg_need = int(st[_lib.GA_STATUS_NUM_RENDERED]), int(st[_lib.GA_STATUS_SEG_WORK])
+        if need > 0xFFFFFFFF:
+            raise RuntimeError(f"{need} binned entries exceed the 2^32 limit of the tile ranges")
+        cap = max(self.capacity, need + need // 4) if need > self.capacity else self.capacity
+        seg = self.seg_capacity
+        if seg_need > (seg if seg > 0 else cap // 2048 + 128):
+            seg = seg_need + seg_need // 4 + 16
+        n, v, h, w = self.key
+        return SurfelWorkspace(self.device, n, v, h, w, cap, seg)
+
+
+def default_capacity(n, v):
+    """Binned entries a fresh workspace is sized for: two tiles per (view, splat) on average -- BASELINE configs[1] needs 1.8;
+    scenes that need more are reported by the device and the workspace is re-sized once."""
+    return max(2 * n * v, 1 << 16)
+
 
 _WS_CACHE_SLOTS = 8          # most recently used (device, N, V, H, W) workspaces kept alive; older ones are released
 _ws_cache = OrderedDict()
+_autograd_pool = {}           # (device, N, V, H, W) -> idle workspaces of the differentiable path (at most two kept per key)
 
 
-def _get_workspace(device, n, v, h, w, min_capacity=0):
+def _get_workspace(device, n, v, h, w, replacement=None):
     key = (str(device), n, v, h, w)
     ws = _ws_cache.pop(key, None)
-    if ws is None or ws.capacity < min_capacity:
-        cap = max(int(min_capacity), 4 * n * v, 1 << 16)
-        ws = SurfelWorkspace(device, n, v, h, w, cap)
+    if replacement is not None:
+        ws = replacement
+    if ws is None:
+        ws = SurfelWorkspace(device, n, v, h, w, default_capacity(n, v))
     _ws_cache[key] = ws          # most recently used last
     while len(_ws_cache) > _WS_CACHE_SLOTS:
         _ws_cache.popitem(last=False)
@@ -123,17 +153,21 @@ class _RasterizeViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, opacities, colors, scales, rotations, vm, pm, bg, h, w, scale_modifier):
         n, v = means3D.shape[0], vm.shape[0]
-        ws = SurfelWorkspace(means3D.device, n, v, h, w, max(4 * n * v, 1 << 16))
+        # a workspace of its own until the backward has read it; taken from / returned to a small pool instead of a fresh
+        # allocation per call
+        pool = _autograd_pool.setdefault((str(means3D.device), n, v, h, w), [])
+        ws = pool.pop() if pool else SurfelWorkspace(means3D.device, n, v, h, w, default_capacity(n, v))
+        ws.generation = getattr(ws, "generation", 0) + 1
         while True:
             color, radii, allmap, _ = _rasterize_views_nograd(means3D, opacities, colors, scales, rotations, vm, pm, bg, h, w,
                                                               scale_modifier, workspace=ws, check_overflow=False)
             st = ws.status().cpu()
             if int(st[_lib.GA_STATUS_OVERFLOW]) == 0:
                 break
-            need = int(st[_lib.GA_STATUS_NUM_RENDERED])
-            ws = SurfelWorkspace(means3D.device, n, v, h, w, need + need // 4)
+            ws = ws.grown(st)
+            ws.generation = 1
         ctx.save_for_backward(means3D, opacities, colors, scales, rotations, vm, pm, bg, color, allmap, radii)
-        ctx.ws, ctx.geom = ws, (n, v, h, w, float(scale_modifier))
+        ctx.ws, ctx.ws_generation, ctx.geom = ws, ws.generation, (n, v, h, w, float(scale_modifier))
         ctx.mark_non_differentiable(radii)
         return color, radii, allmap
 
@@ -142,6 +176,9 @@ class _RasterizeViews(torch.autograd.Function):
         means3D, opacities, colors, scales, rotations, vm, pm, bg, color, allmap, radii = ctx.saved_tensors
         n, v, h, w, mod = ctx.geom
         ws, dev = ctx.ws, means3D.device
+        if ws.generation != ctx.ws_generation:
+            raise RuntimeError("the rasterizer workspace of this forward has been handed to a later forward: a second backward "
+                               "through the same graph (retain_graph=True) is not supported")
         g_color = torch.zeros_like(color) if g_color is None else g_color.detach().float().contiguous()
         g_allmap = torch.zeros_like(allmap) if g_allmap is None else g_allmap.detach().float().contiguous()
         L = _lib.lib()
@@ -150,7 +187,7 @@ class _RasterizeViews(torch.autograd.Function):
         fwd = _lib.GaSurfelForwardArgs(
             n, v, h, w, mod, 0, means3D.data_ptr(), opacities.data_ptr(), colors.data_ptr(), scales.data_ptr(),
             rotations.data_ptr(), vm.data_ptr(), pm.data_ptr(), bg.data_ptr(), color.data_ptr(), allmap.data_ptr(),
-            radii.data_ptr(), ws.ptr, ws.layout.total_bytes, ws.capacity, None)
+            radii.data_ptr(), ws.ptr, ws.layout.total_bytes, ws.capacity, None, ws.seg_capacity)
         nbytes = int(L.ga_surfel_backward_scratch_bytes(ctypes.byref(fwd)))
         if nbytes == 0:
             raise RuntimeError("ga_surfel_backward_scratch_bytes: bad shape")
@@ -160,6 +197,9 @@ class _RasterizeViews(torch.autograd.Function):
         with torch.cuda.device(dev):
             stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             _lib.check(L.ga_surfel_backward(ctypes.byref(args), stream), "ga_surfel_backward")
+        pool = _autograd_pool.setdefault((str(dev), n, v, h, w), [])   # stream order protects the reuse by a later forward
+        if len(pool) < 2:
+            pool.append(ws)
         return d_means, d_op, d_col, d_sc, d_rot, None, None, None, None, None, None
 
 
@@ -240,19 +280,17 @@ def _rasterize_views_nograd(means3D, opacities, colors_precomp, scales, rotation
                 n, v, h, w, float(scale_modifier), 0, means3D.data_ptr(), opacities.data_ptr(), colors.data_ptr(),
                 scales.data_ptr(), rotations.data_ptr(), vm.data_ptr(), pm.data_ptr(), bg.data_ptr(),
                 color.data_ptr(), allmap.data_ptr(), radii.data_ptr(), ws.ptr, ws.layout.total_bytes, ws.capacity,
-                stage_events)
+                stage_events, ws.seg_capacity)
             _lib.check(L.ga_surfel_forward(ctypes.byref(args), ctypes.c_void_p(stream)), "ga_surfel_forward")
             if not check_overflow:
                 break
             st = ws.status().cpu()
             if int(st[_lib.GA_STATUS_OVERFLOW]) == 0:
                 break
-            need = int(st[_lib.GA_STATUS_NUM_RENDERED])
-            if need > 0xFFFFFFFF:
-                raise RuntimeError(f"{need} binned entries exceed the 2^32 limit of the tile ranges")
             if workspace is not None:
-                raise RuntimeError(f"workspace capacity {ws.capacity} < {need} binned entries")
-            ws = _get_workspace(device, n, v, h, w, min_capacity=need + need // 4)
+                raise RuntimeError(f"workspace capacity {ws.capacity} / {ws.seg_items} segment work items < "
+                                   f"{int(st[_lib.GA_STATUS_NUM_RENDERED])} binned entries / {int(st[_lib.GA_STATUS_SEG_WORK])} work items")
+            ws = _get_workspace(device, n, v, h, w, replacement=ws.grown(st))
     return color, radii, allmap, ws
 
 
@@ -314,7 +352,7 @@ class SurfelForwardPlan:
         self.color = torch.empty((v, 3, self.h, self.w), dtype=torch.float32, device=device)
         self.allmap = torch.empty((v, 7, self.h, self.w), dtype=torch.float32, device=device)
         self.radii = torch.empty((v, n), dtype=torch.int32, device=device)
-        self.ws = SurfelWorkspace(device, n, v, self.h, self.w, capacity or max(4 * n * v, 1 << 16))
+        self.ws = SurfelWorkspace(device, n, v, self.h, self.w, capacity or default_capacity(n, v))
         self._L = _lib.lib()
         self._bind(None)
 
@@ -324,7 +362,8 @@ class SurfelForwardPlan:
             self.n, self.v, self.h, self.w, self.scale_modifier, self.flags, self.means3D.data_ptr(),
             self.opacities.data_ptr(), self.colors.data_ptr(), self.scales.data_ptr(), self.rotations.data_ptr(),
             self.vm.data_ptr(), self.pm.data_ptr(), self.bg.data_ptr(), self.color.data_ptr(),
-            self.allmap.data_ptr(), self.radii.data_ptr(), ws.ptr, ws.layout.total_bytes, ws.capacity, stage_events)
+            self.allmap.data_ptr(), self.radii.data_ptr(), ws.ptr, ws.layout.total_bytes, ws.capacity, stage_events,
+            ws.seg_capacity)
         self._argp = ctypes.byref(self._args)
 
     def set_stage_events(self, stage_events):
@@ -340,7 +379,6 @@ class SurfelForwardPlan:
             st = self.ws.status().cpu()
             if int(st[_lib.GA_STATUS_OVERFLOW]) == 0:
                 return int(st[_lib.GA_STATUS_NUM_RENDERED])
-            need = int(st[_lib.GA_STATUS_NUM_RENDERED])
-            self.ws = SurfelWorkspace(self.device, self.n, self.v, self.h, self.w, need + need // 4)
+            self.ws = self.ws.grown(st)
             self._bind(None)
             self.run()

@@ -36,7 +36,7 @@ extern "C" {
 
 /* status words written by the device (int64 each) */
 #define GA_STATUS_NUM_RENDERED 0   /* D = sum over views of tiles touched (upstream `num_rendered`) */
-#define GA_STATUS_OVERFLOW 1       /* 1 if D > capacity: outputs are then NOT written; retry with more capacity */
+#define GA_STATUS_OVERFLOW 1       /* 1 if D > capacity or SEG_WORK > seg_capacity: outputs are then NOT written; retry with more */
 #define GA_STATUS_MAX_TILE 2       /* longest per-tile list (diagnostic)                           */
 #define GA_STATUS_EXTRA_RUNS 3     /* number of entries of run_table (internal)                    */
 #define GA_STATUS_BLEND_ITERS 4   /* with GA_SURFEL_FLAG_STATS: total inner-loop iterations of the blend (all waves) */
@@ -59,7 +59,7 @@ typedef struct GaSurfelForwardArgs {
     const float *opacities;  /* [N] (reference passes [N,1])                                      */
     const float *colors;     /* [N,3] colors_precomp (sh_degree 0 path; shs unsupported as in the reference call) */
     const float *scales;     /* [N,2]                                                             */
-    const float *rotations;  /* [N,4] quaternion (w,x,y,z), used as given (normalised by the caller) */
+    const float *rotations;  /* [N,4] quaternion (w,x,y,z); re-normalised on the device (1 / sqrt) */
     const float *viewmatrix; /* [V,16]                                                            */
     const float *projmatrix; /* [V,16] full view-projection                                       */
     const float *bg;         /* [3]                                                               */
@@ -72,6 +72,11 @@ typedef struct GaSurfelForwardArgs {
     void **stage_events;     /* host, optional (NULL = none): GA_SURFEL_STAGE_EVENTS hipEvent_t handles recorded on
                                 `stream` at the stage boundaries: [0] start, [1] after preprocess, [2] after tile scan +
                                 fill, [3] after per-tile sort, [4] after blend.  Measurement only.          */
+    int64_t seg_capacity;    /* (tile, segment) work items the exchange scratch of the segmented blend holds (lists of 2048
+                                entries or more are blended in 256..512-entry segments by several workgroups); 0 = default
+                                capacity / 2048 + 128.  The worst case is capacity / 256.  More work items than this is
+                                reported like D > capacity: GA_STATUS_OVERFLOW, nothing rendered, the number needed in
+                                GA_STATUS_SEG_WORK.  Same value as passed to ga_surfel_workspace_layout2.       */
 } GaSurfelForwardArgs;
 
 #define GA_SURFEL_STAGE_EVENTS 5
@@ -95,8 +100,10 @@ typedef struct GaSurfelWorkspaceLayout {
     size_t record;      /* float[V*N*GA_SURFEL_RECORD_FLOATS] blend-ready splat records           */
     size_t keys;        /* uint64[capacity]  (depth bits << 32 | gaussian index), binned per tile */
     size_t point_list;  /* uint32[capacity]  gaussian indices, per tile in (depth, index) order   */
-    size_t seg_table;   /* uint32[2*40]      per length class: first tile_order slot, first segment work item */
-    size_t seg_scratch; /* uint64[(capacity/256+1) * 15 * 256] per segment: transmittance + 14 partial sums per pixel,
+    size_t seg_table;   /* uint32[128]       per length class: first tile_order slot, first segment work item (2 x 40 words);
+                           word 96: launch epoch of the exchange words, bumped by the tile scan (never cleared; any initial
+                           value) */
+    size_t seg_scratch; /* uint64[seg_capacity * 15 * 256] per segment: transmittance + 14 partial sums per pixel,
                            each word (value, launch epoch) */
     size_t total_bytes;
 } GaSurfelWorkspaceLayout;
@@ -107,6 +114,10 @@ typedef struct GaSurfelWorkspaceLayout {
 /* host: fills `out` for the given problem size; returns GA_OK or GA_ERR_BAD_SHAPE */
 int ga_surfel_workspace_layout(int32_t num_points, int32_t num_views, int32_t image_height, int32_t image_width,
                                int64_t capacity, GaSurfelWorkspaceLayout *out);
+
+/* as above with an explicit seg_capacity (0 = the default of ga_surfel_workspace_layout) */
+int ga_surfel_workspace_layout2(int32_t num_points, int32_t num_views, int32_t image_height, int32_t image_width,
+                                int64_t capacity, int64_t seg_capacity, GaSurfelWorkspaceLayout *out);
 
 /* host: enqueue the whole forward (preprocess, tile binning, per-tile depth sort, blend) on `stream`
  * (a hipStream_t passed as void* so that this header needs no HIP include). */

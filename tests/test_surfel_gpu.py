@@ -172,6 +172,80 @@ def test_segmented_blend_of_very_long_lists_beside_short_ones(gpu_device):
     assert torch.equal(a1[0], a2[0]) and torch.equal(a1[2], a2[2])
 
 
+def _long_list_scene(seed, n=9000, spread=0.04, lo=0.004, hi=0.024):
+    g = synthetic.random_surfels(n, seed=seed)[0].clone()
+    g[:, 0:3] *= spread
+    g[:, 3] = lo + (hi - lo) * torch.rand(n, generator=torch.Generator().manual_seed(seed + 100))
+    return g
+
+
+def test_graph_replay_of_the_segmented_blend_on_changing_inputs(gpu_device):
+    """SurfelForwardPlan.run() captured in a HIP graph and replayed on DIFFERENT Gaussian sets with lists >= 2048 entries: the
+    cross-workgroup exchange words of the segmented blend carry the launch epoch, which has to advance per REPLAY (it is a device
+    word the tile scan bumps; a host counter passed as a kernel argument would be frozen in the graph and the words of the
+    previous replay would validate).  Every replay is held to the oracle on its own inputs."""
+    from gaussiananything_amd.diff_surfel_rasterization import SurfelForwardPlan
+    cams = synthetic.eval_cameras(8)
+    views, H, W = [0, 3], 96, 96
+    scenes = [_long_list_scene(31), _long_list_scene(32, spread=0.05, lo=0.01, hi=0.05), _long_list_scene(33, lo=0.3, hi=1.0),
+              _long_list_scene(31)]
+    m, o, sc, r, c = [t.to(gpu_device) for t in synthetic.split_gaussians(scenes[0])]
+    plan = SurfelForwardPlan(m, o, c, sc, r, cams["cam_view"][views].to(gpu_device), cams["cam_view_proj"][views].to(gpu_device),
+                             torch.ones(3, device=gpu_device), H, W)
+    plan.run()
+    assert plan.ensure_capacity() > 0
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=gpu_device)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        plan.run()          # warm-up on the capture stream
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            plan.run()
+    torch.cuda.synchronize()
+    for k, g in enumerate(scenes):
+        mm, oo, ss, rr, cc = synthetic.split_gaussians(g)
+        plan.means3D.copy_(mm.to(gpu_device)); plan.opacities.copy_(oo.to(gpu_device).reshape(-1)); plan.colors.copy_(cc.to(gpu_device))
+        plan.scales.copy_(ss.to(gpu_device)); plan.rotations.copy_(rr.to(gpu_device))
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        st = plan.ws.status().cpu()
+        assert int(st[1]) == 0 and int(st[2]) >= 2048, (k, st[:3])
+        color, allmap = plan.color.cpu().numpy(), plan.allmap.cpu().numpy()
+        for j, v in enumerate(views):
+            ref = _util.oracle_view(g, cams, v, H, W)
+            assert float(np.mean((color[j] - ref["color"]) ** 2)) <= MSE_TOL, (k, v)
+            for ch in range(7):
+                assert float(np.mean((allmap[j, ch] - ref["allmap"][ch]) ** 2)) <= MSE_TOL, (k, v, ch)
+
+
+def test_segment_scratch_overflow_is_reported_and_regrown(gpu_device):
+    """The exchange scratch of the segmented blend is sized for seg_capacity work items, not for the worst case: a launch that
+    needs more reports an overflow (nothing rendered, the number needed in the status words) and the host re-sizes."""
+    from gaussiananything_amd import _lib
+    from gaussiananything_amd.diff_surfel_rasterization import SurfelWorkspace, rasterize_views
+    cams = synthetic.eval_cameras(8)
+    g = _long_list_scene(41, n=12000)
+    H = W = 96
+    m, o, sc, r, c = [t.to(gpu_device) for t in synthetic.split_gaussians(g)]
+    vm, pm = cams["cam_view"][[0, 2]].to(gpu_device), cams["cam_view_proj"][[0, 2]].to(gpu_device)
+    small = SurfelWorkspace(gpu_device, g.shape[0], 2, H, W, 1 << 18, seg_capacity=2)
+    bg = torch.ones(3, device=gpu_device)
+    with pytest.raises(RuntimeError, match="segment work items"):
+        rasterize_views(m, o, c, sc, r, vm, pm, bg, H, W, workspace=small)
+    st = small.status().cpu()
+    assert int(st[_lib.GA_STATUS_OVERFLOW]) == 1 and int(st[_lib.GA_STATUS_SEG_WORK]) > 2
+    assert int(st[_lib.GA_STATUS_NUM_RENDERED]) <= small.capacity      # the lists themselves fit
+    big = small.grown(st)
+    assert big.seg_items >= int(st[_lib.GA_STATUS_SEG_WORK]) and big.capacity == small.capacity
+    color, radii, allmap, _ = rasterize_views(m, o, c, sc, r, vm, pm, bg, H, W, workspace=big)
+    ref_color, _, ref_allmap, _ = rasterize_views(m, o, c, sc, r, vm, pm, bg, H, W)   # cached default workspace
+    assert torch.equal(color, ref_color) and torch.equal(allmap, ref_allmap)
+    ref = _util.oracle_view(g, cams, 0, H, W)
+    assert float(np.mean((color[0].cpu().numpy() - ref["color"]) ** 2)) <= MSE_TOL
+
+
 def test_degenerate_inputs(gpu_device):
     """behind-camera, zero-scale, zero / tiny opacity, duplicate depths (tie-break by index), edge-on splats."""
     cams = synthetic.eval_cameras(8)
