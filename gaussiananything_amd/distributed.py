@@ -51,23 +51,23 @@ def cascade_per_rank(stage1, stage2, decoder, cond_fn, cameras, num_samples, bas
     """BASELINE configs[4]: ``num_samples`` independent cascaded samples sharded over the ranks (``shard_samples``), every
     rank running ``cascade.cascade`` for its own seeds with NO data-path collective; the rendered multi-view RGB-D-N of the
     finest level is collected on rank 0 with ONE gather per owned sample round.  ``cond_fn(sample_index) -> (cond, uc)``.
-    Returns (gathered [world, V, 9, H, W] on rank 0 else None, list of this rank's sample indices)."""
+    ``num_samples`` must be a multiple of the world size.  Returns (gathered [num_samples, V, 9, H, W] in sample order on rank 0
+    else None, list of this rank's sample indices)."""
     from . import cascade as _cascade
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
+    if num_samples <= 0 or num_samples % world != 0:
+        # checked on EVERY rank before any work: a rank that ran out of samples would otherwise leave the others waiting in
+        # the gather of the last round
+        raise ValueError(f"num_samples ({num_samples}) must be a positive multiple of the world size ({world})")
     mine = shard_samples(num_samples, rank, world)
-    rounds = (num_samples + world - 1) // world
-    gathered = None
-    for r in range(rounds):
-        payload = None
-        if r < len(mine):
-            cond, uc = cond_fn(mine[r])
-            out = _cascade.cascade(stage1, stage2, decoder, cond, uc, cameras=cameras, seed=base_seed + mine[r],
-                                   **cascade_kwargs)
-            payload = pack_render(out["renders"][level])
-        if payload is None:   # fewer samples than ranks in the last round: an empty contribution keeps the gather collective
-            raise ValueError("num_samples must be a multiple of the world size")
-        gathered = gather_to_rank0(payload)
+    rounds = []
+    for idx in mine:   # every rank owns num_samples / world samples: one gather per round, all rounds returned
+        cond, uc = cond_fn(idx)
+        out = _cascade.cascade(stage1, stage2, decoder, cond, uc, cameras=cameras, seed=base_seed + idx, **cascade_kwargs)
+        rounds.append(gather_to_rank0(pack_render(out["renders"][level])))
+    # rank 0: [world, rounds, V, 9, H, W] -> sample order (rank r owns the contiguous block r * rounds .. )
+    gathered = torch.stack(rounds, dim=1).flatten(0, 1) if rounds[0] is not None else None
     return gathered, mine
 
 

@@ -29,7 +29,8 @@ class ode:
         owner, name = getattr(model, "__self__", None), getattr(model, "__name__", "")
         if (self.sampler_type == "euler" and self.plain_velocity_drift and device.type == "cuda" and len(self.t) > 4
                 and name in ("forward_with_cfg", "forward_cond") and hasattr(owner, "sample_euler_fused")
-                and set(model_kwargs) <= {"context", "cfg_scale"} and os.environ.get("GA_ODE_GRAPH", "1") != "0"):
+                and "context" in model_kwargs and set(model_kwargs) <= {"context", "cfg_scale"}
+                and os.environ.get("GA_ODE_GRAPH", "1") != "0"):
             out = owner.sample_euler_fused(x, self.t.tolist(), model_kwargs["context"],
                                            cfg_scale=model_kwargs.get("cfg_scale", 1.0), cfg=(name == "forward_with_cfg"))
             self.last_stats = {"nfe": len(self.t) - 1, "steps": len(self.t) - 1, "rejected": 0, "graph": True, "fused": True}

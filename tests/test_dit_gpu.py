@@ -3,7 +3,8 @@
 
 Tolerances (bf16 MFMA inputs, fp32 accumulation, fp32 residual stream; the reference itself runs under bf16 autocast):
   per-op      : relative L2 error <= 1e-2 against an fp32 reference fed the same bf16-rounded inputs
-  whole model : relative L2 error <= 3e-2 against the reference's fp32 output, max abs error <= 5e-2 * max|y|
+  whole model : relative L2 error <= 1.5e-2 against the reference's fp32 output (3e-2 behind classifier-free guidance, which
+                amplifies the difference by its scale; measured 5e-3 .. 6e-3), max abs error <= 5e-2 * max|y|
 """
 import math
 import os
@@ -232,9 +233,9 @@ def test_model_matches_reference_golden(gpu_device, stage):
     assert y.dtype == torch.float32 and y.shape == z["y"].shape
     assert torch.equal(y, y2)
     ref = z["y"].to(gpu_device)
-    assert rel_l2(y, ref) < 3e-2, rel_l2(y, ref)
+    assert rel_l2(y, ref) < 1.5e-2, rel_l2(y, ref)
     assert float((y - ref).abs().max()) < 5e-2 * float(ref.abs().max())
-    assert rel_l2(ycfg, z["y_cfg"].to(gpu_device)) < 6e-2        # CFG amplifies the difference by the guidance scale
+    assert rel_l2(ycfg, z["y_cfg"].to(gpu_device)) < 3e-2        # CFG amplifies the difference by the guidance scale
 
 
 def test_zero_context_items_skip_cross_attention_exactly(gpu_device):
@@ -283,7 +284,7 @@ def test_model_release_shape_against_oracle(gpu_device):
     model.to(gpu_device)
     with torch.no_grad():
         y = model(x.to(gpu_device), t.to(gpu_device), {k: v.to(gpu_device) for k, v in ctx.items()})
-    assert rel_l2(y.cpu(), ref) < 3e-2, rel_l2(y.cpu(), ref)
+    assert rel_l2(y.cpu(), ref) < 1.5e-2, rel_l2(y.cpu(), ref)
 
 
 @pytest.mark.parametrize("arch,C", [("DiT-PixArt-PCD-CLAY-L", 3), ("DiT-PixArt-PCD-CLAY-stage2-L", 10)])
@@ -321,8 +322,8 @@ def test_release_models_full_depth_against_oracle(gpu_device, arch, C):
     with torch.no_grad():
         y = model(x.to(gpu_device), t.to(gpu_device), dctx)
         ycfg = model.forward_with_cfg(x.to(gpu_device), t.to(gpu_device), dctx, 4.0)
-    assert rel_l2(y.cpu(), ref) < 3e-2, rel_l2(y.cpu(), ref)
-    assert rel_l2(ycfg.cpu(), ref_cfg) < 6e-2, rel_l2(ycfg.cpu(), ref_cfg)
+    assert rel_l2(y.cpu(), ref) < 1.5e-2, rel_l2(y.cpu(), ref)
+    assert rel_l2(ycfg.cpu(), ref_cfg) < 3e-2, rel_l2(ycfg.cpu(), ref_cfg)
 
 
 def test_dopri5_on_the_golden_model_against_the_ode_oracle(gpu_device):

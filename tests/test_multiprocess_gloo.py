@@ -48,10 +48,23 @@ def _cascade_per_rank_with_stand_ins(gd, rank, world):
                                          sampling_method="euler")
     if mine != [rank]:
         return False
+    # two samples per rank: both rounds come back, in sample order (rank r owns samples 2r, 2r + 1), and a sample's render does
+    # not depend on how the samples were sharded (sample `rank` of the one-per-rank run was seeded 7 + rank as well)
+    g2, mine2 = gd.cascade_per_rank(Den(3), Den(10), Dec(), cond_fn, {"tanfov": 0.36}, 2 * world, base_seed=7, num_steps=4,
+                                    sampling_method="euler")
+    if mine2 != [2 * rank, 2 * rank + 1]:
+        return False
+    try:   # not a multiple of the world size: every rank refuses BEFORE any collective (nobody is left waiting in a gather)
+        gd.cascade_per_rank(Den(3), Den(10), Dec(), cond_fn, {"tanfov": 0.36}, world + 1, base_seed=7, num_steps=4)
+        return False
+    except ValueError:
+        pass
     if rank != 0:
-        return gathered is None
+        return gathered is None and g2 is None
     # every rank's payload arrived, and they differ (own seed, own conditioning)
-    return tuple(gathered.shape) == (world, 2, 9, 4, 4) and float((gathered[0] - gathered[1]).abs().max()) > 0
+    ok = tuple(gathered.shape) == (world, 2, 9, 4, 4) and float((gathered[0] - gathered[1]).abs().max()) > 0
+    ok = ok and tuple(g2.shape) == (2 * world, 2, 9, 4, 4) and all(torch.equal(g2[i], gathered[i]) for i in range(world))
+    return ok and len({float(g2[i].sum()) for i in range(2 * world)}) == 2 * world
 
 
 def _worker(rank, world, port, q):
