@@ -692,6 +692,8 @@ def main():
             # throughput mode: four independent samples batched on the GPU (M = 6144 rows fill the chip; one sample does not)
             out["dit_batched"] = bench_dit(dev, "DiT-PixArt-PCD-CLAY-L", a.dit_nfe, 3, samples=4)
             out["attention"] = bench_attention(dev)
+            from tools.gemm_yardstick import yardstick   # same-run, same-node: torch.matmul beside ga_gemm_bf16 (tools only)
+            out["gemm_yardstick"] = yardstick(dev)
             out["decode"] = bench_decode(dev, cams)
             out["conditioner"] = bench_conditioner(dev)
         if world == 1 and not a.no_extras and not a.no_dit:   # (--no-dit is the quick rasterizer-only mode of the tools)
