@@ -99,7 +99,10 @@ int ga_surfel_forward(const GaSurfelForwardArgs *a, void *stream_v)
     // (event 0 is recorded after this memset so that it brackets kernels only)
     // status words, segment flags / counters and tile counters are contiguous at the head of the workspace: one memset
     // node clears them all
-    if (hipMemsetAsync(w + L.status, 0, L.tile_start - L.status, s) != hipSuccess) return GA_ERR_LAUNCH;
+    // -- unless the caller vouches that the previous forward on this workspace left them clean (the tile scan clears what it and
+    // the blend accumulate into at its end)
+    if (!(a->flags & GA_SURFEL_FLAG_WORKSPACE_CLEAN) && hipMemsetAsync(w + L.status, 0, L.tile_start - L.status, s) != hipSuccess)
+        return GA_ERR_LAUNCH;
     auto mark = [&](int k) {
         if (a->stage_events && a->stage_events[k]) (void)hipEventRecord(static_cast<hipEvent_t>(a->stage_events[k]), s);
     };

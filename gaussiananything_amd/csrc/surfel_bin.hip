@@ -36,7 +36,8 @@ constexpr int kScanPer = 8;         // counters per thread and chunk
 constexpr int kClasses = 33;
 constexpr int kBigStash = 1024;     // (tile, count) of the lists longer than one sort run kept in LDS for the run table
 
-__global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(const uint32_t *__restrict__ tile_count,
+__global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(uint32_t *__restrict__ tile_count,
+                                                                uint32_t *__restrict__ seg_sync, uint32_t seg_sync_words,
                                                                 uint32_t *__restrict__ tile_start,
                                                                 uint32_t *__restrict__ tile_cursor,
                                                                 uint4 *__restrict__ tile_order,
@@ -252,6 +253,12 @@ __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(const uint32_t *
         __syncthreads();
     }
     if (tid == 0) status[GA_STATUS_EXTRA_RUNS] = (int64_t)min(carry_s, table_cap);
+    // Leave the accumulating words of the workspace head clean for the NEXT launch (the tile counters this kernel has consumed;
+    // the arrival / saturation words, ticket and statistics words the blend of THIS launch starts from): a caller that passes
+    // GA_SURFEL_FLAG_WORKSPACE_CLEAN then needs no clearing memset in front of the next forward (4.7 us + a launch boundary).
+    for (int i = tid; i < n; i += 1024) tile_count[i] = 0u;
+    for (uint32_t i = tid; i < seg_sync_words; i += 1024) seg_sync[i] = 0u;
+    if (tid >= 4 && tid < GA_STATUS_WORDS && tid != GA_STATUS_LONG_TILES && tid != GA_STATUS_SEG_WORK) status[tid] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -582,7 +589,8 @@ __global__ __launch_bounds__(256) void surfel_run_merge_kernel(const uint4 *__re
 void launch_binning(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &ws, hipStream_t s)
 {
     const int nt = d.V * d.tiles;
-    hipLaunchKernelGGL(surfel_tile_scan_kernel, dim3(1), dim3(1024), 0, s, ws.tile_count, ws.tile_start,
+    hipLaunchKernelGGL(surfel_tile_scan_kernel, dim3(1), dim3(1024), 0, s, ws.tile_count, ws.seg_sync,
+                       (uint32_t)(8 * ((size_t)a.capacity / 1024 + 1)), ws.tile_start,
                        ws.tile_cursor, ws.tile_order, ws.run_table, nt, a.capacity, seg_items(a.capacity, a.seg_capacity), ws.seg_table, ws.status);
     const dim3 grid((unsigned)((d.N + 256 * kBinSplats - 1) / (256 * kBinSplats)), (unsigned)d.V);
     if (d.tiles <= kLdsTiles)

@@ -73,6 +73,10 @@ class SurfelWorkspace:
     def status(self):
         return self.section("status", torch.int64, _lib.GA_STATUS_WORDS)
 
+    def clean_flag(self):
+        """GA_SURFEL_FLAG_WORKSPACE_CLEAN once a forward has been enqueued on this workspace (include/ga_surfel.h)."""
+        return _lib.GA_SURFEL_FLAG_WORKSPACE_CLEAN if getattr(self, "clean", False) else 0
+
     def grown(self, st):
         """A replacement workspace for the counts an overflowed launch reported in its status words ``st`` (host tensor)."""
         need, seg_need = int(st[_lib.GA_STATUS_NUM_RENDERED]), int(st[_lib.GA_STATUS_SEG_WORK])
@@ -277,11 +281,12 @@ def _rasterize_views_nograd(means3D, opacities, colors_precomp, scales, rotation
     with torch.cuda.device(device):
         while True:
             args = _lib.GaSurfelForwardArgs(
-                n, v, h, w, float(scale_modifier), 0, means3D.data_ptr(), opacities.data_ptr(), colors.data_ptr(),
+                n, v, h, w, float(scale_modifier), ws.clean_flag(), means3D.data_ptr(), opacities.data_ptr(), colors.data_ptr(),
                 scales.data_ptr(), rotations.data_ptr(), vm.data_ptr(), pm.data_ptr(), bg.data_ptr(),
                 color.data_ptr(), allmap.data_ptr(), radii.data_ptr(), ws.ptr, ws.layout.total_bytes, ws.capacity,
                 stage_events, ws.seg_capacity)
             _lib.check(L.ga_surfel_forward(ctypes.byref(args), ctypes.c_void_p(stream)), "ga_surfel_forward")
+            ws.clean = True      # its tile scan leaves the workspace head ready for the next forward
             if not check_overflow:
                 break
             st = ws.status().cpu()
@@ -359,7 +364,7 @@ class SurfelForwardPlan:
     def _bind(self, stage_events):
         ws = self.ws
         self._args = _lib.GaSurfelForwardArgs(
-            self.n, self.v, self.h, self.w, self.scale_modifier, self.flags, self.means3D.data_ptr(),
+            self.n, self.v, self.h, self.w, self.scale_modifier, self.flags | ws.clean_flag(), self.means3D.data_ptr(),
             self.opacities.data_ptr(), self.colors.data_ptr(), self.scales.data_ptr(), self.rotations.data_ptr(),
             self.vm.data_ptr(), self.pm.data_ptr(), self.bg.data_ptr(), self.color.data_ptr(),
             self.allmap.data_ptr(), self.radii.data_ptr(), ws.ptr, ws.layout.total_bytes, ws.capacity, stage_events,
@@ -372,6 +377,9 @@ class SurfelForwardPlan:
     def run(self):
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self._L.ga_surfel_forward(self._argp, ctypes.c_void_p(stream)), "ga_surfel_forward")
+        if not self.ws.clean_flag():     # from the second forward on the clearing memset is not needed any more
+            self.ws.clean = True
+            self._args.flags = self.flags | _lib.GA_SURFEL_FLAG_WORKSPACE_CLEAN
 
     def ensure_capacity(self):
         """One synchronising check (call once after the first run): grow the workspace and re-run on overflow."""

@@ -83,6 +83,10 @@ typedef struct GaSurfelForwardArgs {
 
 #define GA_SURFEL_FLAG_NONE 0
 #define GA_SURFEL_FLAG_STATS 1      /* collect the GA_STATUS_BLEND_* diagnostics (costs three atomics per wave) */
+#define GA_SURFEL_FLAG_WORKSPACE_CLEAN 2 /* the LAST use of this workspace was a ga_surfel_forward with the same sizes that has been
+                                       enqueued completely (it returned GA_OK): its tile scan left the accumulating words of the
+                                       workspace head zeroed, so the clearing memset in front of this forward is skipped.  Never
+                                       set it for the first forward on a workspace (or after writing to it) */
 
 /* Byte offsets of the workspace sections (all 256-byte aligned).  Tests read the integer artefacts
  * (rect, tile ranges, sorted point list) straight out of the workspace through these offsets. */
