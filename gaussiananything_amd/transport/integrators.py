@@ -8,6 +8,43 @@ import torch as th
 from .odeint import odeint
 
 
+class sde:
+    """SDE solver class (/root/reference/transport/integrators.py:8-81): fixed grid linspace(t0, t1, num_steps), one Wiener
+    increment dW ~ N(0, dt) per step drawn on the host generator and moved to the state's device / dtype (the reference's
+    ``th.randn(x.size()).to(x)``, so that a seeded run reproduces the reference's noise sequence)."""
+
+    def __init__(self, drift, diffusion, *, t0, t1, num_steps, sampler_type):
+        assert t0 < t1, "SDE sampler has to be in forward time"
+        self.num_timesteps = num_steps
+        self.t = th.linspace(t0, t1, num_steps)
+        self.dt = self.t[1] - self.t[0]
+        self.drift = drift
+        self.diffusion = diffusion
+        if sampler_type not in ("Euler", "Heun"):
+            raise NotImplementedError("Smapler type not implemented.")
+        self.sampler_type = sampler_type
+
+    def _step(self, x, t, model, **model_kwargs):
+        dw = th.randn(x.size()).to(x) * th.sqrt(self.dt)
+        tv = th.ones(x.size(0)).to(x) * t
+        amp = lambda d: th.sqrt(2 * th.as_tensor(d, dtype=x.dtype, device=x.device))   # noqa: E731  ("constant" form: a float)
+        if self.sampler_type == "Euler":     # Euler-Maruyama
+            mean = x + self.drift(x, tv, model, **model_kwargs) * self.dt
+            return mean + amp(self.diffusion(x, tv)) * dw
+        xhat = x + amp(self.diffusion(x, tv)) * dw    # stochastic Heun: perturb, then a trapezoidal drift step
+        k1 = self.drift(xhat, tv, model, **model_kwargs)
+        k2 = self.drift(xhat + self.dt * k1, tv + self.dt, model, **model_kwargs)
+        return xhat + 0.5 * self.dt * (k1 + k2)
+
+    def sample(self, init, model, **model_kwargs):
+        x, samples = init, []
+        for ti in self.t[:-1]:
+            with th.no_grad():
+                x = self._step(x, ti, model, **model_kwargs)
+                samples.append(x)
+        return samples
+
+
 class ode:
     """ODE solver class"""
 

@@ -1,14 +1,16 @@
-"""``Transport`` / ``Sampler`` / ``create_transport`` with the reference's surface for the probability-flow ODE path
-(/root/reference/transport/transport.py:45-112, 193-242, 322-431 and transport/__init__.py:4-72).  The released models are
-velocity predictors on the GVP path (sgm/configs/stage2-i23d.yaml), for which the drift is the model output itself and the
-integration interval is [0, 1]; score / noise parametrisations and the SDE samplers are outside this tier and raise."""
+"""``Transport`` / ``Sampler`` / ``create_transport`` with the reference's surface (/root/reference/transport/transport.py:45-112,
+193-242, 255-431 and transport/__init__.py:4-72).  The released models are velocity predictors on the GVP path
+(sgm/configs/stage2-i23d.yaml), for which the drift is the model output itself and the integration interval is [0, 1] -- the path
+the HIP denoiser's fused sampler step serves; the score / noise parametrisations and the SDE samplers (Euler-Maruyama, Heun; last
+step Mean / Tweedie / Euler) are host arithmetic around the same model call."""
 from __future__ import annotations
 
 import enum
 
 import torch as th
 
-from .integrators import ode
+from . import path
+from .integrators import ode, sde
 
 
 class ModelType(enum.Enum):
@@ -42,6 +44,7 @@ class Transport:
         self.train_eps = train_eps
         self.sample_eps = sample_eps
         self.snr_type = snr_type
+        self.path_sampler = {PathType.LINEAR: path.ICPlan, PathType.GVP: path.GVPCPlan, PathType.VP: path.VPCPlan}[path_type]()
 
     def check_interval(self, train_eps, sample_eps, *, diffusion_form="SBDM", sde=False, reverse=False, eval=False,
                        last_step_size=0.0):
@@ -57,15 +60,37 @@ class Transport:
         return t0, t1
 
     def get_drift(self):
-        if self.model_type != ModelType.VELOCITY:
-            raise NotImplementedError("only velocity-prediction models are on the GaussianAnything sampling path")
+        """drift of the probability-flow ODE for the model's parametrisation: the output itself for a velocity model,
+        -f + w * score for a score model, the same with score = -noise / sigma for a noise model"""
+        plan = self.path_sampler
+
+        def from_score(x, t, score):
+            mean, var = plan.compute_drift(x, t)
+            return var * score - mean
+
+        if self.model_type == ModelType.VELOCITY:
+            drift_fn = lambda x, t, model, **kw: model(x, t, **kw)                                                   # noqa: E731
+        elif self.model_type == ModelType.SCORE:
+            drift_fn = lambda x, t, model, **kw: from_score(x, t, model(x, t, **kw))                                 # noqa: E731
+        else:
+            drift_fn = lambda x, t, model, **kw: from_score(                                                         # noqa: E731
+                x, t, model(x, t, **kw) / -plan.compute_sigma_t(path.expand_t_like_x(t, x))[0])
 
         def body_fn(x, t, model, **model_kwargs):
-            model_output = model(x, t, **model_kwargs)
+            model_output = drift_fn(x, t, model, **model_kwargs)
             assert model_output.shape == x.shape, "Output shape from ODE solver must match input shape"
             return model_output
 
         return body_fn
+
+    def get_score(self):
+        """score of x_t = alpha_t x + sigma_t eps from the model output"""
+        plan = self.path_sampler
+        if self.model_type == ModelType.NOISE:
+            return lambda x, t, model, **kw: model(x, t, **kw) / -plan.compute_sigma_t(path.expand_t_like_x(t, x))[0]
+        if self.model_type == ModelType.SCORE:
+            return lambda x, t, model, **kw: model(x, t, **kw)
+        return lambda x, t, model, **kw: plan.get_score_from_velocity(model(x, t, **kw), x, t)
 
 
 class Sampler:
@@ -74,6 +99,7 @@ class Sampler:
     def __init__(self, transport, guider_config=None):
         self.transport = transport
         self.drift = self.transport.get_drift()
+        self.score = self.transport.get_score()
 
     def sample_ode(self, *, sampling_method="dopri5", num_steps=50, atol=1e-6, rtol=1e-3, reverse=False, cfg=False):
         """returns ``fn(x, model, **model_kwargs) -> Tensor[num_steps, *x.shape]``; for fixed solvers ``num_steps`` grid
@@ -85,11 +111,49 @@ class Sampler:
         t0, t1 = self.transport.check_interval(self.transport.train_eps, self.transport.sample_eps, sde=False, eval=True,
                                                reverse=reverse, last_step_size=0.0)
         self.last_ode = ode(drift=drift, t0=t0, t1=t1, sampler_type=sampling_method, num_steps=num_steps, atol=atol,
-                            rtol=rtol, plain_velocity_drift=not reverse)
+                            rtol=rtol, plain_velocity_drift=not reverse and self.transport.model_type == ModelType.VELOCITY)
         return self.last_ode.sample
 
-    def sample_sde(self, *a, **k):
-        raise NotImplementedError("SDE sampling is not on the released inference path (sample() uses sample_ode)")
+    def sample_sde(self, *, sampling_method="Euler", diffusion_form="SBDM", diffusion_norm=1.0, last_step="Mean",
+                   last_step_size=0.04, num_steps=250):
+        """returns ``fn(init, model, **model_kwargs) -> list of num_steps states``: num_steps - 1 stochastic steps on
+        linspace(t0, t1, num_steps) plus the closing step (None: repeat, "Mean": one drift step of last_step_size,
+        "Tweedie": denoise with the score, "Euler": one probability-flow step)."""
+        if last_step is None:
+            last_step_size = 0.0
+        plan = self.transport.path_sampler
+
+        def diffusion_fn(x, t):
+            return plan.compute_diffusion(x, t, form=diffusion_form, norm=diffusion_norm)
+
+        def sde_drift(x, t, model, **kw):
+            return self.drift(x, t, model, **kw) + diffusion_fn(x, t) * self.score(x, t, model, **kw)
+
+        t0, t1 = self.transport.check_interval(self.transport.train_eps, self.transport.sample_eps, diffusion_form=diffusion_form,
+                                               sde=True, eval=True, reverse=False, last_step_size=last_step_size)
+        solver = sde(sde_drift, diffusion_fn, t0=t0, t1=t1, num_steps=num_steps, sampler_type=sampling_method)
+
+        if last_step is None:
+            closing = lambda x, t, model, **kw: x                                                                   # noqa: E731
+        elif last_step == "Mean":
+            closing = lambda x, t, model, **kw: x + sde_drift(x, t, model, **kw) * last_step_size                   # noqa: E731
+        elif last_step == "Tweedie":
+            def closing(x, t, model, **kw):
+                a, sg = plan.compute_alpha_t(t)[0][0], plan.compute_sigma_t(t)[0][0]
+                return x / a + (sg ** 2) / a * self.score(x, t, model, **kw)
+        elif last_step == "Euler":
+            closing = lambda x, t, model, **kw: x + self.drift(x, t, model, **kw) * last_step_size                  # noqa: E731
+        else:
+            raise NotImplementedError()
+
+        def _sample(init, model, **model_kwargs):
+            xs = solver.sample(init, model, **model_kwargs)
+            ts = th.ones(init.size(0), device=init.device) * t1
+            xs.append(closing(xs[-1], ts, model, **model_kwargs))
+            assert len(xs) == num_steps, "Samples does not match the number of steps"
+            return xs
+
+        return _sample
 
 
 def create_transport(path_type="Linear", prediction="velocity", loss_weight=None, train_eps=None, sample_eps=None,

@@ -265,6 +265,76 @@ def test_odeint_matches_oracle_and_analytic(method):
         assert s1["nfe"] == len(t) - 1                       # "250 steps" = 249 function evaluations
 
 
+def _reference_transport():
+    """the reference's transport package, imported with the oracle integrator standing in for torchdiffeq"""
+    import types
+    from oracle import ode as oo
+    ref_root = "/root/reference"
+    if not os.path.isdir(ref_root):
+        pytest.skip("reference tree not present (GPU box)")
+
+    def fake_odeint(fn, x, t, method, atol, rtol):
+        return torch.from_numpy(oo.odeint(lambda ts, y: fn(torch.tensor(ts, dtype=torch.float32),
+                                                            torch.from_numpy(y).float()).numpy(),
+                                          x.numpy(), t.numpy(), method=method, atol=atol[0], rtol=rtol[0])).float()
+
+    saved = {k: sys.modules.get(k) for k in ("torchdiffeq", "sgm", "sgm.util", "transport")}
+    sys.modules["torchdiffeq"] = types.SimpleNamespace(odeint=fake_odeint)
+    sys.modules["sgm"] = types.ModuleType("sgm")
+    sys.modules["sgm.util"] = types.SimpleNamespace(instantiate_from_config=lambda *a, **k: None)
+    sys.path.insert(0, ref_root)
+    for k in [k for k in sys.modules if k == "transport" or k.startswith("transport.")]:
+        del sys.modules[k]
+    import transport as ref_transport
+
+    def restore():
+        sys.path.remove(ref_root)
+        for k in [k for k in sys.modules if k == "transport" or k.startswith("transport.")]:
+            del sys.modules[k]
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
+            else:
+                sys.modules.pop(k, None)
+    return ref_transport, restore
+
+
+@pytest.mark.parametrize("path_type", ["Linear", "GVP", "VP"])
+@pytest.mark.parametrize("prediction", ["velocity", "score", "noise"])
+def test_every_parametrisation_and_the_sde_samplers_against_the_reference(path_type, prediction):
+    """score / noise / velocity models on the three interpolants: the probability-flow ODE (euler) and the SDE samplers
+    (Euler-Maruyama, Heun; closing step Mean / Tweedie / Euler / None; SBDM and sigma diffusion) must reproduce the REFERENCE'S
+    own transport/*.py -- same seeded host noise, same arithmetic -- state by state."""
+    from gaussiananything_amd.transport import Sampler, create_transport
+    ref_transport, restore = _reference_transport()
+    try:
+        model = lambda x, t, scale=1.0: torch.tanh(scale * x) * (0.5 + t.view(-1, 1, 1)) - 0.3 * x  # noqa: E731
+        x0 = torch.randn(3, 4, 2, generator=torch.Generator().manual_seed(5))
+        ours_t = create_transport(path_type, prediction, None, None, None, snr_type="uniform")
+        ref_t = ref_transport.create_transport(path_type, prediction, None, None, None, snr_type="uniform")
+        assert (ours_t.train_eps, ours_t.sample_eps) == (ref_t.train_eps, ref_t.sample_eps)
+        ours, ref = Sampler(ours_t), ref_transport.Sampler(ref_t)
+        a = ours.sample_ode(sampling_method="euler", num_steps=9)(x0, model, scale=1.5)
+        b = ref.sample_ode(sampling_method="euler", num_steps=9)(x0, model, scale=1.5)
+        assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+        for method in ("Euler", "Heun"):
+            for last, form in (("Mean", "SBDM"), ("Tweedie", "sigma"), ("Euler", "linear"), (None, "decreasing")):
+                kw = dict(sampling_method=method, diffusion_form=form, diffusion_norm=0.7, last_step=last, last_step_size=0.04, num_steps=8)
+                torch.manual_seed(11)
+                xa = ours.sample_sde(**kw)(x0, model, scale=1.5)
+                torch.manual_seed(11)
+                xb = ref.sample_sde(**kw)(x0, model, scale=1.5)
+                assert len(xa) == len(xb) == 8
+                for k, (u, v) in enumerate(zip(xa, xb)):
+                    assert torch.allclose(u, v, rtol=1e-5, atol=1e-6, equal_nan=True), (method, last, k)   # (SBDM at t0 = 0 is singular in the reference too)
+        # a constant diffusion coefficient (a float; the reference's sqrt() rejects it) works here
+        torch.manual_seed(3)
+        xs = ours.sample_sde(diffusion_form="constant", diffusion_norm=0.1, last_step=None, num_steps=5)(x0, model)
+        assert len(xs) == 5 and all(v.shape == x0.shape for v in xs)
+    finally:
+        restore()
+
+
 def test_transport_surface_and_reference_plumbing():
     """Sampler(create_transport(GVP, velocity)).sample_ode(...) against the REFERENCE'S transport/*.py imported with the
     oracle integrator standing in for torchdiffeq (and a stub for sgm.util): interval, grid and drift must agree."""
