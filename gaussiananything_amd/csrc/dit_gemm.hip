@@ -742,7 +742,7 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
         int ring = 0;
         if (nk % 4 == 0 && nk >= 8) {
             if (wg_big >= 160) ring = 1;
-            else if (!wave64 && wg_mid >= 200) ring = 2;
+            else if (!wave64 && wg_mid >= 160) ring = 2;
             else if (wg_small >= 96) ring = 3;
         }
 #ifdef GA_TUNING  // tuning builds only: GA_GEMM_RING = 0 old kernel, 1 / 2 / 3 force a ring tile
