@@ -10,8 +10,11 @@ TEST INFRASTRUCTURE ONLY.  Works on a DINOv2-format state dict (keys ``cls_token
 patch_embed.proj.*, blocks.{i}.{norm1,norm2}.*, blocks.{i}.attn.{qkv,proj}.*, blocks.{i}.{ls1,ls2}.gamma,
 blocks.{i}.mlp.{fc1,fc2}.*, norm.*``).
 
-PARITY UNPINNED.  The arithmetic lives entirely in third-party code that is absent from /root/reference and cannot be
-fetched here: the model is ``torch.hub.load('facebookresearch/dinov2', 'dinov2_vitl14_reg')`` (modules.py:816-822, hub
+PARITY: the ENCODER (vit_forward) is PINNED against an independent published implementation of the same architecture --
+Hugging Face transformers' Dinov2WithRegistersModel with the same randomly drawn weights mapped to the hub key layout, max
+difference 2e-5 of the output range (tests/test_cpu_oracle_and_host.py::test_dinov2_oracle_against_the_transformers_implementation);
+the kornia resize in front of it and the torch.hub code / released weights themselves stay UNPINNED.  The arithmetic lives entirely in
+third-party code that is absent from /root/reference and cannot be fetched here: the model is ``torch.hub.load('facebookresearch/dinov2', 'dinov2_vitl14_reg')`` (modules.py:816-822, hub
 ref unpinned; the comments at :841 and :895 cite commit e1277af2ba9496fbadf7aec6eba56e8d882d1e35) and the resize is kornia
 (requirements.txt, unpinned).  What is restated below, from the published DINOv2 code [UPSTREAM-RECALLED]:
   dinov2/models/vision_transformer.py  DinoVisionTransformer.prepare_tokens_with_masks / forward_features:

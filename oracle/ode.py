@@ -4,7 +4,11 @@ reference relies on at /root/reference/transport/integrators.py:111-118 (SURVEY.
 TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED for the third-party arithmetic: torchdiffeq is absent from /root/reference and
 unpinned in requirements.txt:40; the reference holds no test for it.  What IS pinned by tests/test_transport.py: the
 reference's own transport plumbing (check_interval, velocity drift, time grid) -- the reference's transport/*.py is
-imported with this module standing in for torchdiffeq -- and the analytic solutions of linear ODEs."""
+imported with this module standing in for torchdiffeq -- and the analytic solutions of linear ODEs.  The Dormand-Prince stage
+matrix, nodes and 5th-order weights are checked against SciPy's RK45 (an independent implementation of the same pair), one step
+against its rk_step, and the error weights against the order conditions (tests/test_cpu_oracle_and_host.py::
+test_ode_oracle_tableau_against_scipy_rk45); torchdiffeq's embedded 4th-order weights and its step-size controller are restated
+from the published code and remain unpinned."""
 import numpy as np
 
 A = [1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0]

@@ -613,3 +613,83 @@ def test_stage2_conditioning_follows_the_release_config():
     assert torch.allclose(s2.seen[n_before]["fps-xyz"][0], raw[0] / 0.45) and torch.equal(out_d["latent"], out["latent"])
     out0 = cascade.cascade(s1, s2, dec, cond, uc, num_steps=4, sampling_method="euler", seed=7, stage2_zero_image_uc=True)
     assert torch.equal(s2.seen[-1]["img_crossattn"][1], torch.zeros(5, 8)) and out0["latent"].shape == (1, 16, 10)
+
+
+# ---- conditioner oracle against an independent published implementation ---------------------------------------------------
+def test_dinov2_oracle_against_the_transformers_implementation():
+    """oracle/dinov2.py::vit_forward restates facebookresearch/dinov2 (torch.hub code, absent here).  Hugging Face transformers
+    ships an independent implementation of the same published architecture (Dinov2WithRegistersModel); with the same randomly
+    drawn weights, mapped from its parameter names to the hub layout, both must produce the same tokens -- this pins the
+    oracle's encoder arithmetic (patch embedding order, cls / register / patch token order, position embedding, pre-norm blocks
+    with LayerScale, erf-GELU MLP, final LayerNorm, head split of the fused qkv) to published code.  (The kornia resize in
+    front of it stays unpinned.)"""
+    tr = pytest.importorskip("transformers")
+    if not hasattr(tr, "Dinov2WithRegistersModel"):
+        pytest.skip("transformers without Dinov2WithRegistersModel")
+    from oracle import dinov2 as od
+    torch.manual_seed(0)
+    D, depth, heads, R, P, grid = 128, 3, 2, 4, 14, 5
+    cfg = tr.Dinov2WithRegistersConfig(hidden_size=D, num_hidden_layers=depth, num_attention_heads=heads, mlp_ratio=4,
+                                       image_size=P * grid, patch_size=P, num_register_tokens=R, layerscale_value=1.0,
+                                       hidden_act="gelu", layer_norm_eps=1e-6, qkv_bias=True, use_swiglu_ffn=False,
+                                       attn_implementation="eager")
+    hf = tr.Dinov2WithRegistersModel(cfg).eval()
+    with torch.no_grad():
+        for p in hf.parameters():          # every parameter away from its initial value (LayerScale = 1, zero biases, ...)
+            p.copy_(torch.randn(p.shape) * (0.3 if p.dim() > 1 else 0.5) + (1.0 if p.dim() == 1 and p.numel() == D else 0.0))
+    h = hf.state_dict()
+    sd = {"cls_token": h["embeddings.cls_token"], "pos_embed": h["embeddings.position_embeddings"],
+          "register_tokens": h["embeddings.register_tokens"],
+          "patch_embed.proj.weight": h["embeddings.patch_embeddings.projection.weight"],
+          "patch_embed.proj.bias": h["embeddings.patch_embeddings.projection.bias"],
+          "norm.weight": h["layernorm.weight"], "norm.bias": h["layernorm.bias"]}
+    for i in range(depth):
+        a, b = f"encoder.layer.{i}.", f"blocks.{i}."
+        for n in ("weight", "bias"):
+            sd[b + "norm1." + n] = h[a + "norm1." + n]
+            sd[b + "norm2." + n] = h[a + "norm2." + n]
+            sd[b + "attn.qkv." + n] = torch.cat([h[a + f"attention.attention.{w}.{n}"] for w in ("query", "key", "value")], 0)
+            sd[b + "attn.proj." + n] = h[a + "attention.output.dense." + n]
+            sd[b + "mlp.fc1." + n] = h[a + "mlp.fc1." + n]
+            sd[b + "mlp.fc2." + n] = h[a + "mlp.fc2." + n]
+        sd[b + "ls1.gamma"] = h[a + "layer_scale1.lambda1"]
+        sd[b + "ls2.gamma"] = h[a + "layer_scale2.lambda1"]
+    img = torch.randn(2, 3, P * grid, P * grid)
+    with torch.no_grad():
+        ref = hf(pixel_values=img).last_hidden_state
+    out = od.vit_forward(sd, img)
+    assert out["x_norm_patchtokens"].shape == (2, grid * grid, D)
+    scale = float(ref.abs().max())
+    assert float((out["x_norm_clstoken"] - ref[:, 0]).abs().max()) < 2e-5 * scale
+    assert float((out["x_norm_patchtokens"] - ref[:, 1 + R:]).abs().max()) < 2e-5 * scale
+
+
+def test_ode_oracle_tableau_against_scipy_rk45():
+    """oracle/ode.py restates torchdiffeq's dopri5 (absent here).  SciPy's RK45 is an independent implementation of the same
+    Dormand-Prince 5(4) pair: nodes, stage matrix and the 5th-order weights must agree, one step from the same state must give
+    the same y1, and the oracle's error weights (torchdiffeq pairs the 5th-order solution with a different 4th-order one than
+    SciPy) must at least be the difference of two order->=4 quadratures: sum E c^q = 0 for q = 0..3 -- a mistyped coefficient
+    would break one of these.  (The step-size controller stays unpinned.)"""
+    sp = pytest.importorskip("scipy.integrate")
+    from scipy.integrate._ivp.rk import RK45, rk_step
+    from oracle import ode as oo
+    c = np.array([0.0] + oo.A[:5])                       # nodes of stages 1..6 (the 7th, FSAL, stage sits at 1)
+    assert np.allclose(c, RK45.C, rtol=0, atol=1e-15)
+    for i in range(5):
+        assert np.allclose(oo.B[i], RK45.A[i + 1][:i + 1], rtol=0, atol=1e-15), i
+    assert np.allclose(oo.B[5], RK45.B, rtol=0, atol=1e-15)
+    cs = np.array([0.0] + oo.A)                          # all seven stages
+    for q in range(4):
+        assert abs(float(np.dot(oo.E, cs ** q))) < 1e-15, q
+    assert abs(float(np.dot(oo.E, cs ** 4))) > 1e-4      # ... and differ at order 5
+    f = lambda t, y: np.array([y[1], -y[0] + 0.1 * np.sin(3 * t), -0.5 * y[2] * y[0]])   # noqa: E731
+    y0, t0, h = np.array([1.0, 0.3, -0.7]), 0.2, 0.05
+    K = np.empty((7, 3))
+    y_sp, _ = rk_step(f, t0, y0, f(t0, y0), h, RK45.A, RK45.B, RK45.C, K)
+    seen = {}
+    oo.odeint(lambda t, y: f(t, y), y0, [t0, t0 + h], method="dopri5", atol=1e9, rtol=1e9, stats=seen)   # (never rejects)
+    k = [f(t0, y0)]
+    for i in range(6):
+        yi = y0 + h * sum(cc * kk for cc, kk in zip(oo.B[i], k))
+        k.append(f(t0 + oo.A[i] * h, yi))
+    assert np.allclose(yi, y_sp, rtol=1e-14, atol=1e-15)
