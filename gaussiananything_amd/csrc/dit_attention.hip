@@ -434,13 +434,26 @@ extern "C" int ga_attention_bf16(const GaAttentionArgs *a, void *stream)
     // cross-attention: 6 x 16 x 1 = 96 workgroups for 256 CUs) 64-query workgroups with two key groups -- measured on
     // MI355X, B = 1, 16 heads, 768 x 1369: 20.7 -> 15.0 us; B = 2: 22.3 us (<8,1>) vs 28.5 us (<4,2>).
 #ifdef GA_TUNING  // tuning builds only: NW*10 + KS from the environment
-    static const int cfg = [] { const char *e = getenv("GA_ATTN_CFG"); return e ? atoi(e) : 0; }();
+    const int cfg = [] { const char *e = getenv("GA_ATTN_CFG"); return e ? atoi(e) : 0; }();
 #else
     constexpr int cfg = 0;
 #endif
     const int64_t wgs128 = (int64_t)((a->Lq + 127) / 128) * a->heads * a->batch;
-    const bool split = cfg ? cfg == 42 : wgs128 <= 128;
-    if (split) launch_attention<4, 2>(*a, s);
+#ifdef GA_TUNING
+    if (cfg == 23) { launch_attention<2, 3>(*a, s); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
+    if (cfg == 43) { launch_attention<4, 3>(*a, s); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
+    if (cfg == 22) { launch_attention<2, 2>(*a, s); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
+    if (cfg == 41) { launch_attention<4, 1>(*a, s); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
+    if (cfg == 82) { launch_attention<8, 2>(*a, s); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
+    if (cfg == 21) { launch_attention<2, 1>(*a, s); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
+#endif
+    // Round 3 (tools/attn_cfg_sweep.py): three key groups on the small grids (1 x 16 x 768 x 1369: 15.9 -> 14.2 us, x 768 keys
+    // 10.1 -> 9.6 us), and two key groups beside eight query waves while 128-query workgroups are fewer than two per CU
+    // (2 x 16 x 768 x 768: 13.7 -> 12.8 us; 4 x 16 x 768 x 1369: 39.5 -> 37.1 us); one group on the grids beyond that.
+    if (cfg == 42) launch_attention<4, 2>(*a, s);
+    else if (cfg == 81) launch_attention<8, 1>(*a, s);
+    else if (wgs128 <= 128) launch_attention<4, 3>(*a, s);
+    else if (wgs128 <= 512) launch_attention<8, 2>(*a, s);
     else launch_attention<8, 1>(*a, s);
     return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
 }
