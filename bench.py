@@ -121,8 +121,10 @@ def bench_attention(dev, reps=50):
         fl = 4.0 * B * H * Lq * Lk * 64
         out[name] = {"us": round(us, 2), "tflops": round(fl / (us * 1e-6) / 1e12, 1),
                      "frac_of_bf16_mfma_peak": round(fl / (us * 1e-6) / 1e12 / 2500.0, 4)}
-    out["note"] = ("launches on torch's current stream, timed with events on that stream; MFMA-busy counters of the same kernels: "
-                   "profiles/r1f_attention_pmc.txt (the kernel body is unchanged since; round 2 made the grid head-major)")
+    out["mfma_busy_from_counters"] = {"self_attention_2x16x768x768": 0.093, "cross_attention_1x16x768x1369": 0.079,
+                                      "source": "committed rocprofv3 PMC pass of exactly these two launches (profiles/r3_attention_pmc.txt: "
+                                                "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs), not measured in this run"}
+    out["note"] = "launches on torch's current stream, timed with events on that stream"
     return out
 
 
@@ -655,7 +657,7 @@ def main():
             blend_bytes = 76.0 * int(st[0]) + 40.0 * P * v      # per launch (all V views), SURVEY.md 8d
             achieved = blend_bytes / (stage["blend"] * 1e-3) / 1e9
             traffic, tsrc = None, None  # PMC counters cannot be collected live: taken from the committed rocprofv3 passes
-            pmc_file = os.path.join(ROOT, "profiles", "r2_blend_pmc.json")
+            pmc_file = os.path.join(ROOT, "profiles", "r3_blend_pmc.json")
             if a.scene == "surface" and n == 100_000 and v == 8 and H == 512 and os.path.exists(pmc_file):
                 pj = json.load(open(pmc_file))
                 traffic, tsrc = pj["traffic_bytes_per_launch"], f"committed PMC ({pj['source']}, HEAD {pj.get('head')}), not measured in this run"
@@ -680,7 +682,7 @@ def main():
                                  "lane_slot_utilisation": round(pairs / max(slots, 1.0), 4),
                                  "tflops_at_60flop_per_evaluated_pair": round(pairs * 60 / (stage["blend"] * 1e-3) / 1e12, 3),
                                  "peak_fp32_valu_tflops": FP32_VALU_PEAK_TFLOPS,
-                                 "note": "53 M wave-level VALU instructions per launch, LDS 22 M active cycles (profiles/r2_pmc.txt); "
+                                 "note": "53.7 M wave-level VALU instructions per launch, LDS 22.5 M active cycles (profiles/r3_blend_pmc.txt); "
                                          "lanes = pixels of an 8x8 quadrant cannot exceed 0.53 lane use on this scene (tools/blend_sim.py)"}
             del splan
             out["stage_ms"] = {k: round(x, 5) for k, x in stage.items()}
