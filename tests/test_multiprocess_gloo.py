@@ -106,3 +106,23 @@ def test_world_size_two_gloo():
     assert all(r[0] for r in res)
     assert sorted(sum((r[1] for r in res), [])) == list(range(5))
     assert all(abs(r[2] - 2.0) < 1e-9 for r in res)
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher must start two ranks itself (torch.distributed.run re-exec), rendezvous and
+    report n_gpus = 2 -- never silently run one rank.  GA_BENCH_LAUNCH_ONLY=1 stops every rank after the rendezvous (gloo), so the
+    launcher is exercised without a GPU; a WORLD_SIZE that contradicts --gpus is refused."""
+    import json
+    import subprocess
+    env = dict(os.environ, GA_BENCH_LAUNCH_ONLY="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec == {"launch_only": True, "n_gpus": 2, "ranks_seen": 2}
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)
