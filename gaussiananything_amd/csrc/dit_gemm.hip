@@ -52,7 +52,17 @@ struct GemmP {  // by-value kernel parameters (kept flat: no pointer into the ar
     const float *row_ss;
     int row_ss_tiles;
     float row_ss_inv_dim, row_ss_eps;
+    int w_tiled;       // W is the tiled image [N/8][K/64][8][64] (include/ga_dit.h)
 };
+
+// Element offset of chunk c (8 bf16) of weight row n at K-tile 0, and the stride from one K-tile to the next: row-major
+// [N][K] or the tiled image [N/8][K/64][8][64], in which the 8 rows x 128 bytes one LDS-DMA instruction moves are 1 KiB
+// contiguous.
+__device__ __forceinline__ size_t w_offset(const GemmP &p, int n, int c)
+{
+    return p.w_tiled ? ((size_t)(n >> 3) * (p.K >> 6) * 512 + (n & 7) * 64 + c * 8) : ((size_t)n * p.K + c * 8);
+}
+__device__ __forceinline__ int w_kstep(const GemmP &p) { return p.w_tiled ? 512 : BK; }
 
 __device__ __forceinline__ void glds16(const uint16_t *gsrc, uint16_t *lds_wave_base)
 {
@@ -337,8 +347,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (wave * 4 + i) * 8 + (lane >> 3);
-        srcW[i] = p.W + (size_t)min(n0 + row, N - 1) * K + ((lane & 7) ^ (row & 7)) * 8;
+        srcW[i] = p.W + w_offset(p, min(n0 + row, N - 1), (lane & 7) ^ (row & 7));
     }
+    const int wks = w_kstep(p);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int row = (wave * MT + i) * 8 + (lane >> 3);
@@ -370,7 +381,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
     do {                                                                                              \
         uint16_t *bw_ = smem + (BUF) * SLOT, *ba_ = bw_ + TILE_ELEMS;                                  \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
-            glds16(srcW[i] + (size_t)(KT) * BK, bw_ + (wave * 4 + i) * 8 * BK);                       \
+            glds16(srcW[i] + (size_t)(KT) * wks, bw_ + (wave * 4 + i) * 8 * BK);                       \
         _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                \
             glds16(srcA[i] + (size_t)(KT) * BK, ba_ + (wave * MT + i) * 8 * BK);                      \
     } while (0)
@@ -502,10 +513,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
     // DMA sources: instruction i of this wave fills rows q*8 .. q*8+7 of the slot image [W rows | A rows], q = i*NW + wave;
     // slot (row, s) of the 128-byte row receives global chunk s ^ (row & 7)
     const uint16_t *src[DPT];
+    static_assert(BNT % (8 * NW) == 0, "instruction i of every wave is on the same side of the W | A boundary");
+    const int wks = w_kstep(p);
 #pragma unroll
     for (int i = 0; i < DPT; ++i) {
         const int row = (i * NW + wave) * 8 + (lane >> 3);
-        if (row < BNT) src[i] = p.W + (size_t)min(n0 + row, N - 1) * K + ((lane & 7) ^ (row & 7)) * 8;
+        if (i * NW * 8 < BNT) src[i] = p.W + w_offset(p, min(n0 + row, N - 1), (lane & 7) ^ (row & 7));
         else src[i] = p.A + (size_t)min(m0 + row - BNT, M - 1) * p.lda + ((lane & 7) ^ ((row - BNT) & 7)) * 8;
     }
     f32x4 acc[FN][FM];
@@ -523,7 +536,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
         constexpr int BUF = decltype(bufc)::value;
         uint16_t *base = smem + BUF * SLOT;
 #pragma unroll
-        for (int i = 0; i < DPT; ++i) glds16(src[i] + (size_t)kt * BK, base + (i * NW + wave) * 8 * BK);
+        for (int i = 0; i < DPT; ++i) glds16(src[i] + (size_t)kt * (i * NW * 8 < BNT ? wks : BK), base + (i * NW + wave) * 8 * BK);
     };
     auto mfmas = [&](const bf16x8(&fw)[FN], const bf16x8(&fa)[FM]) __attribute__((always_inline)) {
 #pragma unroll
@@ -713,13 +726,14 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
     if ((a->emit_x || a->emit_ss) && (a->epilogue != GA_GEMM_EPI_RESIDUAL || !a->emit_x || !a->emit_ss || a->N % 64 != 0 ||
                                       a->emit_ld % 8 != 0 || a->emit_ld < a->N))
         return GA_DIT_ERR_BAD_SHAPE;
+    if (a->w_tiled && a->N % 8 != 0) return GA_DIT_ERR_BAD_SHAPE;
     if (a->row_ss && (a->epilogue != GA_GEMM_EPI_STORE_BF16 || a->bias || a->row_ss_tiles <= 0 || a->row_ss_tiles > 16 ||
                       a->row_ss_tiles % 4 != 0 || a->row_ss_dim <= 0))
         return GA_DIT_ERR_BAD_SHAPE;
     const GemmP p{a->M, a->N, a->K, a->rows_per_batch, a->A, a->W, a->bias, a->gate, a->out, a->lda, a->ldo, a->gate_stride,
                   a->vt, a->vt_col0, a->vt ? (a->N - a->vt_col0) / 64 : 0, a->vt_ld, a->qk_w0, a->qk_w1, a->qk_cols0,
                   a->qk_cols1, a->emit_x, a->emit_ss, a->emit_ld, a->row_ss, a->row_ss_tiles,
-                  a->row_ss_dim > 0 ? 1.0f / (float)a->row_ss_dim : 0.f, a->row_ss_eps};
+                  a->row_ss_dim > 0 ? 1.0f / (float)a->row_ss_dim : 0.f, a->row_ss_eps, a->w_tiled ? 1 : 0};
     // Tile / ring choice (256 CUs).  A workgroup tile is 128 weight rows x 32 MT activation rows (MT = 4, 3, 2, 1); its work is
     // proportional to MT plus a tile-independent share (prologue, weight tile, epilogue: about one MT unit, tools/gemm_sweep.py) and
     // the launch ends with the busiest CU, so the cost of a choice is ceil(workgroups / 256) * (MT + 1)

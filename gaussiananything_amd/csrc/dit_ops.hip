@@ -449,7 +449,7 @@ extern "C" int ga_dit_cache_context(const GaDitModel *m, int32_t batch, int32_t 
     for (int i = 0; i < m->depth; ++i) {
         GaGemmArgs g{};
         g.M = rows; g.N = 2 * D; g.K = m->context_dim; g.epilogue = GA_GEMM_EPI_STORE_BF16;
-        g.A = ctx; g.lda = m->context_dim; g.W = m->blocks[i].ca_kv_w; g.bias = nullptr;
+        g.A = ctx; g.lda = m->context_dim; g.W = m->blocks[i].ca_kv_w; g.w_tiled = m->gemm_weights_tiled; g.bias = nullptr;
         g.out = ca_k + (size_t)i * rows * D; g.ldo = D;                    // K columns [0, D)
         g.vt = ca_vt + (size_t)i * batch * D * Mp; g.vt_col0 = D; g.vt_ld = Mp; g.rows_per_batch = ctx_tokens;
         g.qk_w0 = m->blocks[i].ca_k_norm_w; g.qk_cols0 = D; g.qk_cols1 = D;  // k_norm applied once, here
@@ -496,7 +496,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
                     w.xn, w.xres};
         hipLaunchKernelGGL(embed_tokens_kernel, dim3(Mrows), dim3(256), 0, s, e);
         GaGemmArgs g{};
-        g.M = Mrows; g.N = D; g.K = D; g.epilogue = GA_GEMM_EPI_RESIDUAL; g.A = w.xn; g.lda = D; g.W = m->xe_fc2_w;
+        g.M = Mrows; g.N = D; g.K = D; g.epilogue = GA_GEMM_EPI_RESIDUAL; g.A = w.xn; g.lda = D; g.W = m->xe_fc2_w; g.w_tiled = m->gemm_weights_tiled;
         g.bias = m->xe_fc2_b; g.out = w.xres; g.ldo = D; g.gate = nullptr; g.rows_per_batch = L;
         GA_TRY(ga_gemm_bf16(&g, stream));
     }
@@ -518,7 +518,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         }
         GaGemmArgs gq{};
         gq.M = Mca; gq.N = D; gq.K = D; gq.epilogue = GA_GEMM_EPI_STORE_BF16; gq.A = w.xn; gq.lda = D;
-        gq.W = folded ? bw.ca_q_w_prenorm : bw.ca_q_w;
+        gq.W = folded ? bw.ca_q_w_prenorm : bw.ca_q_w; gq.w_tiled = m->gemm_weights_tiled;
         gq.out = w.qkv; gq.ldo = D;
         if (folded) { gq.row_ss = w.rowss; gq.row_ss_tiles = D / 64; gq.row_ss_dim = D; gq.row_ss_eps = 1e-5f; }
         gq.qk_w0 = bw.ca_q_norm_w; gq.qk_cols0 = D; gq.qk_cols1 = D;           // q_norm fused into the projection
@@ -527,7 +527,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
                            a->ca_vt + (size_t)i * B * D * Mp, D, D, Mp, nullptr, nullptr, w.att, D};
         GA_UNLESS(2, ga_attention_bf16(&ca, stream));
         GaGemmArgs go{};
-        go.M = Mca; go.N = D; go.K = D; go.epilogue = GA_GEMM_EPI_RESIDUAL; go.A = w.att; go.lda = D; go.W = bw.ca_out_w;
+        go.M = Mca; go.N = D; go.K = D; go.epilogue = GA_GEMM_EPI_RESIDUAL; go.A = w.att; go.lda = D; go.W = bw.ca_out_w; go.w_tiled = m->gemm_weights_tiled;
         go.bias = bw.ca_out_b; go.out = w.xres; go.ldo = D; go.gate = nullptr; go.rows_per_batch = L;
         GA_UNLESS(32, ga_gemm_bf16(&go, stream));
         // self-attention
@@ -537,14 +537,14 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         GA_UNLESS(4, ga_rmsnorm_modulate(&n1, stream));
         GaGemmArgs gqkv{};
         gqkv.M = Mrows; gqkv.N = 3 * D; gqkv.K = D; gqkv.epilogue = GA_GEMM_EPI_STORE_BF16; gqkv.A = w.xn; gqkv.lda = D;
-        gqkv.W = bw.qkv_w; gqkv.bias = bw.qkv_b; gqkv.out = w.qkv; gqkv.ldo = 2 * D;   // q | k row-major ...
+        gqkv.W = bw.qkv_w; gqkv.w_tiled = m->gemm_weights_tiled; gqkv.bias = bw.qkv_b; gqkv.out = w.qkv; gqkv.ldo = 2 * D;   // q | k row-major ...
         gqkv.vt = w.vt; gqkv.vt_col0 = 2 * D; gqkv.vt_ld = Lp; gqkv.rows_per_batch = L;  // ... v transposed
         gqkv.qk_w0 = bw.q_norm_w; gqkv.qk_cols0 = D; gqkv.qk_w1 = bw.k_norm_w; gqkv.qk_cols1 = 2 * D;  // per-head q/k RMSNorm
         GA_UNLESS(16, ga_gemm_bf16(&gqkv, stream));
         GaAttentionArgs sa{B, m->heads, L, L, w.qkv, w.qkv + D, w.vt, 2 * D, 2 * D, Lp, nullptr, nullptr, w.att, D};
         GA_UNLESS(1, ga_attention_bf16(&sa, stream));
         GaGemmArgs gp{};
-        gp.M = Mrows; gp.N = D; gp.K = D; gp.epilogue = GA_GEMM_EPI_RESIDUAL; gp.A = w.att; gp.lda = D; gp.W = bw.proj_w;
+        gp.M = Mrows; gp.N = D; gp.K = D; gp.epilogue = GA_GEMM_EPI_RESIDUAL; gp.A = w.att; gp.lda = D; gp.W = bw.proj_w; gp.w_tiled = m->gemm_weights_tiled;
         gp.bias = bw.proj_b; gp.out = w.xres; gp.ldo = D; gp.gate = mod + 2 * D; gp.gate_stride = 6 * (int64_t)D;
         gp.rows_per_batch = L;
         GA_UNLESS(16, ga_gemm_bf16(&gp, stream));
@@ -552,12 +552,12 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         GaRmsNormArgs n2{Mrows, D, L, w.xres, bw.norm2_w, mod + 4 * D, mod + 3 * D, 6 * (int64_t)D, w.xn, nullptr, 0};
         GA_UNLESS(4, ga_rmsnorm_modulate(&n2, stream));
         GaGemmArgs g1{};
-        g1.M = Mrows; g1.N = 4 * D; g1.K = D; g1.epilogue = GA_GEMM_EPI_GELU_BF16; g1.A = w.xn; g1.lda = D; g1.W = bw.fc1_w;
+        g1.M = Mrows; g1.N = 4 * D; g1.K = D; g1.epilogue = GA_GEMM_EPI_GELU_BF16; g1.A = w.xn; g1.lda = D; g1.W = bw.fc1_w; g1.w_tiled = m->gemm_weights_tiled;
         g1.bias = bw.fc1_b; g1.out = w.hmid; g1.ldo = 4 * D;
         GA_UNLESS(8, ga_gemm_bf16(&g1, stream));
         GaGemmArgs g2{};
         g2.M = Mrows; g2.N = D; g2.K = 4 * D; g2.epilogue = GA_GEMM_EPI_RESIDUAL; g2.A = w.hmid; g2.lda = 4 * D;
-        g2.W = bw.fc2_w; g2.bias = bw.fc2_b; g2.out = w.xres; g2.ldo = D; g2.gate = mod + 5 * D;
+        g2.W = bw.fc2_w; g2.w_tiled = m->gemm_weights_tiled; g2.bias = bw.fc2_b; g2.out = w.xres; g2.ldo = D; g2.gate = mod + 5 * D;
         g2.gate_stride = 6 * (int64_t)D; g2.rows_per_batch = L;
         if (i + 1 < m->depth && can_fold(m, i + 1)) { g2.emit_x = w.xn; g2.emit_ld = D; g2.emit_ss = w.rowss; }
         GA_UNLESS(8, ga_gemm_bf16(&g2, stream));

@@ -168,7 +168,7 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
 
     # -- weight packing -------------------------------------------------------------------------------------------------
     def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + (bool(self.fold_prenorm),)
+        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + (bool(self.fold_prenorm), bool(self.tile_weights))
 
     def _prepare(self, device):
         sig = self._signature()
@@ -186,17 +186,25 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
+        tiled = bool(self.tile_weights)
+
+        def gw(t):      # a weight the GEMM reads: stored as the LDS-DMA tile image (GaGemmArgs.w_tiled), packed once here
+            t = t.detach().to(device=device, dtype=torch.bfloat16)
+            t = ops.tile_weight(t) if tiled else t.contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
         blocks = (ops.GaDitBlockWeights * self.depth)()
         for i, b in enumerate(self.blocks):
             ca = b.cross_attn_dino
             blocks[i] = ops.GaDitBlockWeights(
-                fp(b.prenorm_ca_dino.weight), bf(ca.to_q.weight),
-                bf(ca.to_q.weight.detach().float() * b.prenorm_ca_dino.weight.detach().float()[None, :]) if self.fold_prenorm else None,
-                bf(torch.cat([ca.to_k.weight, ca.to_v.weight], 0)),
-                fp(ca.q_norm.weight), fp(ca.k_norm.weight), bf(ca.to_out[0].weight), fp(ca.to_out[0].bias),
-                fp(b.norm1.weight), bf(b.attn.qkv.weight), fp(b.attn.qkv.bias), fp(b.attn.q_norm.weight),
-                fp(b.attn.k_norm.weight), bf(b.attn.proj.weight), fp(b.attn.proj.bias), fp(b.norm2.weight),
-                bf(b.mlp.mlp[0].weight), fp(b.mlp.mlp[1].bias), bf(b.mlp.mlp[2].weight), fp(b.mlp.mlp[3].bias),
+                fp(b.prenorm_ca_dino.weight), gw(ca.to_q.weight),
+                gw(ca.to_q.weight.detach().float() * b.prenorm_ca_dino.weight.detach().float()[None, :]) if self.fold_prenorm else None,
+                gw(torch.cat([ca.to_k.weight, ca.to_v.weight], 0)),
+                fp(ca.q_norm.weight), fp(ca.k_norm.weight), gw(ca.to_out[0].weight), fp(ca.to_out[0].bias),
+                fp(b.norm1.weight), gw(b.attn.qkv.weight), fp(b.attn.qkv.bias), fp(b.attn.q_norm.weight),
+                fp(b.attn.k_norm.weight), gw(b.attn.proj.weight), fp(b.attn.proj.bias), fp(b.norm2.weight),
+                gw(b.mlp.mlp[0].weight), fp(b.mlp.mlp[1].bias), gw(b.mlp.mlp[2].weight), fp(b.mlp.mlp[3].bias),
                 fp(b.scale_shift_table))
         xyz_w = xyz_b = None
         if self._stage2:
@@ -208,9 +216,9 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
             fp(self.t_embedder.mlp[2].bias), fp(self.pooled_vec_embedder[0].weight), fp(self.pooled_vec_embedder[0].bias),
             bf(self.pooled_vec_embedder[1].weight), fp(self.pooled_vec_embedder[1].bias),
             bf(self.adaLN_modulation[1].weight), fp(self.adaLN_modulation[1].bias), fp(self.x_embedder.fc1.weight),
-            fp(self.x_embedder.fc1.bias), bf(self.x_embedder.fc2.weight), fp(self.x_embedder.fc2.bias), xyz_w, xyz_b,
+            fp(self.x_embedder.fc1.bias), gw(self.x_embedder.fc2.weight), fp(self.x_embedder.fc2.bias), xyz_w, xyz_b,
             fp(self.final_layer.scale_shift_table), fp(self.final_layer.linear.weight), fp(self.final_layer.linear.bias),
-            blocks)
+            blocks, 1 if tiled else 0)
         self._pack = dict(sig=sig, device=device, model=model, blocks=blocks, keep=keep, ws=None, ws_key=None)
         self._ctx_cache = None
         return self._pack
@@ -218,6 +226,8 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
     ca_skip = True  # skip the cross-attention of batch items whose image tokens are all zero (exact; tests switch it off)
     # fold the (un-modulated) cross-attention pre-norm into the neighbouring GEMMs (include/ga_dit.h); GA_DIT_FOLD=0: A/B aid
     fold_prenorm = os.environ.get("GA_DIT_FOLD", "1") != "0"
+    # GEMM weights stored as 1-KiB LDS-DMA tiles (GaGemmArgs.w_tiled); GA_DIT_TILED=0: row-major, A/B aid
+    tile_weights = os.environ.get("GA_DIT_TILED", "1") != "0"
 
     def _context_kv(self, pack, ctx_tokens: torch.Tensor):
         key = (ctx_tokens.data_ptr(), ctx_tokens._version, tuple(ctx_tokens.shape), ctx_tokens.dtype)

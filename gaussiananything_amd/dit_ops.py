@@ -19,7 +19,7 @@ class GaGemmArgs(ctypes.Structure):
                 ("bias", c_p), ("out", c_p), ("ldo", i64), ("gate", c_p), ("gate_stride", i64), ("rows_per_batch", i32),
                 ("vt", c_p), ("vt_col0", i32), ("vt_ld", i64), ("qk_w0", c_p), ("qk_w1", c_p), ("qk_cols0", i32),
                 ("qk_cols1", i32), ("emit_x", c_p), ("emit_ss", c_p), ("emit_ld", i64), ("row_ss", c_p),
-                ("row_ss_tiles", i32), ("row_ss_dim", i32), ("row_ss_eps", ctypes.c_float)]
+                ("row_ss_tiles", i32), ("row_ss_dim", i32), ("row_ss_eps", ctypes.c_float), ("w_tiled", i32)]
 
 
 class GaAttentionArgs(ctypes.Structure):
@@ -50,7 +50,8 @@ class GaDitModel(ctypes.Structure):
                 ("context_dim", i32), ("stage2", i32)] + [(n, c_p) for n in (
                     "t_mlp0_w", "t_mlp0_b", "t_mlp2_w", "t_mlp2_b", "pool_ln_w", "pool_ln_b", "pool_w", "pool_b",
                     "adaln_w", "adaln_b", "xe_fc1_w", "xe_fc1_b", "xe_fc2_w", "xe_fc2_b", "xyz_w", "xyz_b",
-                    "final_table", "final_w", "final_b")] + [("blocks", ctypes.POINTER(GaDitBlockWeights))]
+                    "final_table", "final_w", "final_b")] + [("blocks", ctypes.POINTER(GaDitBlockWeights)),
+                                                              ("gemm_weights_tiled", i32)]
 
 
 class GaDitSamplerStep(ctypes.Structure):
@@ -114,7 +115,7 @@ def _need_cuda(*ts):
 
 def gemm(A, W, bias=None, epilogue=EPI_STORE_BF16, out=None, gate=None, rows_per_batch=1, vt=None, vt_col0=0,
          qk_w0=None, qk_cols0=0, qk_w1=None, qk_cols1=0, emit_x=None, emit_ss=None, row_ss=None, row_ss_dim=0,
-         row_ss_eps=1e-5):
+         row_ss_eps=1e-5, w_tiled=False, N=None):
     """A [M,K] bf16, W [N,K] bf16 -> see ga_dit.h.  EPI_RESIDUAL accumulates into ``out`` (fp32 [M,N]).
     ``vt`` [B*heads*64, Lpad] bf16 (zero-initialised): columns >= vt_col0 are stored transposed there (V projection).
     ``qk_w0/qk_w1``: per-head RMSNorm weights for the column groups [0, qk_cols0) / [qk_cols0, qk_cols1).
@@ -122,7 +123,7 @@ def gemm(A, W, bias=None, epilogue=EPI_STORE_BF16, out=None, gate=None, rows_per
     _need_cuda(A, W, bias, out, gate, vt)
     assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and A.stride(-1) == 1 and W.is_contiguous()
     M, K = A.shape
-    N = W.shape[0]
+    N = W.shape[0] if N is None else N       # (a tiled weight comes as the flat image of tile_weight)
     if out is None:
         out = torch.empty((M, N if vt is None else vt_col0), device=A.device,
                           dtype=torch.bfloat16 if epilogue in (EPI_STORE_BF16, EPI_GELU_BF16) else torch.float32)
@@ -130,9 +131,16 @@ def gemm(A, W, bias=None, epilogue=EPI_STORE_BF16, out=None, gate=None, rows_per
                    _ptr(gate), gate.stride(0) if gate is not None else 0, rows_per_batch, _ptr(vt), vt_col0,
                    vt.stride(0) if vt is not None else 0, _ptr(qk_w0), _ptr(qk_w1), qk_cols0, max(qk_cols1, qk_cols0),
                    _ptr(emit_x), _ptr(emit_ss), emit_x.stride(0) if emit_x is not None else 0,
-                   _ptr(row_ss), row_ss.shape[1] if row_ss is not None else 0, row_ss_dim, row_ss_eps)
+                   _ptr(row_ss), row_ss.shape[1] if row_ss is not None else 0, row_ss_dim, row_ss_eps, 1 if w_tiled else 0)
     check(lib().ga_gemm_bf16(ctypes.byref(a), _stream(A)), "ga_gemm_bf16")
     return out
+
+
+def tile_weight(W):
+    """[N, K] weight (N % 8 == 0, K % 64 == 0) -> the tiled image [N/8][K/64][8][64] of GaGemmArgs.w_tiled, flat [N*K]."""
+    N, K = W.shape
+    assert N % 8 == 0 and K % 64 == 0
+    return W.detach().reshape(N // 8, 8, K // 64, 64).permute(0, 2, 1, 3).contiguous().reshape(-1)
 
 
 def transpose_v(v):

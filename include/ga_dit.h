@@ -80,6 +80,10 @@ typedef struct GaGemmArgs {
     const float *row_ss;
     int32_t row_ss_tiles, row_ss_dim;
     float row_ss_eps;
+    /* Round 3: W may be given TILED -- [N/8][K/64][8][64] bf16, i.e. the 8 x 64 block a single 1 KiB LDS-DMA instruction moves is
+     * contiguous in memory (N % 8 == 0).  Weights are packed once at load time; on weights that stream from HBM (a DiT evaluation
+     * reads 600 MB of them) whole-KiB requests measured 3-6 % faster than eight 128-byte row pieces (tools/gemm_lab.hip). */
+    int32_t w_tiled;
 } GaGemmArgs;
 
 int ga_gemm_bf16(const GaGemmArgs *args, void *stream);
@@ -173,6 +177,9 @@ typedef struct GaDitModel {
     const float *final_table;                           /* [2,D]          final_layer.scale_shift_table */
     const float *final_w, *final_b;                     /* [Cout,D], [Cout] final_layer.linear (fp32) */
     const GaDitBlockWeights *blocks;                    /* host array [depth]                          */
+    int32_t gemm_weights_tiled;                         /* 1: every bf16 [N, K] weight that goes through ga_gemm_bf16 (block weights,
+                                                           xe_fc2_w) is stored tiled, see GaGemmArgs.w_tiled; the small-linear
+                                                           weights (t_mlp*, pool_w, adaln_w) stay row-major */
 } GaDitModel;
 
 /* Optional sampler step fused into the final layer (GaDitForwardArgs.step): the Euler update of the reference's fixed-grid

@@ -93,6 +93,33 @@ def test_gemm_is_transpose_sensitive(gpu_device):
     assert torch.equal(out, W.float().T)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(1536, 4096, 1024, "gelu"), (1536, 1024, 4096, "res"), (768, 1024, 1024, "bf16"),
+                                       (1536, 3072, 1024, "bf16"), (200, 264, 192, "f32"), (6144, 1024, 1024, "res")])
+def test_gemm_tiled_weight_image_gives_the_same_bits(gpu_device, M, N, K, epi):
+    """GaGemmArgs.w_tiled (the [N/8][K/64][8][64] image the DiT stores its weights in): only the addresses the LDS-DMA reads
+    from change, so every kernel variant (the three ring tiles and the 2-slot kernel of the small shape) must give the
+    row-major call's bits."""
+    from gaussiananything_amd import dit_ops as ops
+    g = torch.Generator(device="cpu").manual_seed(N + K)
+    A = torch.randn(M, K, generator=g).to(gpu_device).bfloat16()
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(gpu_device).bfloat16()
+    Wt = ops.tile_weight(W)
+    assert Wt.numel() == W.numel() and torch.equal(Wt.reshape(N // 8, K // 64, 8, 64)[3, 1, 5], W[3 * 8 + 5, 64:128])
+    bias = torch.randn(N, generator=g).to(gpu_device)
+    if epi == "res":
+        x0 = torch.randn(M, N, generator=g).to(gpu_device)
+        a, b = x0.clone(), x0.clone()
+        ops.gemm(A, W, bias, ops.EPI_RESIDUAL, out=a)
+        ops.gemm(A, Wt, bias, ops.EPI_RESIDUAL, out=b, w_tiled=True, N=N)
+    else:
+        e = {"gelu": ops.EPI_GELU_BF16, "bf16": ops.EPI_STORE_BF16, "f32": ops.EPI_STORE_F32}[epi]
+        a = ops.gemm(A, W, bias if epi != "f32" else None, e)
+        b = ops.gemm(A, Wt, bias if epi != "f32" else None, e, w_tiled=True, N=N)
+    assert torch.equal(a, b)
+    assert rel_l2(a.float(), (x0 if epi == "res" else 0) + (torch.nn.functional.gelu(A.float() @ W.float().T + bias) if epi == "gelu"
+                                                              else A.float() @ W.float().T + (0 if epi == "f32" else bias))) < 1e-2
+
+
 # norm: "qk" = q and k RMS-normalised in the kernel (register-staged variant), "q" = only q (k arrives normalised from the
 # projection GEMM, as in the DiT forward), "" = neither: the last two run the LDS-DMA variants -- 128-query workgroups when
 # they fill half the chip, else 64-query workgroups with two key groups (ragged last tiles, 1-tile and 1-key inputs included)
