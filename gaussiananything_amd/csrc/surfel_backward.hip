@@ -169,12 +169,20 @@ __device__ __forceinline__ void pair_forward(const float *__restrict__ b, float 
 // col[h][c] says that column c of the tile lies inside entry e's cull box, row[h][r] likewise; a pixel's survivors are
 // col & row, so a lane walks only the entries the forward evaluated for its pixel (4 % of all pairs at BASELINE configs[1]).
 constexpr int kBwdSeg = kBwdChunk;
+#ifndef GA_BWD_ABLATE
+#define GA_BWD_ABLATE 0   // timing-only builds (wrong results): 1 no tail atomics, 2 no phase B, 4 everything takes the former walk, 8 no phase A
+#endif
+#ifndef GA_BWD_PAIR_CAP
+#define GA_BWD_PAIR_CAP 2560
+#endif
+constexpr int kPairCap = GA_BWD_PAIR_CAP;
 
 struct BwdShared {
     float rec[kBRec][kBwdChunk];
     unsigned long long col[2][kTile], row[2][kTile];
     unsigned long long colq[2][2], rowq[2][2];    // union of the masks of the columns / rows 0..7 and 8..15 (a wave = an 8 x 8 quadrant)
     uint32_t id[kBwdChunk];
+    uint32_t wave_area[2];   // survivor pairs of entries 0..63 / 64..127 (sum of the cull rectangles' areas)
 };
 
 struct BwdPlan {   // the segment table and the per-(segment, pixel) exchange arrays, all inside `scratch`
@@ -185,6 +193,8 @@ struct BwdPlan {   // the segment table and the per-(segment, pixel) exchange ar
     float4 *part;           // [max_segs][256]  sums: W', M1', M2', A'; after the second prefix launch: their sums over the earlier segments
     float4 *total;          // [V tiles][256]   W, M1, M2, sum A' of the whole list
     float *Tfinal;          // [V tiles][256]
+    uint32_t *big;          // [1 + 2 max_segs] number and list of the segments whose pairs exceed the gradient kernel's pair table,
+                            // then one word per segment: 1 = it is on that list (both written by the sums launch)
     uint32_t max_segs;
 };
 
@@ -233,6 +243,7 @@ __global__ __launch_bounds__(1024) void surfel_bwd_segtable_kernel(const uint32_
 {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry;
+    if (threadIdx.x == 0) pl.big[0] = 0;
     if (status[GA_STATUS_OVERFLOW]) { if (threadIdx.x == 0) pl.seg_base[vtiles] = 0; return; }
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
@@ -272,10 +283,10 @@ struct SegCtx {
     size_t vbase;
 };
 
-__device__ __forceinline__ bool seg_context(const uint32_t *__restrict__ tile_start, const BwdPlan &pl, const Dims &dm, SegCtx &c)
+__device__ __forceinline__ bool seg_context(const uint32_t *__restrict__ tile_start, const BwdPlan &pl, const Dims &dm, SegCtx &c,
+                                            uint32_t s)
 {
     const int vtiles = dm.V * dm.tiles;
-    const uint32_t s = blockIdx.x;
     if (s >= pl.seg_base[vtiles] || s >= pl.max_segs) return false;
     c.vt = (int)pl.seg_owner[s];
     c.s0 = pl.seg_base[c.vt];
@@ -299,9 +310,11 @@ __device__ __forceinline__ bool seg_context(const uint32_t *__restrict__ tile_st
 }
 
 // stage the segment: records to the field planes (kFields of them), survivor masks of my pixel
+// (xbits / ybits, threads 0..127 only: the tile columns / rows inside the cull box of entry threadIdx.x -- an interval each)
 template <int kFields>
 __device__ __forceinline__ void stage_segment(BwdShared &sh, const SegCtx &c, const uint32_t *__restrict__ point_list,
-                                              const float *__restrict__ brec, unsigned long long &m0, unsigned long long &m1)
+                                              const float *__restrict__ brec, unsigned long long &m0, unsigned long long &m1,
+                                              uint32_t *xbits = nullptr, uint32_t *ybits = nullptr)
 {
     const int se = threadIdx.x & (kBwdChunk - 1), spart = threadIdx.x / kBwdChunk;   // entry, half of its record
     float bx = 0.f, by = 0.f, rx = -1.f, ry = -1.f;   // (an absent entry's box is empty)
@@ -332,13 +345,17 @@ __device__ __forceinline__ void stage_segment(BwdShared &sh, const SegCtx &c, co
         const int h = se >> 6;
         const float ox = bx - (float)(c.tx * kTile), oy = by - (float)(c.ty * kTile);
         unsigned long long cs = 0ull, rs = 0ull;
+        uint32_t xb = 0, yb = 0;
         for (int q = 0; q < kTile; ++q) {
-            const unsigned long long mc = __ballot(fabsf((float)q - ox) <= rx);
-            const unsigned long long mr = __ballot(fabsf((float)q - oy) <= ry);
+            const bool inx = fabsf((float)q - ox) <= rx, iny = fabsf((float)q - oy) <= ry;
+            const unsigned long long mc = __ballot(inx);
+            const unsigned long long mr = __ballot(iny);
+            xb |= (uint32_t)inx << q; yb |= (uint32_t)iny << q;
             cs |= mc; rs |= mr;
             if ((se & 63) == 0) { sh.col[h][q] = mc; sh.row[h][q] = mr; }
             if ((q & 7) == 7) { if ((se & 63) == 0) { sh.colq[h][q >> 3] = cs; sh.rowq[h][q >> 3] = rs; } cs = 0ull; rs = 0ull; }
         }
+        if (xbits) { *xbits = xb; *ybits = yb; }
     }
     __syncthreads();
     m0 = sh.col[0][c.lx] & sh.row[0][c.ly];
@@ -350,7 +367,7 @@ __global__ __launch_bounds__(256) void surfel_bwd_trans_kernel(const uint32_t *_
 {
     __shared__ BwdShared sh;
     SegCtx c;
-    if (!seg_context(tile_start, pl, dm, c)) return;
+    if (!seg_context(tile_start, pl, dm, c, blockIdx.x)) return;
     unsigned long long m[2];
     stage_segment<12>(sh, c, point_list, brec, m[0], m[1]);
     float T = 1.0f;
@@ -425,7 +442,7 @@ __global__ __launch_bounds__(256) void surfel_bwd_sums_kernel(const uint32_t *__
 {
     __shared__ BwdShared sh;
     SegCtx c;
-    if (!seg_context(tile_start, pl, dm, c)) return;
+    if (!seg_context(tile_start, pl, dm, c, blockIdx.x)) return;
     const float kM = kFar / (kFar - kNear);
     float T = pl.Tseg[(size_t)blockIdx.x * 256 + threadIdx.x];   // (T_start since the prefix launch)
     bool done = !c.inside || T < 0.0001f;
@@ -435,7 +452,21 @@ __global__ __launch_bounds__(256) void surfel_bwd_sums_kernel(const uint32_t *__
         PixelGrads pg;
         load_pixel_grads(g_color, g_others, dm, c, pg);
         unsigned long long m[2];
-        stage_segment<kBRec>(sh, c, point_list, brec, m[0], m[1]);
+        uint32_t xb = 0, yb = 0;
+        stage_segment<kBRec>(sh, c, point_list, brec, m[0], m[1], &xb, &yb);
+        // which gradient kernel takes this segment: the pairs the forward evaluated (entry by entry a rectangle of the tile)
+        // against the pair table of surfel_bwd_grad_kernel
+        if (threadIdx.x < kBwdChunk) {
+            uint32_t area = (uint32_t)(__popc(xb) * __popc(yb));
+            for (int o = 32; o > 0; o >>= 1) area += __shfl_xor(area, o, 64);
+            if ((threadIdx.x & 63) == 0) sh.wave_area[threadIdx.x >> 6] = area;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const bool big = sh.wave_area[0] + sh.wave_area[1] > (uint32_t)kPairCap || (GA_BWD_ABLATE & 4);
+            pl.big[1 + pl.max_segs + blockIdx.x] = big ? 1u : 0u;
+            if (big) pl.big[1 + atomicAdd(pl.big, 1u)] = blockIdx.x;
+        }
         for (int h = 0; h < 2; ++h) {
             unsigned long long mm = done ? 0ull : m[h];
             while (mm) {
@@ -459,22 +490,142 @@ __global__ __launch_bounds__(256) void surfel_bwd_sums_kernel(const uint32_t *__
     pl.Tend[slot] = T;
 }
 
-// Two ways to walk a 64-entry half of the segment, chosen per wave from its survivor masks:
-//   lane-major   every lane walks its own survivors and adds its 18 words to the segment's gradient image with LDS atomics:
-//                no idle lanes beyond the spread of the list lengths, but lanes on the same entry serialise on its words;
+// ---- the gradient walk ---------------------------------------------------------------------------------------------------
+// Every contributing (pixel, entry) pair has 18 gradient words that must be summed per entry.  LDS float atomics cannot carry
+// that: ds_add_f32 is executed one lane at a time on gfx950 (tools/lds_atomic_rate.hip: 52 CU cycles for a 64-lane
+// instruction on 64 different addresses, 0.8 per active lane, against 1.4 cycles for ds_add_u32), and with one lane-major walk
+// adding its 18 words per pair they were 510 of the kernel's 810 us at BASELINE configs[1] (in-situ ablation).  So the sums
+// are formed in registers and the kernel has two phases (PAIR-MAJOR path, whenever the segment's pairs fit its LDS table):
+//   A  lanes = pixels, each walks its own survivors in list order -- the part that is sequential per pixel -- and leaves per
+//      pair only T_i (transmittance on entering the pair) and P_i (the running sum of w v up to and including it) in a pair
+//      table.  A pixel's survivors of entry e are exactly the pixels of e's cull box (an axis-aligned rectangle of the tile:
+//      the masks are products of a column and a row interval), so the table is laid out entry by entry, rectangle row-major:
+//      slot = base[e] + (y - y0) w + (x - x0), base = exclusive prefix of the rectangle areas.
+//   B  lanes = table slots (256 per round: no idle lanes whatever the spread of the list lengths).  A lane re-evaluates its pair
+//      from the record and its pixel's constants (LDS), takes T_i and P_i from the table and forms the 18 words; the slots of
+//      an entry are consecutive lanes, so a segmented sum along each row of 16 lanes (4 DPP steps per word) leaves every
+//      entry's total in the last lane of its run, which adds it to the global gradient record (~1.6 runs per entry).
+// Segments with more than kPairCap pairs (large splats) keep the former walk with its LDS gradient image:
+//   lane-major   every lane walks its own survivors and adds its 18 words to the segment's gradient image with LDS atomics;
 //   entry-major  the wave walks the union of its lanes' survivors, all lanes evaluate the same entry (one broadcast record
 //                read), the words are summed across the wave (wave_totals18) and four lanes add the totals: cheaper as soon
-//                as an entry is evaluated by GA_BWD_WAVE_MAJOR_LANES lanes of the wave on average (large splats).
+//                as an entry is evaluated by GA_BWD_WAVE_MAJOR_LANES lanes of the wave on average.
+constexpr int kTailBatch = 8;
+static_assert(kGRec == 18 && kTailBatch * kGRec <= 144, "(i * 3641) >> 16 == i / 18 was checked for i < 144");
+constexpr int kPixFields = 13;   // gC(3) gN(3) gD gDist | W M1 M2 Vtot | T_final (gC.bg - gA)
+
+struct PairShared {
+    float pix[kPixFields][256];       // per-pixel constants, pixel = ly * 16 + lx
+    float pT[kPairCap], pP[kPairCap];
+    uint32_t desc[kBwdChunk];         // per entry: base | x0 << 16 | y0 << 20 | w << 24 (w = 0: empty box)
+    unsigned char pE[kPairCap];       // entry of a slot
+    uint32_t wave_area[2];
+    float tails[4][kTailBatch][kGRec];   // per wave: run totals on their way to the global record
+    uint32_t tail_id[4][kTailBatch];
+};
+
+struct PixC { float gC[3], gN[3], gD, gDist, W, M1, M2, Vtot, Tfb; };
+struct PairV { float w, mz, rd, vi; };
+
+__device__ __forceinline__ PairV pair_value(const float *__restrict__ b, const PairFwd &f, float T, const PixC &pc)
+{
+    const float kM = kFar / (kFar - kNear);
+    PairV o;
+    o.rd = __builtin_amdgcn_rcpf(f.depth);
+    o.w = f.alpha * T;
+    o.mz = kM * (1.0f - kNear * o.rd);
+    const float Dq = o.mz * o.mz * pc.W - 2.0f * o.mz * pc.M1 + pc.M2;
+    o.vi = (pc.gC[0] * GA_BF(15) + pc.gC[1] * GA_BF(16) + pc.gC[2] * GA_BF(17)) +
+           (pc.gN[0] * GA_BF(12) + pc.gN[1] * GA_BF(13) + pc.gN[2] * GA_BF(14)) + pc.gD * f.depth + pc.gDist * Dq;
+    return o;
+}
+
+// the 18 gradient words of one contributing pair; P = sum of w v up to and including this pair
+__device__ __forceinline__ void pair_words(const PairFwd &f, const PairV &v, float T, float P, const PixC &pc, float pxf, float pyf,
+                                           float *cw)
+{
+    const float kM = kFar / (kFar - kNear);
+    const float inv1ma = __builtin_amdgcn_rcpf(1.0f - f.alpha);
+    const float dL_dalpha = T * v.vi - (pc.Vtot - P) * inv1ma - pc.Tfb * inv1ma;
+    const float dL_ddepth = v.w * pc.gD + 2.0f * pc.gDist * v.w * (v.mz * pc.W - pc.M1) * (kM * kNear * v.rd * v.rd);
+    for (int q = 0; q < 3; ++q) { cw[15 + q] = v.w * pc.gC[q]; cw[12 + q] = v.w * pc.gN[q]; }
+    const float dL_draw = f.raw > 0.99f ? 0.0f : dL_dalpha;       // the clamp carries no gradient
+    cw[11] = f.G * dL_draw;
+    const float dL_drho = -0.5f * f.raw * dL_draw;
+    float dsx = 0.f, dsy = 0.f, dTw[3] = {0.f, 0.f, dL_ddepth};
+    cw[9] = 0.f; cw[10] = 0.f;
+    if (f.use3d) {
+        dsx = 2.0f * f.sx * dL_drho + dL_ddepth * f.Tw[0];
+        dsy = 2.0f * f.sy * dL_drho + dL_ddepth * f.Tw[1];
+        dTw[0] = dL_ddepth * f.sx; dTw[1] = dL_ddepth * f.sy;
+    } else {
+        cw[9] = 2.0f * kFilterInvSquare * f.dxc * dL_drho;
+        cw[10] = 2.0f * kFilterInvSquare * f.dyc * dL_drho;
+    }
+    // s = p.xy / p.z ; p = k x l ; k = px Tw - Tu ; l = py Tw - Tv
+    const float ipz = f.rz;
+    const float gp[3] = {dsx * ipz, dsy * ipz, -(dsx * f.sx + dsy * f.sy) * ipz};
+    const float dk[3] = {f.l[1] * gp[2] - f.l[2] * gp[1], f.l[2] * gp[0] - f.l[0] * gp[2], f.l[0] * gp[1] - f.l[1] * gp[0]};
+    const float dl[3] = {gp[1] * f.k[2] - gp[2] * f.k[1], gp[2] * f.k[0] - gp[0] * f.k[2], gp[0] * f.k[1] - gp[1] * f.k[0]};
+    for (int q = 0; q < 3; ++q) {
+        cw[q] = -dk[q];
+        cw[3 + q] = -dl[q];
+        cw[6 + q] = dTw[q] + pxf * dk[q] + pyf * dl[q];
+    }
+}
+
+template <int kCtrl>
+__device__ __forceinline__ int dpp_row_i(int v)
+{
+    return __builtin_amdgcn_mov_dpp(v, kCtrl, 0xf, 0xf, true);
+}
+// One step of the segmented inclusive sum along a row of 16 lanes: lanes whose neighbour kShr to the left holds the same key
+// add its partial sums (keys are runs of equal values; a lane shifted in from outside the row reads key 0 and value 0).
+// One v_fmac_f32 with a DPP source per word: acc += neighbour(acc) * same, same = 1.0 / 0.0 (the values are finite).
+// (inline assembly, one statement per step: hipcc does not fold the DPP move into the multiply-add.  Inside the statement
+// every word is read 19 instructions after the previous step wrote it; the s_nop in front covers the two wait states a DPP
+// read needs after a VALU write for whatever the compiler placed before the statement -- the hazard recogniser does not look
+// inside it)
+#define GA_SEG_STEP(SHR)                                                                                     \
+    do {                                                                                                    \
+        const float same_ = dpp_row_i<0x110 + SHR>(key) == key ? 1.0f : 0.0f;                               \
+        asm("s_nop 1\n\t"                                                                                   \
+            "v_fmac_f32_dpp %0, %0, %19 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"        \
+            "v_fmac_f32_dpp %1, %1, %19 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"        \
+            "v_fmac_f32_dpp %2, %2, %19 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"        \
+            "v_fmac_f32_dpp %3, %3, %19 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"        \
+            "v_fmac_f32_dpp %4, %4, %19 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"        \
+            "v_fmac_f32_dpp %5, %5, %19 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"        \
+            "v_fmac_f32_dpp %6, %6, %19 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"        \
+            "v_fmac_f32_dpp %7, %7, %19 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"        \
+            "v_fmac_f32_dpp %8, %8, %19 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"        \
+            "v_fmac_f32_dpp %9, %9, %19 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"        \
+            "v_fmac_f32_dpp %10, %10, %19 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"      \
+            "v_fmac_f32_dpp %11, %11, %19 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"      \
+            "v_fmac_f32_dpp %12, %12, %19 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"      \
+            "v_fmac_f32_dpp %13, %13, %19 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"      \
+            "v_fmac_f32_dpp %14, %14, %19 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"      \
+            "v_fmac_f32_dpp %15, %15, %19 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"      \
+            "v_fmac_f32_dpp %16, %16, %19 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"      \
+            "v_fmac_f32_dpp %17, %17, %19 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"      \
+            "v_fmac_f32_dpp %18, %18, %19 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"      \
+            : "+v"(cw[0]), "+v"(cw[1]), "+v"(cw[2]), "+v"(cw[3]), "+v"(cw[4]), "+v"(cw[5]), "+v"(cw[6]), "+v"(cw[7]), "+v"(cw[8]), "+v"(cw[9]), "+v"(cw[10]), "+v"(cw[11]), "+v"(cw[12]), "+v"(cw[13]), "+v"(cw[14]), "+v"(cw[15]), "+v"(cw[16]), "+v"(cw[17]), "+v"(cnt) \
+            : "v"(same_));                                                                                  \
+    } while (0)
+static_assert(kGRec == 18, "GA_SEG_STEP names the 18 words and the count");
+#define GA_LDS_ORDER() asm volatile("" ::: "memory")   // DS operations of one wave reach the LDS in program order
+
 __global__ __launch_bounds__(256) void surfel_bwd_grad_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
                                                               const float *__restrict__ brec, const float *__restrict__ bg, Dims dm, BwdPlan pl,
                                                               const float *__restrict__ g_color, const float *__restrict__ g_others,
                                                               float *__restrict__ grec)
 {
     __shared__ BwdShared sh;
-    __shared__ float sgrad[kBwdChunk][kGRec + 1];   // (+1: the 18 words of neighbouring entries start in different banks)
+    __shared__ PairShared pr;
     SegCtx c;
-    if (!seg_context(tile_start, pl, dm, c)) return;
-    const float kM = kFar / (kFar - kNear);
+    if (!seg_context(tile_start, pl, dm, c, blockIdx.x)) return;
+    // (written by the sums launch for every segment it walked; a segment it skipped -- every pixel finished -- is skipped here as well)
+    if (pl.big[1 + pl.max_segs + blockIdx.x] != 0u) return;
     // my pixel's state on entering the segment, and the totals of its whole walk
     const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
     float T = pl.Tseg[slot];
@@ -482,53 +633,181 @@ __global__ __launch_bounds__(256) void surfel_bwd_grad_kernel(const uint32_t *__
     if (__syncthreads_and(done)) return;
     const float4 pre = pl.part[slot], tot = pl.total[(size_t)c.vt * 256 + threadIdx.x];
     const float T_final = pl.Tfinal[(size_t)c.vt * 256 + threadIdx.x];
-    const float W = tot.x, M1 = tot.y, M2 = tot.z, Aall = tot.w, Wp = pre.x, M1p = pre.y, M2p = pre.z, Ap = pre.w;
-    PixelGrads pg;
-    load_pixel_grads(g_color, g_others, dm, c, pg);
-    const float Vtot = Aall + 2.0f * pg.gDist * (W * M2 - M1 * M1);
-    float P = Ap + pg.gDist * (W * M2p - 2.0f * M1 * M1p + M2 * Wp);
-    const float bgterm = (pg.gC[0] * bg[0] + pg.gC[1] * bg[1] + pg.gC[2] * bg[2]) - pg.gA;
+    PixC pc;
+    {
+        PixelGrads pg;
+        load_pixel_grads(g_color, g_others, dm, c, pg);
+        for (int q = 0; q < 3; ++q) { pc.gC[q] = pg.gC[q]; pc.gN[q] = pg.gN[q]; }
+        pc.gD = pg.gD; pc.gDist = pg.gDist;
+        pc.W = tot.x; pc.M1 = tot.y; pc.M2 = tot.z;
+        pc.Vtot = tot.w + 2.0f * pg.gDist * (tot.x * tot.z - tot.y * tot.y);
+        pc.Tfb = T_final * ((pg.gC[0] * bg[0] + pg.gC[1] * bg[1] + pg.gC[2] * bg[2]) - pg.gA);
+    }
+    float P = pre.w + pc.gDist * (pc.W * pre.z - 2.0f * pc.M1 * pre.y + pc.M2 * pre.x);
+    unsigned long long m[2];
+    uint32_t xb = 0, yb = 0;
+    stage_segment<kBRec>(sh, c, point_list, brec, m[0], m[1], &xb, &yb);
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float pxf = c.pxf, pyf = c.pyf;
+
+    // the entries' rectangles and their places in the pair table (threads 0..127 = entries)
+    uint32_t area = 0, incl = 0;
+    if (threadIdx.x < kBwdChunk) {
+        area = (uint32_t)(__popc(xb) * __popc(yb));
+        incl = area;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) pr.wave_area[wv] = incl;
+    }
+    __syncthreads();
+    const uint32_t total = pr.wave_area[0] + pr.wave_area[1];
+
+    if (total > (uint32_t)kPairCap) return;   // (cannot happen: those segments are on the other kernel's list)
+    {
+        if (threadIdx.x < kBwdChunk) {
+            const uint32_t base = incl - area + (wv == 1 ? pr.wave_area[0] : 0u);
+            const uint32_t w = (uint32_t)__popc(xb);
+            pr.desc[threadIdx.x] = base | (area ? ((uint32_t)__builtin_ctz(xb) << 16) | ((uint32_t)__builtin_ctz(yb) << 20) | (w << 24) : 0u);
+            for (uint32_t q = 0; q < area; ++q) { pr.pE[base + q] = (unsigned char)threadIdx.x; pr.pT[base + q] = 0.0f; }
+        }
+        {
+            const int pix = c.ly * kTile + c.lx;
+            const float vals[kPixFields] = {pc.gC[0], pc.gC[1], pc.gC[2], pc.gN[0], pc.gN[1], pc.gN[2], pc.gD, pc.gDist,
+                                            pc.W, pc.M1, pc.M2, pc.Vtot, pc.Tfb};
+#pragma unroll
+            for (int q = 0; q < kPixFields; ++q) pr.pix[q][pix] = vals[q];
+        }
+        __syncthreads();
+        // A: my pixel's walk
+        for (int h = 0; h < 2; ++h) {
+            unsigned long long mm = (done || (GA_BWD_ABLATE & 8)) ? 0ull : m[h];
+            while (mm) {
+                const int e = __builtin_ctzll(mm) + 64 * h;
+                mm &= mm - 1;
+                const float *b = &sh.rec[0][e];
+                PairFwd f;
+                pair_forward(b, pxf, pyf, f);
+                if (!f.ok) continue;
+                const float test_T = T * (1.0f - f.alpha);
+                if (test_T < 0.0001f) { done = true; break; }
+                const PairV v = pair_value(b, f, T, pc);
+                P += v.w * v.vi;
+                const uint32_t d = pr.desc[e];
+                const uint32_t s2 = (d & 0xffffu) + ((uint32_t)c.ly - ((d >> 20) & 15u)) * (d >> 24) + ((uint32_t)c.lx - ((d >> 16) & 15u));
+                pr.pT[s2] = T;
+                pr.pP[s2] = P;
+                T = test_T;
+            }
+        }
+        __syncthreads();
+        if (GA_BWD_ABLATE & 2) return;
+        // B: one lane per slot
+        const float tx0 = (float)(c.tx * kTile), ty0 = (float)(c.ty * kTile);
+        for (uint32_t p0 = 0; p0 < total; p0 += 256) {
+            const uint32_t p = p0 + threadIdx.x;
+            const bool valid = p < total;
+            const int e = valid ? (int)pr.pE[p] : 0;
+            const float Ti = valid ? pr.pT[p] : 0.0f;
+            const bool on = Ti > 0.0f;     // (a contributing pair was entered with T >= 1e-4)
+            float cw[kGRec];
+#pragma unroll
+            for (int q = 0; q < kGRec; ++q) cw[q] = 0.0f;
+            if (__ballot(on) == 0ull) continue;     // (runs of entries behind the surface: nothing in these 64 slots)
+            if (on) {
+                const uint32_t d = pr.desc[e];
+                const uint32_t r = p - (d & 0xffffu), w = d >> 24;
+                // r / w for r < 256, w <= 16: (r + 0.5) / w is at least 1/32 away from an integer, v_rcp_f32 is good to 1 ulp
+                const uint32_t yy = (uint32_t)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)w));
+                const uint32_t lx = ((d >> 16) & 15u) + (r - yy * w), ly = ((d >> 20) & 15u) + yy;
+                const int pix = (int)(ly * kTile + lx);
+                PixC q;
+                q.gC[0] = pr.pix[0][pix]; q.gC[1] = pr.pix[1][pix]; q.gC[2] = pr.pix[2][pix];
+                q.gN[0] = pr.pix[3][pix]; q.gN[1] = pr.pix[4][pix]; q.gN[2] = pr.pix[5][pix];
+                q.gD = pr.pix[6][pix]; q.gDist = pr.pix[7][pix]; q.W = pr.pix[8][pix]; q.M1 = pr.pix[9][pix];
+                q.M2 = pr.pix[10][pix]; q.Vtot = pr.pix[11][pix]; q.Tfb = pr.pix[12][pix];
+                const float qx = tx0 + (float)lx, qy = ty0 + (float)ly;
+                const float *b = &sh.rec[0][e];
+                PairFwd f;
+                pair_forward(b, qx, qy, f);    // (the same arithmetic on the same operands as in A: f.ok holds again)
+                const PairV v = pair_value(b, f, Ti, q);
+                pair_words(f, v, Ti, pr.pP[p], q, qx, qy, cw);
+            }
+            const int key = valid ? e + 1 : 0;
+            float cnt = on ? 1.0f : 0.0f;       // (a 19th word: does the run hold a contributing pair at all)
+            GA_SEG_STEP(1);
+            GA_SEG_STEP(2);
+            GA_SEG_STEP(4);
+            GA_SEG_STEP(8);
+            // the last lane of a run holds its totals.  One lane adding its 18 words to the global record is 18 separate
+            // requests to the L2's atomic units (measured: 585 us per launch); so the totals go through a small per-wave LDS
+            // buffer, kTailBatch runs at a time, and leave as one atomic per lane on consecutive words -- the coalesced form
+            // the former per-segment flush has.
+            const bool tail = valid && cnt > 0.0f && dpp_row_i<0x101>(key) != key;   // row_shl:1 (0 past the end of the row)
+            const unsigned long long tm = __ballot(tail);
+            const int nt = __popcll(tm);
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(tm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm, 0u));
+            for (int b0 = 0; b0 < nt && !(GA_BWD_ABLATE & 1); b0 += kTailBatch) {
+                if (tail && rank >= b0 && rank < b0 + kTailBatch) {
+#pragma unroll
+                    for (int q = 0; q < kGRec; ++q) pr.tails[wv][rank - b0][q] = cw[q];
+                    pr.tail_id[wv][rank - b0] = sh.id[e];
+                }
+                GA_LDS_ORDER();
+                const int nw = min(kTailBatch, nt - b0) * kGRec;
+                for (int i = lane; i < nw; i += 64) {
+                    const int r = (i * 3641) >> 16, q = i - r * kGRec;      // i / 18 for i < 18 kTailBatch
+                    const float val = pr.tails[wv][r][q];
+                    if (val != 0.0f) atomicAdd(grec + (c.vbase + pr.tail_id[wv][r]) * kGRec + q, val);
+                }
+                GA_LDS_ORDER();
+            }
+            if ((GA_BWD_ABLATE & 1) && tail) { float z = 0.f; for (int q = 0; q < kGRec; ++q) z += cw[q]; if (z == 123.4f) grec[0] = z; }
+        }
+    }
+}
+
+// The segments the pair table cannot hold (listed in pl.big by the kernel above): the walk with an LDS gradient image of the
+// segment.  (A kernel of its own: its 24 KB of LDS allow four workgroups per CU, the pair table's 52 KB three.)
+__global__ __launch_bounds__(256) void surfel_bwd_grad_big_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+                                                                  const float *__restrict__ brec, const float *__restrict__ bg, Dims dm, BwdPlan pl,
+                                                                  const float *__restrict__ g_color, const float *__restrict__ g_others,
+                                                                  float *__restrict__ grec)
+{
+    __shared__ BwdShared sh;
+    __shared__ float sgrad[kBwdChunk][kGRec + 1];   // (+1: the 18 words of neighbouring entries start in different banks)
+    if (blockIdx.x >= pl.big[0]) return;
+    const uint32_t seg = pl.big[1 + blockIdx.x];
+    SegCtx c;
+    if (!seg_context(tile_start, pl, dm, c, seg)) return;
+    // my pixel's state on entering the segment, and the totals of its whole walk
+    const size_t slot = (size_t)seg * 256 + threadIdx.x;
+    float T = pl.Tseg[slot];
+    bool done = !c.inside || T < 0.0001f;
+    if (__syncthreads_and(done)) return;
+    const float4 pre = pl.part[slot], tot = pl.total[(size_t)c.vt * 256 + threadIdx.x];
+    const float T_final = pl.Tfinal[(size_t)c.vt * 256 + threadIdx.x];
+    PixC pc;
+    {
+        PixelGrads pg;
+        load_pixel_grads(g_color, g_others, dm, c, pg);
+        for (int q = 0; q < 3; ++q) { pc.gC[q] = pg.gC[q]; pc.gN[q] = pg.gN[q]; }
+        pc.gD = pg.gD; pc.gDist = pg.gDist;
+        pc.W = tot.x; pc.M1 = tot.y; pc.M2 = tot.z;
+        pc.Vtot = tot.w + 2.0f * pg.gDist * (tot.x * tot.z - tot.y * tot.y);
+        pc.Tfb = T_final * ((pg.gC[0] * bg[0] + pg.gC[1] * bg[1] + pg.gC[2] * bg[2]) - pg.gA);
+    }
+    float P = pre.w + pc.gDist * (pc.W * pre.z - 2.0f * pc.M1 * pre.y + pc.M2 * pre.x);
     for (uint32_t w = threadIdx.x; w < kBwdChunk * (kGRec + 1); w += 256) (&sgrad[0][0])[w] = 0.0f;
     unsigned long long m[2];
     stage_segment<kBRec>(sh, c, point_list, brec, m[0], m[1]);   // (its barriers also publish the cleared gradient image)
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float pxf = c.pxf, pyf = c.pyf;
-
-    // one contributing (pixel, entry) pair: the 18 gradient words in cw[]
     auto pair_grad = [&](const float *b, const PairFwd &f, float test_T, float *cw) {
-        const float rd = __builtin_amdgcn_rcpf(f.depth);
-        const float w = f.alpha * T, mz = kM * (1.0f - kNear * rd);
-        const float Dq = mz * mz * W - 2.0f * mz * M1 + M2;
-        const float vi = (pg.gC[0] * GA_BF(15) + pg.gC[1] * GA_BF(16) + pg.gC[2] * GA_BF(17)) +
-                         (pg.gN[0] * GA_BF(12) + pg.gN[1] * GA_BF(13) + pg.gN[2] * GA_BF(14)) + pg.gD * f.depth + pg.gDist * Dq;
-        P += w * vi;
-        const float inv1ma = __builtin_amdgcn_rcpf(1.0f - f.alpha);
-        const float dL_dalpha = T * vi - (Vtot - P) * inv1ma - T_final * bgterm * inv1ma;
-        const float dL_ddepth = w * pg.gD + 2.0f * pg.gDist * w * (mz * W - M1) * (kM * kNear * rd * rd);
-        for (int q = 0; q < 3; ++q) { cw[15 + q] = w * pg.gC[q]; cw[12 + q] = w * pg.gN[q]; }
-        const float dL_draw = f.raw > 0.99f ? 0.0f : dL_dalpha;       // the clamp carries no gradient
-        cw[11] = f.G * dL_draw;
-        const float dL_drho = -0.5f * f.raw * dL_draw;
-        float dsx = 0.f, dsy = 0.f, dTw[3] = {0.f, 0.f, dL_ddepth};
-        cw[9] = 0.f; cw[10] = 0.f;
-        if (f.use3d) {
-            dsx = 2.0f * f.sx * dL_drho + dL_ddepth * f.Tw[0];
-            dsy = 2.0f * f.sy * dL_drho + dL_ddepth * f.Tw[1];
-            dTw[0] = dL_ddepth * f.sx; dTw[1] = dL_ddepth * f.sy;
-        } else {
-            cw[9] = 2.0f * kFilterInvSquare * f.dxc * dL_drho;
-            cw[10] = 2.0f * kFilterInvSquare * f.dyc * dL_drho;
-        }
-        // s = p.xy / p.z ; p = k x l ; k = px Tw - Tu ; l = py Tw - Tv
-        const float ipz = f.rz;
-        const float gp[3] = {dsx * ipz, dsy * ipz, -(dsx * f.sx + dsy * f.sy) * ipz};
-        const float dk[3] = {f.l[1] * gp[2] - f.l[2] * gp[1], f.l[2] * gp[0] - f.l[0] * gp[2], f.l[0] * gp[1] - f.l[1] * gp[0]};
-        const float dl[3] = {gp[1] * f.k[2] - gp[2] * f.k[1], gp[2] * f.k[0] - gp[0] * f.k[2], gp[0] * f.k[1] - gp[1] * f.k[0]};
-        for (int q = 0; q < 3; ++q) {
-            cw[q] = -dk[q];
-            cw[3 + q] = -dl[q];
-            cw[6 + q] = dTw[q] + pxf * dk[q] + pyf * dl[q];
-        }
+        const PairV v = pair_value(b, f, T, pc);
+        P += v.w * v.vi;
+        pair_words(f, v, T, P, pc, pxf, pyf, cw);
         T = test_T;
     };
 
@@ -671,9 +950,9 @@ __global__ __launch_bounds__(256) void surfel_preprocess_bwd_kernel(const float 
 
 namespace ga {
 
-// `scratch`: brec | grec | seg_base | seg_owner | Tseg | Tend | part | totals | Tfinal (every section 256-byte aligned)
+// `scratch`: brec | grec | seg_base | seg_owner | Tseg | Tend | part | totals | Tfinal | big (every section 256-byte aligned)
 struct BwdScratch {
-    size_t brec, grec, seg_base, seg_owner, Tseg, Tend, part, totals, Tfinal, total;
+    size_t brec, grec, seg_base, seg_owner, Tseg, Tend, part, totals, Tfinal, big, total;
     uint32_t max_segs;
 };
 
@@ -694,6 +973,7 @@ static bool bwd_scratch_layout(int64_t N, int64_t V, int64_t tiles, int64_t capa
     o.part = take((size_t)segs * 256 * 16);
     o.totals = take((size_t)V * tiles * 256 * 16);
     o.Tfinal = take((size_t)V * tiles * 256 * 4);
+    o.big = take((size_t)(2 * segs + 1) * 4);
     o.total = off;
     return true;
 }
@@ -744,6 +1024,7 @@ extern "C" int ga_surfel_backward(const GaSurfelBackwardArgs *a, void *stream_v)
     pl.part = reinterpret_cast<float4 *>(sp + sc.part);
     pl.total = reinterpret_cast<float4 *>(sp + sc.totals);
     pl.Tfinal = reinterpret_cast<float *>(sp + sc.Tfinal);
+    pl.big = reinterpret_cast<uint32_t *>(sp + sc.big);
     pl.max_segs = sc.max_segs;
     (void)hipMemsetAsync(a->grad_means3D, 0, (size_t)d.N * 3 * 4, s);
     (void)hipMemsetAsync(a->grad_opacities, 0, (size_t)d.N * 4, s);
@@ -763,6 +1044,8 @@ extern "C" int ga_surfel_backward(const GaSurfelBackwardArgs *a, void *stream_v)
                        a->grad_others);
     hipLaunchKernelGGL(surfel_bwd_prefix_sums_kernel, dim3((unsigned)(d.V * d.tiles)), dim3(256), 0, s, tile_start, pl, d.V * d.tiles);
     hipLaunchKernelGGL(surfel_bwd_grad_kernel, gridS, dim3(256), 0, s, tile_start, point_list, brec, f.bg, d, pl,
+                       a->grad_color, a->grad_others, grec);
+    hipLaunchKernelGGL(surfel_bwd_grad_big_kernel, gridS, dim3(256), 0, s, tile_start, point_list, brec, f.bg, d, pl,
                        a->grad_color, a->grad_others, grec);
     hipLaunchKernelGGL(surfel_preprocess_bwd_kernel, gridN, dim3(256), 0, s, f.means3D, f.scales, f.rotations, f.viewmatrix,
                        f.projmatrix, f.scale_modifier, d, f.radii, grec, a->grad_means3D, a->grad_opacities, a->grad_colors,

@@ -186,7 +186,7 @@ __device__ __forceinline__ void composite(const Rec &r, const Alpha &e, PixelAcc
 }
 
 struct Stats {
-    unsigned iters, chunks, useful;
+    unsigned iters, chunks, useful, lanemax;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -370,6 +370,7 @@ __device__ __forceinline__ void consume(Ring &ring, const Consumer &c, uint32_t 
     };
 
     uint32_t i = 0;
+    unsigned mine = 0;   // (statistics) entries of my own list
     for (; i < nch; ++i) {
         if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
         if (WRAP && duty.next == i + 4 && duty.next < nch) duty_stage(ring, duty, c.lane, nch);
@@ -380,6 +381,7 @@ __device__ __forceinline__ void consume(Ring &ring, const Consumer &c, uint32_t 
         nxt = done ? 0ull : (mx & my);
         if (flags & GA_SURFEL_FLAG_STATS) {
             unsigned pc = __builtin_popcountll(nxt);
+            mine += pc;
             for (int o = 32; o > 0; o >>= 1) pc += __shfl_xor(pc, o, 64);
             st.useful += pc;
         }
@@ -393,6 +395,10 @@ __device__ __forceinline__ void consume(Ring &ring, const Consumer &c, uint32_t 
         }
     }
     trips((int)((i + kItemChunks - 1) % kItemChunks) * 64, 0);  // drain: `cur` is the last fetched chunk, `nxt` is empty
+    if (flags & GA_SURFEL_FLAG_STATS) {
+        for (int o = 32; o > 0; o >>= 1) mine = max(mine, (unsigned)__shfl_xor(mine, o, 64));
+        st.lanemax += mine;
+    }
     if (WRAP) {
         GA_LDS_ORDER();
         if (c.lane == 0) lds_store(&ring.done[c.quad], kGone);
@@ -674,6 +680,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
         atomicMax(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_MAX_ITERS), (unsigned long long)st.iters);
         atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_LANE_SLOTS), (unsigned long long)st.useful);
         atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_CHUNKS), (unsigned long long)st.chunks);
+        atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_LANE_MAX), (unsigned long long)st.lanemax);
     }
 }
 

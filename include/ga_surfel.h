@@ -46,6 +46,8 @@ extern "C" {
 #define GA_STATUS_BLEND_LANE_SLOTS 8 /* with GA_SURFEL_FLAG_STATS: (pixel, pair) evaluations that had work (of 64 x BLEND_ITERS) */
 #define GA_STATUS_SEG_WORK 9      /* (tile, segment) work items of the segmented tiles (internal)                      */
 #define GA_STATUS_SEG_TICKET 10   /* next segment work item to hand out (internal)                                     */
+#define GA_STATUS_BLEND_LANE_MAX 11 /* with GA_SURFEL_FLAG_STATS: sum over (wave, work item, pass) of the LONGEST per-pixel survivor
+                                     list of the wave: what BLEND_ITERS would be if the 64 pixels did not wait for each other */
 #define GA_STATUS_WORDS 16
 
 typedef struct GaSurfelForwardArgs {

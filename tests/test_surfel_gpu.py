@@ -428,6 +428,13 @@ def test_backward_many_small_surfels_long_lists(gpu_device):
     _backward_case(gpu_device, 400, 40, 40, [0], seed=9, scale_lo=0.002, scale_hi=0.05, spread=0.25)
 
 
+def test_backward_many_large_surfels_take_the_walk_with_the_lds_gradient_image(gpu_device):
+    """60 surfels that each cover most of a 32 x 32 image: 60 x ~256 pairs per tile, more than the pair table of the gradient
+    kernel holds (kPairCap = 2560), so this is the former walk -- entry-major waves with the cross-lane sums -- while the six
+    surfels of the small scene (at most 6 x 256 pairs) always take the pair-major path."""
+    _backward_case(gpu_device, 60, 32, 32, [2], seed=11, scale_lo=0.08, scale_hi=0.2, spread=0.2)
+
+
 def test_rasterizer_module_is_differentiable(gpu_device):
     """The reference's call sequence (nsr/gs_surfel.py:85-114) with tensors that require grad: gradients arrive."""
     from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
