@@ -10,8 +10,8 @@
 // Launches (all on the caller's stream, nothing allocated):
 //   1. surfel_bwd_record_kernel      per (view, Gaussian): the forward's per-splat quantities once more -- Tu, Tv, Tw, the
 //      screen-space centre, the camera-facing normal, opacity, colour, the forward's cull half-extents -- as a 24-float record;
-//   2. surfel_bwd_segtable_kernel    every tile's depth-ordered list cut into 128-entry segments: first segment of each tile,
-//      owner of each segment;
+//   2. (one extra workgroup of the same launch) every tile's depth-ordered list cut into 128-entry segments: first segment of
+//      each tile, owner of each segment;
 //   3. the blend backward, ONE WORKGROUP PER SEGMENT in each of three launches (see the comment above BwdShared) with a
 //      one-workgroup-per-tile prefix launch after the first two: surfel_bwd_trans_kernel, surfel_bwd_prefix_T_kernel,
 //      surfel_bwd_sums_kernel, surfel_bwd_prefix_sums_kernel, surfel_bwd_grad_kernel.  Per contributing (pixel, entry) pair
@@ -21,9 +21,9 @@
 //      and from them the gradients of opacity, colour, normal, centre and of Tu / Tv / Tw through
 //      p = (px Tw - Tu) x (py Tw - Tv); the 18 gradient words of an entry are accumulated in LDS per segment and flushed
 //      with one global atomic per word and (segment, entry);
-//   4. surfel_preprocess_bwd_kernel  per (view, Gaussian): through M = Hm P N_pix (and the bounding-box centre formula for the
-//      low-pass filter's centre), the view rotation of the normal and the normalised quaternion to means3D, scales, rotations,
-//      opacities and colours, summed over the views with atomics.
+//   4. surfel_preprocess_bwd_kernel  per Gaussian, summed over the views in registers: through M = Hm P N_pix (and the bounding-box
+//      centre formula for the low-pass filter's centre), the view rotation of the normal and the normalised quaternion to means3D,
+//      scales, rotations, opacities and colours.
 #include <hip/hip_fp16.h>
 
 #include "surfel_common.h"
@@ -88,14 +88,74 @@ __device__ __forceinline__ void splat_forward(const float *__restrict__ means3D,
     o.cy = inv * (t[0] * o.Tv[0] * o.Tw[0] + t[1] * o.Tv[1] * o.Tw[1] + t[2] * o.Tv[2] * o.Tw[2]);
 }
 
-__global__ __launch_bounds__(256) void surfel_bwd_record_kernel(const float *__restrict__ means3D, const float *__restrict__ opacities,
-                                                                const float *__restrict__ colors, const float *__restrict__ scales,
-                                                                const float *__restrict__ rotations, const float *__restrict__ viewmatrix,
-                                                                const float *__restrict__ projmatrix, float scale_modifier, Dims dm,
-                                                                const int32_t *__restrict__ radii, const float *__restrict__ fwd_record,
-                                                                float *__restrict__ brec, float *__restrict__ grec)
+constexpr int kBwdSeg = 128;   // list entries per segment (= kBwdChunk, the LDS image of the segment kernels)
+
+struct BwdPlan {   // the segment table and the per-(segment, pixel) exchange arrays, all inside `scratch`
+    uint32_t *seg_base;     // [V tiles + 1] first segment of every tile's list; the last word is the number of segments
+    uint32_t *seg_owner;    // [max_segs] the (view, tile) a segment belongs to
+    float *Tseg;            // [max_segs][256]  trans: T_seg; after the first prefix launch: T_start
+    float *Tend;            // [max_segs][256]
+    float4 *part;           // [max_segs][256]  sums: W', M1', M2', A'; after the second prefix launch: their sums over the earlier segments
+    float4 *total;          // [V tiles][256]   W, M1, M2, sum A' of the whole list
+    float *Tfinal;          // [V tiles][256]
+    uint32_t *big;          // [1 + 2 max_segs] number and list of the segments whose pairs exceed the gradient kernel's pair table,
+                            // then one word per segment: 1 = it is on that list (both written by the sums launch)
+    uint32_t max_segs;
+};
+
+// number of segments of every tile's list, their exclusive prefix and the owner of every segment (one workgroup)
+__device__ __forceinline__ void bwd_segtable(const uint32_t *__restrict__ tile_start, int vtiles, const BwdPlan &pl,
+                                             const int64_t *__restrict__ status)
 {
-    const int v = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) pl.big[0] = 0;
+    if (status[GA_STATUS_OVERFLOW]) { if (threadIdx.x == 0) pl.seg_base[vtiles] = 0; return; }
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int base = 0; base < vtiles; base += 1024) {
+        const int vt = base + (int)threadIdx.x;
+        uint32_t n = 0;
+        if (vt < vtiles) n = (tile_start[vt + 1] - tile_start[vt] + kBwdSeg - 1) / kBwdSeg;
+        uint32_t inc = n;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wave_tot[wv] = inc;
+        __syncthreads();
+        uint32_t off = carry;
+        for (int w = 0; w < wv; ++w) off += wave_tot[w];
+        const uint32_t first = off + inc - n;
+        if (vt < vtiles) {
+            pl.seg_base[vt] = first;
+            for (uint32_t j = 0; j < n; ++j)
+                if (first + j < pl.max_segs) pl.seg_owner[first + j] = (uint32_t)vt;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = off + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) pl.seg_base[vtiles] = carry;
+}
+
+
+// (grid row V: workgroup 0 builds the segment table -- a serial 20 us that would otherwise be a launch of its own)
+__global__ __launch_bounds__(1024) void surfel_bwd_record_kernel(const float *__restrict__ means3D, const float *__restrict__ opacities,
+                                                                 const float *__restrict__ colors, const float *__restrict__ scales,
+                                                                 const float *__restrict__ rotations, const float *__restrict__ viewmatrix,
+                                                                 const float *__restrict__ projmatrix, float scale_modifier, Dims dm,
+                                                                 const int32_t *__restrict__ radii, const float *__restrict__ fwd_record,
+                                                                 float *__restrict__ brec, float *__restrict__ grec,
+                                                                 const uint32_t *__restrict__ tile_start, BwdPlan pl,
+                                                                 const int64_t *__restrict__ status)
+{
+    if ((int)blockIdx.y == dm.V) {
+        if (blockIdx.x == 0) bwd_segtable(tile_start, dm.V * dm.tiles, pl, status);
+        return;
+    }
+    const int v = blockIdx.y, i = blockIdx.x * 1024 + threadIdx.x;
     if (i >= dm.N) return;
     const size_t idx = (size_t)v * dm.N + i;
     float *g = grec + idx * kGRec;
@@ -168,7 +228,7 @@ __device__ __forceinline__ void pair_forward(const float *__restrict__ b, float 
 // Shared by the three: the segment's records in LDS by field plane, and per 64-entry half the survivor masks -- bit e of
 // col[h][c] says that column c of the tile lies inside entry e's cull box, row[h][r] likewise; a pixel's survivors are
 // col & row, so a lane walks only the entries the forward evaluated for its pixel (4 % of all pairs at BASELINE configs[1]).
-constexpr int kBwdSeg = kBwdChunk;
+static_assert(kBwdSeg == kBwdChunk, "one LDS image per segment");
 #ifndef GA_BWD_ABLATE
 #define GA_BWD_ABLATE 0   // timing-only builds (wrong results): 1 no tail atomics, 2 no phase B, 4 everything takes the former walk, 8 no phase A
 #endif
@@ -185,18 +245,6 @@ struct BwdShared {
     uint32_t wave_area[2];   // survivor pairs of entries 0..63 / 64..127 (sum of the cull rectangles' areas)
 };
 
-struct BwdPlan {   // the segment table and the per-(segment, pixel) exchange arrays, all inside `scratch`
-    uint32_t *seg_base;     // [V tiles + 1] first segment of every tile's list; the last word is the number of segments
-    uint32_t *seg_owner;    // [max_segs] the (view, tile) a segment belongs to
-    float *Tseg;            // [max_segs][256]  trans: T_seg; after the first prefix launch: T_start
-    float *Tend;            // [max_segs][256]
-    float4 *part;           // [max_segs][256]  sums: W', M1', M2', A'; after the second prefix launch: their sums over the earlier segments
-    float4 *total;          // [V tiles][256]   W, M1, M2, sum A' of the whole list
-    float *Tfinal;          // [V tiles][256]
-    uint32_t *big;          // [1 + 2 max_segs] number and list of the segments whose pairs exceed the gradient kernel's pair table,
-                            // then one word per segment: 1 = it is on that list (both written by the sums launch)
-    uint32_t max_segs;
-};
 
 // Sums of 18 words over the wavefront in 5 registers: halves of the wave exchanged between pairs of words
 // (v_permlane32_swap: one add then carries two words, 32 lanes each), rows of 16 lanes between pairs of those
@@ -235,43 +283,6 @@ __device__ __forceinline__ void wave_totals18(const float (&w)[18], float (&q)[5
     for (int i = 0; i < 5; ++i) q[i] += dpp_row<0x114>(q[i]);   // row_shr:4
 #pragma unroll
     for (int i = 0; i < 5; ++i) q[i] += dpp_row<0x118>(q[i]);   // row_shr:8
-}
-
-// number of segments of every tile's list, their exclusive prefix and the owner of every segment (one workgroup)
-__global__ __launch_bounds__(1024) void surfel_bwd_segtable_kernel(const uint32_t *__restrict__ tile_start, int vtiles, BwdPlan pl,
-                                                                  const int64_t *__restrict__ status)
-{
-    __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) pl.big[0] = 0;
-    if (status[GA_STATUS_OVERFLOW]) { if (threadIdx.x == 0) pl.seg_base[vtiles] = 0; return; }
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int base = 0; base < vtiles; base += 1024) {
-        const int vt = base + (int)threadIdx.x;
-        uint32_t n = 0;
-        if (vt < vtiles) n = (tile_start[vt + 1] - tile_start[vt] + kBwdSeg - 1) / kBwdSeg;
-        uint32_t inc = n;
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += o;
-        }
-        if (lane == 63) wave_tot[wv] = inc;
-        __syncthreads();
-        uint32_t off = carry;
-        for (int w = 0; w < wv; ++w) off += wave_tot[w];
-        const uint32_t first = off + inc - n;
-        if (vt < vtiles) {
-            pl.seg_base[vt] = first;
-            for (uint32_t j = 0; j < n; ++j)
-                if (first + j < pl.max_segs) pl.seg_owner[first + j] = (uint32_t)vt;
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = off + inc;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) pl.seg_base[vtiles] = carry;
 }
 
 struct SegCtx {
@@ -368,6 +379,7 @@ __global__ __launch_bounds__(256) void surfel_bwd_trans_kernel(const uint32_t *_
     __shared__ BwdShared sh;
     SegCtx c;
     if (!seg_context(tile_start, pl, dm, c, blockIdx.x)) return;
+    if (c.k == c.nseg - 1) return;   // nobody enters a later segment through the last one (a quarter of the segments at BASELINE configs[1])
     unsigned long long m[2];
     stage_segment<12>(sh, c, point_list, brec, m[0], m[1]);
     float T = 1.0f;
@@ -391,11 +403,20 @@ __global__ __launch_bounds__(256) void surfel_bwd_prefix_T_kernel(const uint32_t
     if (pl.seg_base[vtiles] == 0) return;   // (no segments: nothing rendered, or the forward overflowed its lists)
     const uint32_t s0 = pl.seg_base[vt];
     const int nseg = (int)((tile_start[vt + 1] - tile_start[vt] + kBwdSeg - 1) / kBwdSeg);
+    // (loads of four segments in flight at a time: the loop is a chain of dependent multiplies, not of dependent loads)
+    float *__restrict__ base = pl.Tseg + (size_t)s0 * 256 + threadIdx.x;
     float T = 1.0f;
-    for (int j = 0; j < nseg; ++j) {
-        float *p = pl.Tseg + (size_t)(s0 + j) * 256 + threadIdx.x;
-        const float t = *p;
-        *p = T;
+    int j = 0;
+    for (; j + 4 < nseg; j += 4) {   // (the last segment's product is never formed: surfel_bwd_trans_kernel skips it)
+        float t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = base[(size_t)(j + u) * 256];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { base[(size_t)(j + u) * 256] = T; T *= t[u]; }
+    }
+    for (; j < nseg; ++j) {
+        const float t = j + 1 < nseg ? base[(size_t)j * 256] : 1.0f;
+        base[(size_t)j * 256] = T;
         T *= t;
     }
 }
@@ -411,11 +432,26 @@ __global__ __launch_bounds__(256) void surfel_bwd_prefix_sums_kernel(const uint3
     if (nseg == 0) return;
     float4 run = make_float4(0.f, 0.f, 0.f, 0.f);
     float T_final = 1.0f;
-    for (int j = 0; j < nseg; ++j) {
-        const size_t sl = (size_t)(s0 + j) * 256 + threadIdx.x;
-        if (pl.Tseg[sl] >= 0.0001f) T_final = pl.Tend[sl];
-        const float4 q = pl.part[sl];
-        pl.part[sl] = run;
+    const float *__restrict__ ts = pl.Tseg + (size_t)s0 * 256 + threadIdx.x;
+    const float *__restrict__ te = pl.Tend + (size_t)s0 * 256 + threadIdx.x;
+    float4 *__restrict__ pp = pl.part + (size_t)s0 * 256 + threadIdx.x;
+    int j = 0;
+    for (; j + 4 <= nseg; j += 4) {   // (four segments' loads in flight at a time)
+        float a[4], b[4];
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = ts[(size_t)(j + u) * 256]; b[u] = te[(size_t)(j + u) * 256]; q[u] = pp[(size_t)(j + u) * 256]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (a[u] >= 0.0001f) T_final = b[u];
+            pp[(size_t)(j + u) * 256] = run;
+            run.x += q[u].x; run.y += q[u].y; run.z += q[u].z; run.w += q[u].w;
+        }
+    }
+    for (; j < nseg; ++j) {
+        if (ts[(size_t)j * 256] >= 0.0001f) T_final = te[(size_t)j * 256];
+        const float4 q = pp[(size_t)j * 256];
+        pp[(size_t)j * 256] = run;
         run.x += q.x; run.y += q.y; run.z += q.z; run.w += q.w;
     }
     pl.total[(size_t)vt * 256 + threadIdx.x] = run;
@@ -520,7 +556,7 @@ struct PairShared {
     uint32_t desc[kBwdChunk];         // per entry: base | x0 << 16 | y0 << 20 | w << 24 (w = 0: empty box)
     unsigned char pE[kPairCap];       // entry of a slot
     uint32_t wave_area[2];
-    float tails[4][kTailBatch][kGRec];   // per wave: run totals on their way to the global record
+    float4 tails[4][kTailBatch][5];      // per wave: run totals (18 words in 20) on their way to the global record
     uint32_t tail_id[4][kTailBatch];
 };
 
@@ -750,15 +786,17 @@ __global__ __launch_bounds__(256) void surfel_bwd_grad_kernel(const uint32_t *__
             const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(tm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm, 0u));
             for (int b0 = 0; b0 < nt && !(GA_BWD_ABLATE & 1); b0 += kTailBatch) {
                 if (tail && rank >= b0 && rank < b0 + kTailBatch) {
-#pragma unroll
-                    for (int q = 0; q < kGRec; ++q) pr.tails[wv][rank - b0][q] = cw[q];
+                    float4 *t4 = pr.tails[wv][rank - b0];
+                    t4[0] = make_float4(cw[0], cw[1], cw[2], cw[3]); t4[1] = make_float4(cw[4], cw[5], cw[6], cw[7]);
+                    t4[2] = make_float4(cw[8], cw[9], cw[10], cw[11]); t4[3] = make_float4(cw[12], cw[13], cw[14], cw[15]);
+                    t4[4] = make_float4(cw[16], cw[17], 0.0f, 0.0f);
                     pr.tail_id[wv][rank - b0] = sh.id[e];
                 }
                 GA_LDS_ORDER();
                 const int nw = min(kTailBatch, nt - b0) * kGRec;
                 for (int i = lane; i < nw; i += 64) {
                     const int r = (i * 3641) >> 16, q = i - r * kGRec;      // i / 18 for i < 18 kTailBatch
-                    const float val = pr.tails[wv][r][q];
+                    const float val = reinterpret_cast<const float *>(pr.tails[wv][r])[q];
                     if (val != 0.0f) atomicAdd(grec + (c.vbase + pr.tail_id[wv][r]) * kGRec + q, val);
                 }
                 GA_LDS_ORDER();
@@ -883,6 +921,10 @@ __global__ __launch_bounds__(256) void surfel_bwd_grad_big_kernel(const uint32_t
 
 #undef GA_BF
 
+// One thread per Gaussian, the views in a loop: what is linear in the per-view gradient record -- dL/dHm (scaled axes and
+// centre), the normal column of dL/dR, opacity, colour -- is summed over the views in registers, the rotation / scale /
+// quaternion chain is applied once, and the five gradients leave as plain stores (no atomics, no clearing memsets, and a sum
+// whose order does not depend on the schedule).
 __global__ __launch_bounds__(256) void surfel_preprocess_bwd_kernel(const float *__restrict__ means3D, const float *__restrict__ scales,
                                                                     const float *__restrict__ rotations, const float *__restrict__ viewmatrix,
                                                                     const float *__restrict__ projmatrix, float scale_modifier, Dims dm,
@@ -891,59 +933,72 @@ __global__ __launch_bounds__(256) void surfel_preprocess_bwd_kernel(const float 
                                                                     float *__restrict__ d_colors, float *__restrict__ d_scales,
                                                                     float *__restrict__ d_rot)
 {
-    const int v = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= dm.N) return;
-    const size_t idx = (size_t)v * dm.N + i;
-    if (radii[idx] <= 0) return;
-    const float *g = grec + idx * kGRec;
-    const float *vm = viewmatrix + 16 * v, *pm = projmatrix + 16 * v;
+    float sHm[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};   // sum over views of dL/dHm
+    float sn[3] = {0.f, 0.f, 0.f};                                           // ... of the normal column of dL/dR
+    float sop = 0.f, scol[3] = {0.f, 0.f, 0.f};
     SplatFwd s;
-    splat_forward(means3D, scales, rotations, vm, pm, scale_modifier, dm, i, s);
-    // dM[a][c]: rows a = (u axis, v axis, centre), columns c = (Tu, Tv, Tw)
-    float dM[3][3];
-    for (int a = 0; a < 3; ++a) { dM[a][0] = g[a]; dM[a][1] = g[3 + a]; dM[a][2] = g[6 + a]; }
-    // the low-pass filter's centre: cx = sum t Tu Tw / Dn, cy = sum t Tv Tw / Dn, Dn = sum t Tw^2
-    const float t[3] = {kCutoff * kCutoff, kCutoff * kCutoff, -1.0f};
-    const float gcx = g[9], gcy = g[10], inv = 1.0f / s.Dn;
-    for (int a = 0; a < 3; ++a) {
-        dM[a][0] += gcx * t[a] * s.Tw[a] * inv;
-        dM[a][1] += gcy * t[a] * s.Tw[a] * inv;
-        dM[a][2] += gcx * (t[a] * s.Tu[a] * inv - s.cx * 2.0f * t[a] * s.Tw[a] * inv) +
-                    gcy * (t[a] * s.Tv[a] * inv - s.cy * 2.0f * t[a] * s.Tw[a] * inv);
-    }
-    // M[a] = A(a) N_pix with A(a)[j'] = sum_j Hm[a][j] pm[4 j + j'] (+ pm[12 + j'] for the centre row)
+    bool seen = false;
     const float halfW = (float)dm.W / 2.0f, halfH = (float)dm.H / 2.0f;
     const float cW = (float)(dm.W - 1) / 2.0f, cH = (float)(dm.H - 1) / 2.0f;
-    float dHm[3][3];
-    for (int a = 0; a < 3; ++a) {
-        const float dA[4] = {dM[a][0] * halfW, dM[a][1] * halfH, 0.0f, dM[a][0] * cW + dM[a][1] * cH + dM[a][2]};
-        for (int j = 0; j < 3; ++j) dHm[a][j] = dA[0] * pm[4 * j] + dA[1] * pm[4 * j + 1] + dA[2] * pm[4 * j + 2] + dA[3] * pm[4 * j + 3];
+    for (int v = 0; v < dm.V; ++v) {
+        const size_t idx = (size_t)v * dm.N + i;
+        if (radii[idx] <= 0) continue;
+        seen = true;
+        const float *g = grec + idx * kGRec;
+        const float *vm = viewmatrix + 16 * v, *pm = projmatrix + 16 * v;
+        splat_forward(means3D, scales, rotations, vm, pm, scale_modifier, dm, i, s);
+        // dM[a][c]: rows a = (u axis, v axis, centre), columns c = (Tu, Tv, Tw)
+        float dM[3][3];
+        for (int a = 0; a < 3; ++a) { dM[a][0] = g[a]; dM[a][1] = g[3 + a]; dM[a][2] = g[6 + a]; }
+        // the low-pass filter's centre: cx = sum t Tu Tw / Dn, cy = sum t Tv Tw / Dn, Dn = sum t Tw^2
+        const float t[3] = {kCutoff * kCutoff, kCutoff * kCutoff, -1.0f};
+        const float gcx = g[9], gcy = g[10], inv = 1.0f / s.Dn;
+        for (int a = 0; a < 3; ++a) {
+            dM[a][0] += gcx * t[a] * s.Tw[a] * inv;
+            dM[a][1] += gcy * t[a] * s.Tw[a] * inv;
+            dM[a][2] += gcx * (t[a] * s.Tu[a] * inv - s.cx * 2.0f * t[a] * s.Tw[a] * inv) +
+                        gcy * (t[a] * s.Tv[a] * inv - s.cy * 2.0f * t[a] * s.Tw[a] * inv);
+        }
+        // M[a] = A(a) N_pix with A(a)[j'] = sum_j Hm[a][j] pm[4 j + j'] (+ pm[12 + j'] for the centre row)
+        for (int a = 0; a < 3; ++a) {
+            const float dA[4] = {dM[a][0] * halfW, dM[a][1] * halfH, 0.0f, dM[a][0] * cW + dM[a][1] * cH + dM[a][2]};
+            for (int j = 0; j < 3; ++j) sHm[a][j] += dA[0] * pm[4 * j] + dA[1] * pm[4 * j + 1] + dA[2] * pm[4 * j + 2] + dA[3] * pm[4 * j + 3];
+        }
+        for (int r = 0; r < 3; ++r)   // nv_c = mult sum_r vm[4 r + c] n_r
+            sn[r] += s.mult * (g[12] * vm[4 * r] + g[13] * vm[4 * r + 1] + g[14] * vm[4 * r + 2]);
+        sop += g[11];
+        for (int a = 0; a < 3; ++a) scol[a] += g[15 + a];
     }
-    float dR[3][3];   // dL/dR[row][col]: columns tu, tv, n
-    float dsu = 0.f, dsv = 0.f;
-    for (int r = 0; r < 3; ++r) {
-        dR[r][0] = s.su * dHm[0][r];
-        dR[r][1] = s.sv * dHm[1][r];
-        dsu += s.tu[r] * dHm[0][r];
-        dsv += s.tv[r] * dHm[1][r];
-        dR[r][2] = s.mult * (g[12] * vm[4 * r] + g[13] * vm[4 * r + 1] + g[14] * vm[4 * r + 2]);   // nv_c = mult sum_r vm[4 r + c] n_r
+    float dq_out[4] = {0.f, 0.f, 0.f, 0.f}, dsu = 0.f, dsv = 0.f;
+    if (seen) {   // (s: the view-independent members -- rotation columns, scales, quaternion -- of the last view seen)
+        float dR[3][3];   // dL/dR[row][col]: columns tu, tv, n
+        for (int r = 0; r < 3; ++r) {
+            dR[r][0] = s.su * sHm[0][r];
+            dR[r][1] = s.sv * sHm[1][r];
+            dsu += s.tu[r] * sHm[0][r];
+            dsv += s.tv[r] * sHm[1][r];
+            dR[r][2] = sn[r];
+        }
+        // R(q^) with q^ = (r, x, y, z) = q / |q|
+        const float r = s.q[0] * s.qs, x = s.q[1] * s.qs, y = s.q[2] * s.qs, z = s.q[3] * s.qs;
+        float dq[4];
+        dq[0] = 2.0f * (z * (dR[1][0] - dR[0][1]) + y * (dR[0][2] - dR[2][0]) + x * (dR[2][1] - dR[1][2]));
+        dq[1] = 2.0f * (y * (dR[0][1] + dR[1][0]) + z * (dR[0][2] + dR[2][0]) + r * (dR[2][1] - dR[1][2])) - 4.0f * x * (dR[1][1] + dR[2][2]);
+        dq[2] = 2.0f * (x * (dR[0][1] + dR[1][0]) + r * (dR[0][2] - dR[2][0]) + z * (dR[1][2] + dR[2][1])) - 4.0f * y * (dR[0][0] + dR[2][2]);
+        dq[3] = 2.0f * (r * (dR[1][0] - dR[0][1]) + x * (dR[0][2] + dR[2][0]) + y * (dR[1][2] + dR[2][1])) - 4.0f * z * (dR[0][0] + dR[1][1]);
+        // q^ = q / |q|: dq = (dq^ - q^ (q^ . dq^)) / |q|
+        const float dotq = r * dq[0] + x * dq[1] + y * dq[2] + z * dq[3];
+        const float qh[4] = {r, x, y, z};
+        for (int c = 0; c < 4; ++c) dq_out[c] = (dq[c] - qh[c] * dotq) * s.qs;
     }
-    for (int a = 0; a < 3; ++a) atomicAdd(d_means + 3 * i + a, dHm[2][a]);
-    atomicAdd(d_scales + 2 * i, scale_modifier * dsu);
-    atomicAdd(d_scales + 2 * i + 1, scale_modifier * dsv);
-    atomicAdd(d_opac + i, g[11]);
-    for (int a = 0; a < 3; ++a) atomicAdd(d_colors + 3 * i + a, g[15 + a]);
-    // R(q^) with q^ = (r, x, y, z) = q / |q|
-    const float r = s.q[0] * s.qs, x = s.q[1] * s.qs, y = s.q[2] * s.qs, z = s.q[3] * s.qs;
-    float dq[4];
-    dq[0] = 2.0f * (z * (dR[1][0] - dR[0][1]) + y * (dR[0][2] - dR[2][0]) + x * (dR[2][1] - dR[1][2]));
-    dq[1] = 2.0f * (y * (dR[0][1] + dR[1][0]) + z * (dR[0][2] + dR[2][0]) + r * (dR[2][1] - dR[1][2])) - 4.0f * x * (dR[1][1] + dR[2][2]);
-    dq[2] = 2.0f * (x * (dR[0][1] + dR[1][0]) + r * (dR[0][2] - dR[2][0]) + z * (dR[1][2] + dR[2][1])) - 4.0f * y * (dR[0][0] + dR[2][2]);
-    dq[3] = 2.0f * (r * (dR[1][0] - dR[0][1]) + x * (dR[0][2] + dR[2][0]) + y * (dR[1][2] + dR[2][1])) - 4.0f * z * (dR[0][0] + dR[1][1]);
-    // q^ = q / |q|: dq = (dq^ - q^ (q^ . dq^)) / |q|
-    const float dotq = r * dq[0] + x * dq[1] + y * dq[2] + z * dq[3];
-    const float qh[4] = {r, x, y, z};
-    for (int c = 0; c < 4; ++c) atomicAdd(d_rot + 4 * i + c, (dq[c] - qh[c] * dotq) * s.qs);
+    for (int a = 0; a < 3; ++a) d_means[3 * i + a] = sHm[2][a];
+    d_scales[2 * i] = scale_modifier * dsu;
+    d_scales[2 * i + 1] = scale_modifier * dsv;
+    d_opac[i] = sop;
+    for (int a = 0; a < 3; ++a) d_colors[3 * i + a] = scol[a];
+    for (int c = 0; c < 4; ++c) d_rot[4 * i + c] = dq_out[c];
 }
 
 }  // namespace ga
@@ -1026,16 +1081,10 @@ extern "C" int ga_surfel_backward(const GaSurfelBackwardArgs *a, void *stream_v)
     pl.Tfinal = reinterpret_cast<float *>(sp + sc.Tfinal);
     pl.big = reinterpret_cast<uint32_t *>(sp + sc.big);
     pl.max_segs = sc.max_segs;
-    (void)hipMemsetAsync(a->grad_means3D, 0, (size_t)d.N * 3 * 4, s);
-    (void)hipMemsetAsync(a->grad_opacities, 0, (size_t)d.N * 4, s);
-    (void)hipMemsetAsync(a->grad_colors, 0, (size_t)d.N * 3 * 4, s);
-    (void)hipMemsetAsync(a->grad_scales, 0, (size_t)d.N * 2 * 4, s);
-    (void)hipMemsetAsync(a->grad_rotations, 0, (size_t)d.N * 4 * 4, s);
     const dim3 gridN((unsigned)((d.N + 255) / 256), (unsigned)d.V);
-    hipLaunchKernelGGL(surfel_bwd_record_kernel, gridN, dim3(256), 0, s, f.means3D, f.opacities, f.colors, f.scales, f.rotations,
-                       f.viewmatrix, f.projmatrix, f.scale_modifier, d, f.radii, reinterpret_cast<const float *>(w + L.record), brec,
-                       grec);
-    hipLaunchKernelGGL(surfel_bwd_segtable_kernel, dim3(1), dim3(1024), 0, s, tile_start, d.V * d.tiles, pl, status);
+    hipLaunchKernelGGL(surfel_bwd_record_kernel, dim3((unsigned)((d.N + 1023) / 1024), (unsigned)d.V + 1u), dim3(1024), 0, s, f.means3D,
+                       f.opacities, f.colors, f.scales, f.rotations, f.viewmatrix, f.projmatrix, f.scale_modifier, d, f.radii,
+                       reinterpret_cast<const float *>(w + L.record), brec, grec, tile_start, pl, status);
     // (the grid covers the bound on the number of segments; the workgroups past the real count leave at once)
     const dim3 gridS(sc.max_segs);
     hipLaunchKernelGGL(surfel_bwd_trans_kernel, gridS, dim3(256), 0, s, tile_start, point_list, brec, d, pl);
@@ -1047,7 +1096,7 @@ extern "C" int ga_surfel_backward(const GaSurfelBackwardArgs *a, void *stream_v)
                        a->grad_color, a->grad_others, grec);
     hipLaunchKernelGGL(surfel_bwd_grad_big_kernel, gridS, dim3(256), 0, s, tile_start, point_list, brec, f.bg, d, pl,
                        a->grad_color, a->grad_others, grec);
-    hipLaunchKernelGGL(surfel_preprocess_bwd_kernel, gridN, dim3(256), 0, s, f.means3D, f.scales, f.rotations, f.viewmatrix,
+    hipLaunchKernelGGL(surfel_preprocess_bwd_kernel, dim3(gridN.x), dim3(256), 0, s, f.means3D, f.scales, f.rotations, f.viewmatrix,
                        f.projmatrix, f.scale_modifier, d, f.radii, grec, a->grad_means3D, a->grad_opacities, a->grad_colors,
                        a->grad_scales, a->grad_rotations);
     return hipGetLastError() == hipSuccess ? GA_OK : GA_ERR_LAUNCH;
