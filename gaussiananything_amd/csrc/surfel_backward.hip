@@ -5,7 +5,8 @@
 // forward being differentiated is SURVEY.md Appendix A.1; the piecewise-constant choices are treated as constants of the
 // gradient exactly as oracle/surfel_autograd.py (the backward oracle) does: the selection min(rho3d, rho2d), the
 // alpha >= 1/255, depth >= near and T(1 - alpha) >= 1e-4 tests, the 0.99 clamp (no gradient above it), the sign that turns
-// the normal towards the camera, and the median depth (not differentiated).
+// the normal towards the camera, and WHICH pair is the median contributor (its depth carries the gradient of the median-depth
+// channel, as in upstream's backward).
 //
 // Launches (all on the caller's stream, nothing allocated):
 //   1. surfel_bwd_record_kernel      per (view, Gaussian): the forward's per-splat quantities once more -- Tu, Tv, Tw, the
@@ -233,12 +234,12 @@ static_assert(kBwdSeg == kBwdChunk, "one LDS image per segment");
 #define GA_BWD_ABLATE 0   // timing-only builds (wrong results): 1 no tail atomics, 2 no phase B, 4 everything takes the former walk, 8 no phase A
 #endif
 #ifndef GA_BWD_PAIR_CAP
-#define GA_BWD_PAIR_CAP 2560
+#define GA_BWD_PAIR_CAP 2528
 #endif
-constexpr int kPairCap = GA_BWD_PAIR_CAP;
+constexpr int kPairCap = GA_BWD_PAIR_CAP;   // slots of the gradient kernel's pair table; segments with more pairs (large splats) go entry-major
 
 struct BwdShared {
-    float rec[kBRec][kBwdChunk];
+    float rec[20][kBwdChunk];        // field planes 0 .. 19 of the 24-float records (the rest is padding)
     unsigned long long col[2][kTile], row[2][kTile];
     unsigned long long colq[2][2], rowq[2][2];    // union of the masks of the columns / rows 0..7 and 8..15 (a wave = an 8 x 8 quadrant)
     uint32_t id[kBwdChunk];
@@ -458,18 +459,18 @@ __global__ __launch_bounds__(256) void surfel_bwd_prefix_sums_kernel(const uint3
     pl.Tfinal[(size_t)vt * 256 + threadIdx.x] = T_final;
 }
 
-struct PixelGrads { float gC[3], gN[3], gD, gA, gDist; };
+struct PixelGrads { float gC[3], gN[3], gD, gA, gDist, gMed; };
 
 __device__ __forceinline__ void load_pixel_grads(const float *__restrict__ g_color, const float *__restrict__ g_others, const Dims &dm,
                                                  const SegCtx &c, PixelGrads &o)
 {
     for (int q = 0; q < 3; ++q) { o.gC[q] = 0.f; o.gN[q] = 0.f; }
-    o.gD = 0.f; o.gA = 0.f; o.gDist = 0.f;
+    o.gD = 0.f; o.gA = 0.f; o.gDist = 0.f; o.gMed = 0.f;
     if (!c.inside) return;
     const size_t HW = (size_t)dm.H * dm.W, pid = (size_t)c.pyi * dm.W + c.pxi;
     for (int q = 0; q < 3; ++q) o.gC[q] = g_color[((size_t)c.v * 3 + q) * HW + pid];
     const float *go = g_others + (size_t)c.v * 7 * HW + pid;
-    o.gD = go[0]; o.gA = go[HW]; o.gN[0] = go[2 * HW]; o.gN[1] = go[3 * HW]; o.gN[2] = go[4 * HW]; o.gDist = go[6 * HW];
+    o.gD = go[0]; o.gA = go[HW]; o.gN[0] = go[2 * HW]; o.gN[1] = go[3 * HW]; o.gN[2] = go[4 * HW]; o.gMed = go[5 * HW]; o.gDist = go[6 * HW];
 }
 
 __global__ __launch_bounds__(256) void surfel_bwd_sums_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
@@ -541,14 +542,17 @@ __global__ __launch_bounds__(256) void surfel_bwd_sums_kernel(const uint32_t *__
 //      from the record and its pixel's constants (LDS), takes T_i and P_i from the table and forms the 18 words; the slots of
 //      an entry are consecutive lanes, so a segmented sum along each row of 16 lanes (4 DPP steps per word) leaves every
 //      entry's total in the last lane of its run, which adds it to the global gradient record (~1.6 runs per entry).
-// Segments with more than kPairCap pairs (large splats) keep the former walk with its LDS gradient image:
+// Segments with more than kPairCap pairs (large splats; 19.7 pairs per entry on average) keep the former walk with its LDS
+// gradient image, in a kernel of their own (walking such a segment pair-major in several fills of the table was built and
+// measured: slower on the stress scene -- the table has a slot for every survivor, also those of pixels that are finished,
+// and with long lists behind saturated pixels that is most of them):
 //   lane-major   every lane walks its own survivors and adds its 18 words to the segment's gradient image with LDS atomics;
 //   entry-major  the wave walks the union of its lanes' survivors, all lanes evaluate the same entry (one broadcast record
 //                read), the words are summed across the wave (wave_totals18) and four lanes add the totals: cheaper as soon
 //                as an entry is evaluated by GA_BWD_WAVE_MAJOR_LANES lanes of the wave on average.
 constexpr int kTailBatch = 8;
 static_assert(kGRec == 18 && kTailBatch * kGRec <= 144, "(i * 3641) >> 16 == i / 18 was checked for i < 144");
-constexpr int kPixFields = 13;   // gC(3) gN(3) gD gDist | W M1 M2 Vtot | T_final (gC.bg - gA)
+constexpr int kPixFields = 15;   // gC(3) gN(3) gD gDist | W M1 M2 Vtot | T_final (gC.bg - gA) | gMedian T_final
 
 struct PairShared {
     float pix[kPixFields][256];       // per-pixel constants, pixel = ly * 16 + lx
@@ -560,7 +564,7 @@ struct PairShared {
     uint32_t tail_id[4][kTailBatch];
 };
 
-struct PixC { float gC[3], gN[3], gD, gDist, W, M1, M2, Vtot, Tfb; };
+struct PixC { float gC[3], gN[3], gD, gDist, W, M1, M2, Vtot, Tfb, gMed, Tfin; };
 struct PairV { float w, mz, rd, vi; };
 
 __device__ __forceinline__ PairV pair_value(const float *__restrict__ b, const PairFwd &f, float T, const PixC &pc)
@@ -583,7 +587,14 @@ __device__ __forceinline__ void pair_words(const PairFwd &f, const PairV &v, flo
     const float kM = kFar / (kFar - kNear);
     const float inv1ma = __builtin_amdgcn_rcpf(1.0f - f.alpha);
     const float dL_dalpha = T * v.vi - (pc.Vtot - P) * inv1ma - pc.Tfb * inv1ma;
-    const float dL_ddepth = v.w * pc.gD + 2.0f * pc.gDist * v.w * (v.mz * pc.W - pc.M1) * (kM * kNear * v.rd * v.rd);
+    // The median depth (allmap channel 5) is the depth of the LAST contributing pair entered with T > 0.5: the next one is
+    // entered with T (1 - alpha) <= 0.5, or there is none -- then the pixel's final transmittance is this product (up to the
+    // rounding of the per-segment products; any later contributing pair would have taken at least 1/255 off it).  Which
+    // pair that is counts as a constant of the gradient.
+    const float next_T = T * (1.0f - f.alpha);
+    const bool is_median = T > 0.5f && (!(next_T > 0.5f) || pc.Tfin > 0.998f * next_T);
+    const float dL_ddepth = v.w * pc.gD + 2.0f * pc.gDist * v.w * (v.mz * pc.W - pc.M1) * (kM * kNear * v.rd * v.rd) +
+                            (is_median ? pc.gMed : 0.0f);
     for (int q = 0; q < 3; ++q) { cw[15 + q] = v.w * pc.gC[q]; cw[12 + q] = v.w * pc.gN[q]; }
     const float dL_draw = f.raw > 0.99f ? 0.0f : dL_dalpha;       // the clamp carries no gradient
     cw[11] = f.G * dL_draw;
@@ -678,6 +689,7 @@ __global__ __launch_bounds__(256) void surfel_bwd_grad_kernel(const uint32_t *__
         pc.W = tot.x; pc.M1 = tot.y; pc.M2 = tot.z;
         pc.Vtot = tot.w + 2.0f * pg.gDist * (tot.x * tot.z - tot.y * tot.y);
         pc.Tfb = T_final * ((pg.gC[0] * bg[0] + pg.gC[1] * bg[1] + pg.gC[2] * bg[2]) - pg.gA);
+        pc.gMed = pg.gMed; pc.Tfin = T_final;
     }
     float P = pre.w + pc.gDist * (pc.W * pre.z - 2.0f * pc.M1 * pre.y + pc.M2 * pre.x);
     unsigned long long m[2];
@@ -699,23 +711,23 @@ __global__ __launch_bounds__(256) void surfel_bwd_grad_kernel(const uint32_t *__
     }
     __syncthreads();
     const uint32_t total = pr.wave_area[0] + pr.wave_area[1];
-
     if (total > (uint32_t)kPairCap) return;   // (cannot happen: those segments are on the other kernel's list)
+    if (threadIdx.x < kBwdChunk) {
+        const uint32_t base = incl - area + (wv == 1 ? pr.wave_area[0] : 0u);
+        const uint32_t w = (uint32_t)__popc(xb);
+        pr.desc[threadIdx.x] = base | (area ? ((uint32_t)__builtin_ctz(xb) << 16) | ((uint32_t)__builtin_ctz(yb) << 20) | (w << 24) : 0u);
+        for (uint32_t q = 0; q < area; ++q) { pr.pE[base + q] = (unsigned char)threadIdx.x; pr.pT[base + q] = 0.0f; }
+    }
     {
-        if (threadIdx.x < kBwdChunk) {
-            const uint32_t base = incl - area + (wv == 1 ? pr.wave_area[0] : 0u);
-            const uint32_t w = (uint32_t)__popc(xb);
-            pr.desc[threadIdx.x] = base | (area ? ((uint32_t)__builtin_ctz(xb) << 16) | ((uint32_t)__builtin_ctz(yb) << 20) | (w << 24) : 0u);
-            for (uint32_t q = 0; q < area; ++q) { pr.pE[base + q] = (unsigned char)threadIdx.x; pr.pT[base + q] = 0.0f; }
-        }
-        {
-            const int pix = c.ly * kTile + c.lx;
-            const float vals[kPixFields] = {pc.gC[0], pc.gC[1], pc.gC[2], pc.gN[0], pc.gN[1], pc.gN[2], pc.gD, pc.gDist,
-                                            pc.W, pc.M1, pc.M2, pc.Vtot, pc.Tfb};
+        const int pix = c.ly * kTile + c.lx;
+        const float vals[kPixFields] = {pc.gC[0], pc.gC[1], pc.gC[2], pc.gN[0], pc.gN[1], pc.gN[2], pc.gD, pc.gDist,
+                                        pc.W, pc.M1, pc.M2, pc.Vtot, pc.Tfb, pc.gMed, pc.Tfin};
 #pragma unroll
-            for (int q = 0; q < kPixFields; ++q) pr.pix[q][pix] = vals[q];
-        }
-        __syncthreads();
+        for (int q = 0; q < kPixFields; ++q) pr.pix[q][pix] = vals[q];
+    }
+    __syncthreads();
+    const float tx0 = (float)(c.tx * kTile), ty0 = (float)(c.ty * kTile);
+    {
         // A: my pixel's walk
         for (int h = 0; h < 2; ++h) {
             unsigned long long mm = (done || (GA_BWD_ABLATE & 8)) ? 0ull : m[h];
@@ -740,7 +752,6 @@ __global__ __launch_bounds__(256) void surfel_bwd_grad_kernel(const uint32_t *__
         __syncthreads();
         if (GA_BWD_ABLATE & 2) return;
         // B: one lane per slot
-        const float tx0 = (float)(c.tx * kTile), ty0 = (float)(c.ty * kTile);
         for (uint32_t p0 = 0; p0 < total; p0 += 256) {
             const uint32_t p = p0 + threadIdx.x;
             const bool valid = p < total;
@@ -763,6 +774,7 @@ __global__ __launch_bounds__(256) void surfel_bwd_grad_kernel(const uint32_t *__
                 q.gN[0] = pr.pix[3][pix]; q.gN[1] = pr.pix[4][pix]; q.gN[2] = pr.pix[5][pix];
                 q.gD = pr.pix[6][pix]; q.gDist = pr.pix[7][pix]; q.W = pr.pix[8][pix]; q.M1 = pr.pix[9][pix];
                 q.M2 = pr.pix[10][pix]; q.Vtot = pr.pix[11][pix]; q.Tfb = pr.pix[12][pix];
+                q.gMed = pr.pix[13][pix]; q.Tfin = pr.pix[14][pix];
                 const float qx = tx0 + (float)lx, qy = ty0 + (float)ly;
                 const float *b = &sh.rec[0][e];
                 PairFwd f;
@@ -835,6 +847,7 @@ __global__ __launch_bounds__(256) void surfel_bwd_grad_big_kernel(const uint32_t
         pc.W = tot.x; pc.M1 = tot.y; pc.M2 = tot.z;
         pc.Vtot = tot.w + 2.0f * pg.gDist * (tot.x * tot.z - tot.y * tot.y);
         pc.Tfb = T_final * ((pg.gC[0] * bg[0] + pg.gC[1] * bg[1] + pg.gC[2] * bg[2]) - pg.gA);
+        pc.gMed = pg.gMed; pc.Tfin = T_final;
     }
     float P = pre.w + pc.gDist * (pc.W * pre.z - 2.0f * pc.M1 * pre.y + pc.M2 * pre.x);
     for (uint32_t w = threadIdx.x; w < kBwdChunk * (kGRec + 1); w += 256) (&sgrad[0][0])[w] = 0.0f;

@@ -211,8 +211,8 @@ def rasterize_views(means3D, opacities, colors_precomp, scales, rotations, viewm
                     image_height, image_width, scale_modifier=1.0, workspace: Optional[SurfelWorkspace] = None,
                     check_overflow: bool = True, stage_events=None):
     """``_rasterize_views_nograd`` (below), differentiable when autograd is recording and a Gaussian tensor requires grad:
-    ``color`` and ``allmap`` then carry a grad_fn whose backward is ``ga_surfel_backward`` (the median-depth channel and
-    ``radii`` are not differentiable; the workspace of such a call is its own)."""
+    ``color`` and ``allmap`` then carry a grad_fn whose backward is ``ga_surfel_backward`` (``radii`` is not differentiable; the median-depth
+    channel passes its gradient to the depth of the median contributor; the workspace of such a call is its own)."""
     if torch.is_grad_enabled() and any(getattr(t, "requires_grad", False) for t in
                                        (means3D, opacities, colors_precomp, scales, rotations)):
         device = means3D.device

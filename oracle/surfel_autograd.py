@@ -5,14 +5,16 @@ TEST INFRASTRUCTURE ONLY.  Written from the published method (Huang et al. 2024,
 intersection, object-space low-pass filter, front-to-back alpha blending, depth distortion, sec. 4-5) with the constants
 and output channels of the reference's consumer (/root/reference/nsr/gs_surfel.py:85-142), as a
 plain per-pixel solve: for every pixel and surfel it finds the (u, v) whose world point p0 + su u tu + sv v tv projects
-onto the pixel centre -- no homography / cross-product trick, no tiles, no culling (only the CENTRE of the screen-space
-low-pass filter follows the rasterizer's bounding-box formula, see below).  Gradients come from autograd, so the
+onto the pixel centre -- no homography / cross-product trick, no lists, no culling; of the rasterizer's tile machinery only
+what changes results is kept: the CENTRE of the screen-space low-pass filter follows the bounding-box formula, and a splat
+reaches only the pixels of its tile rectangle (see below).  Gradients come from autograd, so the
 backward oracle is BY CONSTRUCTION the derivative of this forward; tests/test_cpu_oracle_and_host.py checks (a) the
 forward against oracle/surfel_raster.c and (b) the gradients against finite differences (torch.autograd.gradcheck).
 
 PARITY UNPINNED with respect to upstream's backward.cu (third-party, absent): the piecewise-constant choices are the
-natural ones -- the selection min(rho3d, rho2d), the alpha >= 1/255 and T >= 1e-4 tests, the 0.99 clamp and the median
-depth are treated as constants of the gradient; upstream additionally reports an absolute screen-space gradient for
+natural ones -- the selection min(rho3d, rho2d), the alpha >= 1/255 and T >= 1e-4 tests, the 0.99 clamp and the choice of
+the median contributor are treated as constants of the gradient (the median depth itself is the depth of that pair and
+carries its gradient there, as upstream's ``dL_dmedian_depth`` does); upstream additionally reports an absolute screen-space gradient for
 densification (``means2D``), which is a training heuristic, not a derivative, and is not restated.
 """
 from __future__ import annotations
@@ -67,6 +69,19 @@ def render(means3D, opacities, colors, scales, rotations, cam_view, cam_view_pro
         fvec = tvec / (Mh[:, 2] * Mh[:, 2] * tvec).sum()
         xc, yc = (fvec * Mh[:, 0] * Mh[:, 2]).sum(), (fvec * Mh[:, 1] * Mh[:, 2]).sum()
         rho2d = 2.0 * ((xc - px) ** 2 + (yc - py) ** 2)                                         # low-pass filter
+        # The rasterizer's tile rectangle (oracle/surfel_raster.c: compute_aabb + getRect): a splat only
+        # reaches the pixels of the 16 x 16 tiles its rect covers.  getRect's upper edge, trunc((c + radius + 15) / 16), leaves
+        # out the tile that begins at 16 k when c + radius lies in [16 k, 16 k + 1) -- a pixel row / column inside the radius is
+        # then NOT touched.  A constant of the gradient like the other selections.
+        with torch.no_grad():
+            ex = torch.sqrt(torch.clamp(xc * xc - (fvec * Mh[:, 0] * Mh[:, 0]).sum(), min=1e-4))
+            ey = torch.sqrt(torch.clamp(yc * yc - (fvec * Mh[:, 1] * Mh[:, 1]).sum(), min=1e-4))
+            radius = torch.ceil(torch.maximum(torch.maximum(ex, ey), torch.tensor(3.0 * 0.70710678118654752, dtype=dt)))
+            gx, gy = (W + 15) // 16, (H + 15) // 16
+            clampi = lambda v, hi_: min(hi_, max(0, int(v)))    # noqa: E731   (int(): truncation towards zero, as the C cast)
+            rminx, rmaxx = clampi((xc - radius) / 16, gx), clampi((xc + radius + 15) / 16, gx)
+            rminy, rmaxy = clampi((yc - radius) / 16, gy), clampi((yc + radius + 15) / 16, gy)
+            in_rect = (px >= 16 * rminx) & (px < 16 * rmaxx) & (py >= 16 * rminy) & (py < 16 * rmaxy)
         zc = (torch.cat([p0, z0 + 1]) @ V)[2]
         use3d = (rho3d <= rho2d).detach()
         depth = torch.where(use3d, zc + u * (torch.cat([tu, z0]) @ V)[2] + v * (torch.cat([tv, z0]) @ V)[2], zc.expand(H, W))
@@ -74,12 +89,12 @@ def render(means3D, opacities, colors, scales, rotations, cam_view, cam_view_pro
         alpha = torch.where(raw.detach() > 0.99, torch.full_like(raw, 0.99), raw)              # clamp: no gradient above it
         nv = n @ V[:3, :3]
         nv = nv * torch.sign(-torch.dot((torch.cat([p0, z0 + 1]) @ V)[:3], nv)).detach()        # facing the camera
-        ok = ((alpha >= 1.0 / 255.0) & (depth >= NEAR) & (T * (1 - alpha) >= 1e-4)).detach()
+        ok = ((alpha >= 1.0 / 255.0) & (depth >= NEAR) & (T * (1 - alpha) >= 1e-4)).detach() & in_rect
         wgt = torch.where(ok, alpha * T, torch.zeros_like(T))
         m = FAR / (FAR - NEAR) * (1 - NEAR / depth)
         dist = dist + torch.where(ok, (m * m * (1 - T) + M2 - 2 * m * M1) * wgt, torch.zeros_like(T))
         Dp = Dp + depth * wgt; M1 = M1 + m * wgt; M2 = M2 + m * m * wgt
-        median = torch.where(ok & (T.detach() > 0.5), depth.detach(), median)                     # not differentiated
+        median = torch.where(ok & (T.detach() > 0.5), depth, median)          # (the selection is a constant; the depth is not)
         Nrm = Nrm + nv[:, None, None] * wgt
         C = C + colors[i][:, None, None] * wgt
         T = torch.where(ok, T * (1 - alpha), T)

@@ -203,7 +203,8 @@ def test_surfel_backward_oracle_forward_and_gradcheck():
     # gradients: a scalar functional of every differentiable output (random fixed weights), checked by finite differences
     wc = torch.rand(3, H, W, generator=g).double()
     wa = torch.rand(7, H, W, generator=g).double()
-    wa[5] = 0                                                           # the median depth is piecewise constant
+    # (channel 5, the median depth: the depth of the pair that crosses T = 0.5 -- differentiable through that depth, the choice
+    #  of the pair being a constant, like the other selections)
 
     def f(m_, o_, c_, s_, q_):
         col, a_ = oag.render(m_, o_, c_, s_, q_, cv, cvp, bg, H, W)

@@ -4,6 +4,8 @@ Bars (BASELINE.json north_star): integer artefacts -- radii, tile rects, per-til
 lists -- BIT-IDENTICAL; pixels MSE <= 1e-5 per output (colour and each allmap channel).
 """
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -390,7 +392,6 @@ def _backward_case(gpu_device, n, H, W, views, seed, scale_lo, scale_hi, spread)
     bg = torch.tensor([0.3, 0.6, 0.1], dtype=torch.float64)
     wc = torch.rand(len(views), 3, H, W, generator=g).double()
     wa = torch.rand(len(views), 7, H, W, generator=g).double()
-    wa[:, 5] = 0                                                         # the median depth is not differentiated
     # oracle: autograd through the float64 restatement, view by view
     ins = [t.clone().requires_grad_(True) for t in (means, opac, rgb, scales, quats)]
     loss = 0.0
@@ -407,11 +408,13 @@ def _backward_case(gpu_device, n, H, W, views, seed, scale_lo, scale_hi, spread)
     dloss = (color.double() * wc.to(gpu_device)).sum() + (allmap.double() * wa.to(gpu_device)).sum()
     assert abs(float(dloss.detach()) - float(loss.detach())) <= 2e-4 * abs(float(loss.detach())) + 1e-3
     got = torch.autograd.grad(dloss, dins)
+    errs = {}
     for name, a, b in zip(("means3D", "opacities", "colors", "scales", "rotations"), got, ref):
         a = a.double().cpu()
-        err = float((a - b).norm() / (b.norm() + 1e-30))
-        print(f"backward {name}: rel. L2 error vs the autograd oracle {err:.2e}")
-        assert torch.isfinite(a).all() and err < 2e-4, (name, err, float(b.norm()))   # measured: 2e-7 .. 1.5e-5 (fp32 vs float64)
+        errs[name] = float((a - b).norm() / (b.norm() + 1e-30))
+        print(f"backward {name}: rel. L2 error vs the autograd oracle {errs[name]:.2e}")
+        assert torch.isfinite(a).all(), name
+    assert max(errs.values()) < 2e-4, errs      # measured: 2e-7 .. 1.5e-5 (fp32 vs float64)
     return ref
 
 
@@ -430,9 +433,16 @@ def test_backward_many_small_surfels_long_lists(gpu_device):
 
 def test_backward_many_large_surfels_take_the_walk_with_the_lds_gradient_image(gpu_device):
     """60 surfels that each cover most of a 32 x 32 image: 60 x ~256 pairs per tile, more than the pair table of the gradient
-    kernel holds (kPairCap = 2560), so this is the former walk -- entry-major waves with the cross-lane sums -- while the six
+    kernel holds (kPairCap = 2528), so this is the former walk -- entry-major waves with the cross-lane sums -- while the six
     surfels of the small scene (at most 6 x 256 pairs) always take the pair-major path."""
     _backward_case(gpu_device, 60, 32, 32, [2], seed=11, scale_lo=0.08, scale_hi=0.2, spread=0.2)
+
+
+def test_backward_medium_surfels(gpu_device):
+    """300 surfels of 3 .. 8 pixels across in a 32 x 32 image: ~100 and more entries per tile at ~30 pairs each -- segments on
+    either side of the pair table's capacity (kPairCap = 2528), i.e. both gradient kernels in one launch, and splats whose
+    radius reaches over a tile edge that getRect leaves out (the autograd oracle restates that rule)."""
+    _backward_case(gpu_device, 300, 32, 32, [3], seed=13, scale_lo=0.02, scale_hi=0.05, spread=0.2)
 
 
 def test_rasterizer_module_is_differentiable(gpu_device):
@@ -486,7 +496,7 @@ def test_backward_directional_derivatives_at_baseline_config2(gpu_device):
     gen = torch.Generator(device="cpu").manual_seed(11)
     wc = torch.rand(8, 3, 512, 512, generator=gen).to(gpu_device)
     wo = (torch.rand(8, 7, 512, 512, generator=gen) * 0.1).to(gpu_device)
-    wo[:, 5] = 0                                            # the median depth is not differentiable
+    wo[:, 5] = 0                                            # (the median contributor changes under steps of this size)
 
     def loss(m_, op_, sc_, rot_, rgb_):
         color, _, allmap, _ = rasterize_views(m_, op_, rgb_, sc_, rot_, vm, pm, bg, 512, 512)
