@@ -467,7 +467,7 @@ def bench_backward(m, o, c, s, r, cams, H, W, dev, reps=8):
     return {"forward_autograd_ms": round(float(np.median(fwd)), 4), "loss_plus_backward_ms": round(float(np.median(bwd)), 4),
             "grads_finite": bool(all(torch.isfinite(t.grad).all() for t in leaves)),
             "note": "forward through the autograd Function (own workspace per call); backward = ga_surfel_backward + the loss's "
-                    "elementwise kernels; per-kernel times: profiles/r2_backward_kernel_stats.txt"}
+                    "elementwise kernels (~0.1 ms); per-kernel times: profiles/r3_backward_kernel_stats.txt"}
 
 
 def bench_mesh_export(g, cams, dev):
