@@ -11,7 +11,7 @@
 // Launches (all on the caller's stream, nothing allocated):
 //   1. surfel_bwd_record_kernel      per (view, Gaussian): the forward's per-splat quantities once more -- Tu, Tv, Tw, the
 //      screen-space centre, the camera-facing normal, opacity, colour, the forward's cull half-extents -- as a 24-float record;
-//   2. (one extra workgroup of the same launch) every tile's depth-ordered list cut into 128-entry segments: first segment of
+//   2. (an extra grid row of the same launch) every tile's depth-ordered list cut into 128-entry segments: first segment of
 //      each tile, owner of each segment;
 //   3. the blend backward, ONE WORKGROUP PER SEGMENT in each of three launches (see the comment above BwdShared) with a
 //      one-workgroup-per-tile prefix launch after the first two: surfel_bwd_trans_kernel, surfel_bwd_prefix_T_kernel,
@@ -104,45 +104,28 @@ struct BwdPlan {   // the segment table and the per-(segment, pixel) exchange ar
     uint32_t max_segs;
 };
 
-// number of segments of every tile's list, their exclusive prefix and the owner of every segment (one workgroup)
+// The segment table, in closed form: the segments of tile vt are numbered from floor(tile_start[vt] / 128) + vt -- increasing with vt,
+// never overlapping (floor((a + n) / 128) - floor(a / 128) >= ceil(n / 128) - 1), at most one unused number between two tiles, all
+// below capacity / 128 + tiles -- so every tile fills in its own rows and no scan over the tiles is needed (round 2: one
+// workgroup, 27 us of serial scan).  One thread per tile.
 __device__ __forceinline__ void bwd_segtable(const uint32_t *__restrict__ tile_start, int vtiles, const BwdPlan &pl,
-                                             const int64_t *__restrict__ status)
+                                             const int64_t *__restrict__ status, int vt)
 {
-    __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) pl.big[0] = 0;
-    if (status[GA_STATUS_OVERFLOW]) { if (threadIdx.x == 0) pl.seg_base[vtiles] = 0; return; }
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int base = 0; base < vtiles; base += 1024) {
-        const int vt = base + (int)threadIdx.x;
-        uint32_t n = 0;
-        if (vt < vtiles) n = (tile_start[vt + 1] - tile_start[vt] + kBwdSeg - 1) / kBwdSeg;
-        uint32_t inc = n;
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += o;
-        }
-        if (lane == 63) wave_tot[wv] = inc;
-        __syncthreads();
-        uint32_t off = carry;
-        for (int w = 0; w < wv; ++w) off += wave_tot[w];
-        const uint32_t first = off + inc - n;
-        if (vt < vtiles) {
-            pl.seg_base[vt] = first;
-            for (uint32_t j = 0; j < n; ++j)
-                if (first + j < pl.max_segs) pl.seg_owner[first + j] = (uint32_t)vt;
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = off + inc;
-        __syncthreads();
+    const bool overflow = status[GA_STATUS_OVERFLOW] != 0;
+    if (vt == 0) {
+        pl.big[0] = 0;
+        pl.seg_base[vtiles] = overflow ? 0u : tile_start[vtiles] / kBwdSeg + (uint32_t)vtiles;   // (one past the last number in use)
     }
-    if (threadIdx.x == 0) pl.seg_base[vtiles] = carry;
+    if (overflow || vt >= vtiles) return;
+    const uint32_t beg = tile_start[vt], end = tile_start[vt + 1];
+    const uint32_t first = beg / kBwdSeg + (uint32_t)vt, n = (end - beg + kBwdSeg - 1) / kBwdSeg;
+    const uint32_t next_first = end / kBwdSeg + (uint32_t)vt + 1u;
+    pl.seg_base[vt] = first;
+    for (uint32_t j = first; j < next_first; ++j)
+        if (j < pl.max_segs) pl.seg_owner[j] = j < first + n ? (uint32_t)vt : 0xffffffffu;
 }
 
-
-// (grid row V: workgroup 0 builds the segment table -- a serial 20 us that would otherwise be a launch of its own)
+// (grid row V builds the segment table, one thread per tile)
 __global__ __launch_bounds__(1024) void surfel_bwd_record_kernel(const float *__restrict__ means3D, const float *__restrict__ opacities,
                                                                  const float *__restrict__ colors, const float *__restrict__ scales,
                                                                  const float *__restrict__ rotations, const float *__restrict__ viewmatrix,
@@ -153,7 +136,8 @@ __global__ __launch_bounds__(1024) void surfel_bwd_record_kernel(const float *__
                                                                  const int64_t *__restrict__ status)
 {
     if ((int)blockIdx.y == dm.V) {
-        if (blockIdx.x == 0) bwd_segtable(tile_start, dm.V * dm.tiles, pl, status);
+        for (int vt = (int)(blockIdx.x * 1024 + threadIdx.x); vt < max(dm.V * dm.tiles, 1); vt += (int)(gridDim.x * 1024))
+            bwd_segtable(tile_start, dm.V * dm.tiles, pl, status, vt);
         return;
     }
     const int v = blockIdx.y, i = blockIdx.x * 1024 + threadIdx.x;
@@ -300,6 +284,7 @@ __device__ __forceinline__ bool seg_context(const uint32_t *__restrict__ tile_st
 {
     const int vtiles = dm.V * dm.tiles;
     if (s >= pl.seg_base[vtiles] || s >= pl.max_segs) return false;
+    if (pl.seg_owner[s] == 0xffffffffu) return false;   // (a number between two tiles that no segment has)
     c.vt = (int)pl.seg_owner[s];
     c.s0 = pl.seg_base[c.vt];
     c.k = (int)(s - c.s0);
