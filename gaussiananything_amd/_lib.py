@@ -34,6 +34,7 @@ class GaSurfelForwardArgs(ctypes.Structure):
         ("out_color", ctypes.c_void_p), ("out_others", ctypes.c_void_p), ("radii", ctypes.c_void_p),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t), ("capacity", ctypes.c_int64),
         ("stage_events", ctypes.POINTER(ctypes.c_void_p)), ("seg_capacity", ctypes.c_int64),
+        ("seg_T", ctypes.c_void_p), ("seg_T_floats", ctypes.c_int64),
     ]
 
 

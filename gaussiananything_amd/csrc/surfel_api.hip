@@ -76,6 +76,7 @@ int ga_surfel_forward(const GaSurfelForwardArgs *a, void *stream_v)
         return GA_ERR_NULL_ARG;
     if (a->workspace_bytes < L.total_bytes) return GA_ERR_WORKSPACE;
     if (((uintptr_t)a->workspace & 255) != 0) return GA_ERR_WORKSPACE;
+    if (a->seg_T && a->seg_T_floats < (a->capacity / 128 + (int64_t)d.V * d.tiles + 1) * 256) return GA_ERR_WORKSPACE;
 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_v);
     unsigned char *w = static_cast<unsigned char *>(a->workspace);

@@ -14,7 +14,8 @@
 //   2. (an extra grid row of the same launch) every tile's depth-ordered list cut into 128-entry segments: first segment of
 //      each tile, owner of each segment;
 //   3. the blend backward, ONE WORKGROUP PER SEGMENT in each of three launches (see the comment above BwdShared) with a
-//      one-workgroup-per-tile prefix launch after the first two: surfel_bwd_trans_kernel, surfel_bwd_prefix_T_kernel,
+//      one-workgroup-per-tile prefix launch after the first two (the first pair -- trans and its prefix -- only when the forward did
+//      not leave the transmittances in fwd.seg_T, as the autograd path asks it to): surfel_bwd_trans_kernel, surfel_bwd_prefix_T_kernel,
 //      surfel_bwd_sums_kernel, surfel_bwd_prefix_sums_kernel, surfel_bwd_grad_kernel.  Per contributing (pixel, entry) pair
 //          v_i         = gC.c_i + gN.n_i + gD d_i + gDist (m_i^2 W - 2 m_i M1 + M2)     (dist = sum_{j<i} w_i w_j (m_i - m_j)^2)
 //          dL/dalpha_i = T_i v_i - (V - P_i) / (1 - alpha_i) - T_final (gC.bg - gA) / (1 - alpha_i),   P_i = sum_{j<=i} w_j v_j
@@ -1072,7 +1073,10 @@ extern "C" int ga_surfel_backward(const GaSurfelBackwardArgs *a, void *stream_v)
     BwdPlan pl;
     pl.seg_base = reinterpret_cast<uint32_t *>(sp + sc.seg_base);
     pl.seg_owner = reinterpret_cast<uint32_t *>(sp + sc.seg_owner);
-    pl.Tseg = reinterpret_cast<float *>(sp + sc.Tseg);
+    // the transmittance every pixel enters every segment with: left by the forward (fwd.seg_T), or formed here by two launches
+    const bool have_T = f.seg_T != nullptr;
+    if (have_T && f.seg_T_floats < (int64_t)sc.max_segs * 256) return GA_ERR_WORKSPACE;
+    pl.Tseg = have_T ? f.seg_T : reinterpret_cast<float *>(sp + sc.Tseg);
     pl.Tend = reinterpret_cast<float *>(sp + sc.Tend);
     pl.part = reinterpret_cast<float4 *>(sp + sc.part);
     pl.total = reinterpret_cast<float4 *>(sp + sc.totals);
@@ -1085,8 +1089,10 @@ extern "C" int ga_surfel_backward(const GaSurfelBackwardArgs *a, void *stream_v)
                        reinterpret_cast<const float *>(w + L.record), brec, grec, tile_start, pl, status);
     // (the grid covers the bound on the number of segments; the workgroups past the real count leave at once)
     const dim3 gridS(sc.max_segs);
-    hipLaunchKernelGGL(surfel_bwd_trans_kernel, gridS, dim3(256), 0, s, tile_start, point_list, brec, d, pl);
-    hipLaunchKernelGGL(surfel_bwd_prefix_T_kernel, dim3((unsigned)(d.V * d.tiles)), dim3(256), 0, s, tile_start, pl, d.V * d.tiles);
+    if (!have_T) {
+        hipLaunchKernelGGL(surfel_bwd_trans_kernel, gridS, dim3(256), 0, s, tile_start, point_list, brec, d, pl);
+        hipLaunchKernelGGL(surfel_bwd_prefix_T_kernel, dim3((unsigned)(d.V * d.tiles)), dim3(256), 0, s, tile_start, pl, d.V * d.tiles);
+    }
     hipLaunchKernelGGL(surfel_bwd_sums_kernel, gridS, dim3(256), 0, s, tile_start, point_list, brec, d, pl, a->grad_color,
                        a->grad_others);
     hipLaunchKernelGGL(surfel_bwd_prefix_sums_kernel, dim3((unsigned)(d.V * d.tiles)), dim3(256), 0, s, tile_start, pl, d.V * d.tiles);

@@ -311,26 +311,33 @@ struct Consumer {
 #define GA_BLEND_KU 4
 #endif
 
-template <bool FULL, bool WRAP>
+// STORE (the forward of a differentiable call, GaSurfelForwardArgs.seg_T): at every second chunk boundary -- the 128-entry
+// segments of ga_surfel_backward -- the pixel's transmittance (-1: its walk has ended) goes to tseg[(gc0 + i) / 2 * 256], gc0 = the
+// item's first chunk counted from the list's begin.  Lanes run ahead into the new chunk as always; a lane notes its transmittance
+// when it takes its first entry from there (three instructions per entry slot in those steps).
+template <bool FULL, bool WRAP, bool STORE = false>
 __device__ __forceinline__ void consume(Ring &ring, const Consumer &c, uint32_t nch, PixelAcc &a, bool &done, Stats &st, int flags,
-                                        Duty &duty)
+                                        Duty &duty, float *__restrict__ tseg = nullptr, uint32_t gc0 = 0)
 {
     // Per-lane survivor masks of a TWO-chunk window: `cur` = what is left of the previous chunk, `nxt` = the chunk fetched
     // in this step.  A lane that has finished `cur` runs ahead into `nxt` while slower lanes still work on `cur`; the step
     // ends when no lane has anything left in `cur`.
     unsigned long long cur = 0, nxt = 0;
     constexpr int kU = GA_BLEND_KU;
-    auto trips = [&](int oldb, int newb) {
+    float Tsnap = 0.0f;     // STORE: my transmittance on entering the chunk in `nxt` (-1: my walk ended before)
+    bool snapped = false;
+    auto trips = [&](int oldb, int newb, bool bstep = false) {
         // Lanes walk their own lists independently (compositing order only matters per pixel), kU entries per trip: the
         // kU gathers and alpha evaluations are mutually independent, then the contributing ones are composited in
         // order.  An exhausted lane re-reads its last slot with the live flag off.
         while (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
             int j[kU];
-            bool live[kU];
+            bool live[kU], ahead[kU];
             int last = newb;   // (a staged slot: an exhausted lane reads finite values)
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 const bool has = cur != 0;
+                ahead[u] = !has;
                 const unsigned long long sel = has ? cur : nxt;
                 live[u] = sel != 0;
                 j[u] = live[u] ? __builtin_ctzll(sel) + (has ? oldb : newb) : last;
@@ -352,6 +359,11 @@ __device__ __forceinline__ void consume(Ring &ring, const Consumer &c, uint32_t 
             for (int u = 0; u < kU; ++u) e[u] = eval_alpha(r[u], c.dxy);
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
+                if (STORE && bstep) {   // the first entry a lane takes from the new chunk: it crosses the segment boundary here
+                    const bool cross = ahead[u] && live[u] && !snapped;
+                    Tsnap = cross ? (done ? -1.0f : a.T) : Tsnap;
+                    snapped = snapped || cross;
+                }
                 if (FULL) {
                     composite(r[u], e[u], a, done, live[u] && e[u].pass && !done);
                 } else {
@@ -378,6 +390,8 @@ __device__ __forceinline__ void consume(Ring &ring, const Consumer &c, uint32_t 
         while (lds_load(&ring.stamp[slot]) != i + 1) __builtin_amdgcn_s_sleep(1);
         GA_LDS_ORDER();
         const unsigned long long mx = ring.masks[slot][c.col], my = ring.masks[slot][16 + c.row];
+        const bool bstep = STORE && ((gc0 + i) & 1u) == 0u;   // chunk i begins a 128-entry segment of the backward
+        snapped = false;
         nxt = done ? 0ull : (mx & my);
         if (flags & GA_SURFEL_FLAG_STATS) {
             unsigned pc = __builtin_popcountll(nxt);
@@ -386,7 +400,9 @@ __device__ __forceinline__ void consume(Ring &ring, const Consumer &c, uint32_t 
             st.useful += pc;
         }
         ++st.chunks;
-        trips((int)((i + kItemChunks - 1) % kItemChunks) * 64, slot * 64);   // until every lane has finished the previous chunk
+        trips((int)((i + kItemChunks - 1) % kItemChunks) * 64, slot * 64, bstep);   // until every lane has finished the previous chunk
+        if (bstep)   // (a lane that has not reached the new chunk yet enters it with what it has now)
+            tseg[(size_t)((gc0 + i) >> 1) * 256] = snapped ? Tsnap : (done ? -1.0f : a.T);
         cur = nxt;           // what is left of this chunk becomes the "previous chunk" of the next step
         nxt = 0;
         if (WRAP) {          // chunks < i are finished: their slots may be reused
@@ -395,6 +411,9 @@ __device__ __forceinline__ void consume(Ring &ring, const Consumer &c, uint32_t 
         }
     }
     trips((int)((i + kItemChunks - 1) % kItemChunks) * 64, 0);  // drain: `cur` is the last fetched chunk, `nxt` is empty
+    if (STORE)   // (left the loop early: every pixel's walk has ended)
+        for (uint32_t j = i; j < nch; ++j)
+            if (((gc0 + j) & 1u) == 0u) tseg[(size_t)((gc0 + j) >> 1) * 256] = -1.0f;
     if (flags & GA_SURFEL_FLAG_STATS) {
         for (int o = 32; o > 0; o >>= 1) mine = max(mine, (unsigned)__shfl_xor(mine, o, 64));
         st.lanemax += mine;
@@ -438,6 +457,7 @@ struct BlendArgs {
     float *__restrict__ out_others;
     uint32_t epoch;
     int flags;
+    float *__restrict__ seg_T;   // GaSurfelForwardArgs.seg_T (the STORE instantiation only)
 };
 
 // A segment's quadrant has published what it has to: count it; the last one of the tile's segments to arrive adds the partial
@@ -474,6 +494,7 @@ __device__ __forceinline__ void finish_segment(const BlendArgs &k, const Dims &d
     if (inside) write_pixel(r, k.bg, dm, v, pxi, pyi, k.out_color, k.out_others);
 }
 
+template <bool STORE>
 __device__ __forceinline__ void blend_item(Ring &ring, const BlendArgs &k, const Dims &dm, int lane, int wave, uint32_t pos,
                                            const uint4 sched, uint32_t seg, uint32_t nsegs, uint32_t work, uint32_t wstride,
                                            Stats &st)
@@ -498,6 +519,8 @@ __device__ __forceinline__ void blend_item(Ring &ring, const BlendArgs &k, const
     const bool last_seg = seg + 1 == nsegs;
     const float4 *rec4 = reinterpret_cast<const float4 *>(record) + (size_t)v * dm.N * (kRec / 4);
     const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
+    // my pixel's column of the backward's transmittance table (rows: the list's 128-entry segments, include/ga_surfel.h)
+    float *tseg = STORE ? k.seg_T + ((size_t)(beg / 128u + vt) * 256 + (size_t)(wave * 64 + lane)) : nullptr;
 
     // SATURATED TILE.  Once every pixel of the tile has ended its walk inside segment k (the stop rule fired, or the
     // segment's own transmittance product is already below it), the segments after k contribute nothing: a segment that
@@ -509,6 +532,9 @@ __device__ __forceinline__ void blend_item(Ring &ring, const BlendArgs &k, const
         const int col = (wave & 1) * 8 + (lane & 7), row = (wave >> 1) * 8 + (lane >> 3);
         const int pxi = tx * kTile + col, pyi = ty * kTile + row;
         const int px = wave * 64 + lane;
+        if (STORE)
+            for (uint32_t gc = c0; gc < c1; ++gc)
+                if ((gc & 1u) == 0u) tseg[(size_t)(gc >> 1) * 256] = -1.0f;
         if (!last_seg) xwg_store(seg_scratch + (size_t)work * kSegFloats + px, 0.0f, epoch);
         finish_segment(k, dm, lane, pos, work - seg * wstride, wstride, nsegs, px, v, pxi, pyi, pxi < dm.W && pyi < dm.H,
                        seg_sync + 8 * (size_t)pos + wave);
@@ -543,8 +569,8 @@ __device__ __forceinline__ void blend_item(Ring &ring, const BlendArgs &k, const
     }
 
     if (nsegs == 1) {
-        if (wraps) consume<true, true>(ring, c, nch, a, done, st, flags, duty);
-        else consume<true, false>(ring, c, nch, a, done, st, flags, duty);
+        if (wraps) consume<true, true, STORE>(ring, c, nch, a, done, st, flags, duty, tseg, 0u);
+        else consume<true, false, STORE>(ring, c, nch, a, done, st, flags, duty, tseg, 0u);
         if (inside) write_pixel(a, bg, dm, v, pxi, pyi, out_color, out_others);
     } else {
         const uint32_t work0 = work - seg * wstride;            // work item of segment 0 of this tile (segment k: + k * wstride)
@@ -567,7 +593,7 @@ __device__ __forceinline__ void blend_item(Ring &ring, const BlendArgs &k, const
         a = fresh_pixel(P);
         done = done || P < 0.0001f;  // T never falls below 1e-4 in the sequential loop: it stopped before this segment
         a.median = -1.0f;            // depths are >= near > 0: a negative median means "not set inside this segment"
-        consume<true, false>(ring, c, nch, a, done, st, flags, duty);
+        consume<true, false, STORE>(ring, c, nch, a, done, st, flags, duty, tseg, c0);
         unsigned long long *o = mine + 256 + px;
         const float part[14] = {a.N2C0.y, a.C12.x, a.C12.y, a.N01.x, a.N01.y, a.N2C0.x, a.Dp, a.M.x, a.M.y, a.dist,
                                 a.median, a.T, done ? 1.0f : 0.0f, P};
@@ -592,6 +618,7 @@ __device__ __forceinline__ void blend_item(Ring &ring, const BlendArgs &k, const
 #ifndef GA_BLEND_XCD_RUNS
 #define GA_BLEND_XCD_RUNS 3   // log2 of the run length (0: off)
 #endif
+template <bool STORE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WAVES, GA_BLEND_WAVES))) void surfel_blend_kernel(BlendArgs k, Dims dm, int ntiles,
                                                            uint32_t seg_region,
                                                            const uint32_t *__restrict__ seg_table,
@@ -656,7 +683,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
                 ring.sat_waves[0] = 0; ring.sat_waves[1] = 0;
             }
             __syncthreads();
-            blend_item(ring, ks, dm, lane, wave, pos, k.tile_order[pos], rel / ntile, nsegs, work, ntile, st);
+            blend_item<STORE>(ring, ks, dm, lane, wave, pos, k.tile_order[pos], rel / ntile, nsegs, work, ntile, st);
             __syncthreads();   // everybody has left the item: the LDS image and the ticket word may be overwritten
         }
     } else {
@@ -673,7 +700,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
         if (threadIdx.x < kItemChunks) ring.stamp[threadIdx.x] = 0;
         if (threadIdx.x < 4) ring.done[threadIdx.x] = 0;
         __syncthreads();
-        blend_item(ring, k, dm, lane, wave, pos, my_sched, 0u, 1u, 0u, 0u, st);
+        blend_item<STORE>(ring, k, dm, lane, wave, pos, my_sched, 0u, 1u, 0u, 0u, st);
     }
     if ((k.flags & GA_SURFEL_FLAG_STATS) && lane == 0) {
         atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_ITERS), (unsigned long long)st.iters);
@@ -691,9 +718,13 @@ void launch_blend(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &
     constexpr uint32_t kSegWGs = 512;   // two of the three workgroup slots of a CU; beyond that they loop
     const uint32_t seg_region = (uint32_t)std::min<int64_t>(a.capacity / 256, kSegWGs);
     const BlendArgs k{ws.tile_order, ws.point_list, ws.record, a.bg, ws.seg_sync, ws.seg_scratch, a.out_color, a.out_others,
-                      0u /* the segment workgroups read the launch epoch from the workspace */, a.flags};
-    hipLaunchKernelGGL(surfel_blend_kernel, dim3(seg_region + (unsigned)nt), dim3(256), 0, s, k, d, nt, seg_region,
-                       ws.seg_table, ws.status);
+                      0u /* the segment workgroups read the launch epoch from the workspace */, a.flags, a.seg_T};
+    if (a.seg_T)
+        hipLaunchKernelGGL(surfel_blend_kernel<true>, dim3(seg_region + (unsigned)nt), dim3(256), 0, s, k, d, nt, seg_region,
+                           ws.seg_table, ws.status);
+    else
+        hipLaunchKernelGGL(surfel_blend_kernel<false>, dim3(seg_region + (unsigned)nt), dim3(256), 0, s, k, d, nt, seg_region,
+                           ws.seg_table, ws.status);
 }
 
 }  // namespace ga

@@ -90,6 +90,20 @@ class SurfelWorkspace:
         return SurfelWorkspace(self.device, n, v, h, w, cap, seg)
 
 
+def _seg_T(ws):
+    """The transmittance table a differentiable forward leaves for ``ga_surfel_backward`` (GaSurfelForwardArgs.seg_T): one row of
+    256 floats per 128-entry list segment; kept with the workspace it was sized for.  ``GA_SURFEL_SEG_T=0``: do without (the
+    backward then walks the lists once more for these products; A/B aid)."""
+    if os.environ.get("GA_SURFEL_SEG_T", "1") == "0":
+        return None
+    t = getattr(ws, "seg_T", None)
+    if t is None:
+        n, v, h, w = ws.key
+        rows = ws.capacity // 128 + v * ((h + 15) // 16) * ((w + 15) // 16) + 1
+        t = ws.seg_T = torch.empty(rows * 256, dtype=torch.float32, device=ws.device)
+    return t
+
+
 def default_capacity(n, v):
     """Binned entries a fresh workspace is sized for: two tiles per (view, splat) on average -- BASELINE configs[1] needs 1.8;
     scenes that need more are reported by the device and the workspace is re-sized once."""
@@ -164,7 +178,7 @@ class _RasterizeViews(torch.autograd.Function):
         ws.generation = getattr(ws, "generation", 0) + 1
         while True:
             color, radii, allmap, _ = _rasterize_views_nograd(means3D, opacities, colors, scales, rotations, vm, pm, bg, h, w,
-                                                              scale_modifier, workspace=ws, check_overflow=False)
+                                                              scale_modifier, workspace=ws, check_overflow=False, for_backward=True)
             st = ws.status().cpu()
             if int(st[_lib.GA_STATUS_OVERFLOW]) == 0:
                 break
@@ -172,6 +186,7 @@ class _RasterizeViews(torch.autograd.Function):
             ws.generation = 1
         ctx.save_for_backward(means3D, opacities, colors, scales, rotations, vm, pm, bg, color, allmap, radii)
         ctx.ws, ctx.ws_generation, ctx.geom = ws, ws.generation, (n, v, h, w, float(scale_modifier))
+        ctx.seg_T = getattr(ws, "seg_T", None) if os.environ.get("GA_SURFEL_SEG_T", "1") != "0" else None
         ctx.mark_non_differentiable(radii)
         return color, radii, allmap
 
@@ -191,7 +206,8 @@ class _RasterizeViews(torch.autograd.Function):
         fwd = _lib.GaSurfelForwardArgs(
             n, v, h, w, mod, 0, means3D.data_ptr(), opacities.data_ptr(), colors.data_ptr(), scales.data_ptr(),
             rotations.data_ptr(), vm.data_ptr(), pm.data_ptr(), bg.data_ptr(), color.data_ptr(), allmap.data_ptr(),
-            radii.data_ptr(), ws.ptr, ws.layout.total_bytes, ws.capacity, None, ws.seg_capacity)
+            radii.data_ptr(), ws.ptr, ws.layout.total_bytes, ws.capacity, None, ws.seg_capacity,
+            ctx.seg_T.data_ptr() if ctx.seg_T is not None else None, ctx.seg_T.numel() if ctx.seg_T is not None else 0)
         nbytes = int(L.ga_surfel_backward_scratch_bytes(ctypes.byref(fwd)))
         if nbytes == 0:
             raise RuntimeError("ga_surfel_backward_scratch_bytes: bad shape")
@@ -242,7 +258,7 @@ def _f32g(t: torch.Tensor, name: str, device) -> torch.Tensor:
 
 def _rasterize_views_nograd(means3D, opacities, colors_precomp, scales, rotations, viewmatrix, projmatrix, bg,
                             image_height, image_width, scale_modifier=1.0, workspace: Optional[SurfelWorkspace] = None,
-                            check_overflow: bool = True, stage_events=None):
+                            check_overflow: bool = True, stage_events=None, for_backward: bool = False):
     """Rasterize V views of one Gaussian set.  ``viewmatrix`` / ``projmatrix``: ``[V,4,4]`` row-vector matrices
     (``cam_view`` / ``cam_view_proj``).  Returns ``color [V,3,H,W]``, ``radii [V,N] int32``, ``allmap [V,7,H,W]`` and
     the workspace used (its ``status()`` holds D / overflow / longest tile list).
@@ -280,11 +296,13 @@ def _rasterize_views_nograd(means3D, opacities, colors_precomp, scales, rotation
         raise ValueError("workspace was laid out for a different problem size")
     with torch.cuda.device(device):
         while True:
+            seg_T = _seg_T(ws) if for_backward else None     # (the forward of a differentiable call leaves it for the backward)
             args = _lib.GaSurfelForwardArgs(
                 n, v, h, w, float(scale_modifier), ws.clean_flag(), means3D.data_ptr(), opacities.data_ptr(), colors.data_ptr(),
                 scales.data_ptr(), rotations.data_ptr(), vm.data_ptr(), pm.data_ptr(), bg.data_ptr(),
                 color.data_ptr(), allmap.data_ptr(), radii.data_ptr(), ws.ptr, ws.layout.total_bytes, ws.capacity,
-                stage_events, ws.seg_capacity)
+                stage_events, ws.seg_capacity, seg_T.data_ptr() if seg_T is not None else None,
+                seg_T.numel() if seg_T is not None else 0)
             _lib.check(L.ga_surfel_forward(ctypes.byref(args), ctypes.c_void_p(stream)), "ga_surfel_forward")
             ws.clean = True      # its tile scan leaves the workspace head ready for the next forward
             if not check_overflow:

@@ -79,6 +79,14 @@ typedef struct GaSurfelForwardArgs {
                                 capacity / 2048 + 128.  The worst case is capacity / 256.  More work items than this is
                                 reported like D > capacity: GA_STATUS_OVERFLOW, nothing rendered, the number needed in
                                 GA_STATUS_SEG_WORK.  Same value as passed to ga_surfel_workspace_layout2.       */
+    float *seg_T;            /* optional (NULL = not wanted; inference never sets it), for ga_surfel_backward: the blend records,
+                                for every 128-entry segment k of every non-empty tile list and every pixel of the tile, the
+                                transmittance the pixel enters the segment with, or -1 when its walk ended earlier (pixel outside
+                                the image, stop rule).  Row floor(list begin / 128) + (view * tiles + tile) + k of 256 floats;
+                                pixel (x, y) of the tile at ((y >> 3) * 2 + (x >> 3)) * 64 + (y & 7) * 8 + (x & 7).  With it the
+                                backward does not walk the lists a first time for these products.  Costs the blend the
+                                run-ahead across every second 64-entry chunk boundary and 4 bytes per (segment, pixel).       */
+    int64_t seg_T_floats;    /* floats `seg_T` holds: at least (capacity / 128 + V * tiles + 1) * 256 (else GA_ERR_WORKSPACE) */
 } GaSurfelForwardArgs;
 
 #define GA_SURFEL_STAGE_EVENTS 5
@@ -166,6 +174,7 @@ typedef struct GaSurfelBackwardArgs {
     float *grad_colors;        /* [N,3]                                                          */
     float *grad_scales;        /* [N,2]                                                          */
     float *grad_rotations;     /* [N,4]  with respect to the quaternion as given (not normalised) */
+    /* (fwd.seg_T, when the forward was run with it: the transmittance pass and its prefix launch are skipped) */
 } GaSurfelBackwardArgs;
 size_t ga_surfel_backward_scratch_bytes(const GaSurfelForwardArgs *fwd);   /* 0: bad shape */
 int ga_surfel_backward(const GaSurfelBackwardArgs *args, void *stream);
