@@ -96,6 +96,10 @@ def lib():
                 f"{LIB_PATH} is missing: the MI355X HIP library has not been built "
                 "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C gaussiananything_amd/csrc`). "
                 "There is no CPU fallback for the product path.")
+        # torch first: the library's libamdhip64 dependency must resolve to the HIP runtime PyTorch has loaded (its streams and
+        # allocations are handed to the kernels); loaded the other way round -- e.g. build() and then smoke() in one process --
+        # the process ends up with the launches failing (GA_ERR_LAUNCH)
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name in EXPORTS:
             if not hasattr(L, name):
