@@ -682,7 +682,7 @@ def main():
                                  "lane_slot_utilisation": round(pairs / max(slots, 1.0), 4),
                                  "tflops_at_60flop_per_evaluated_pair": round(pairs * 60 / (stage["blend"] * 1e-3) / 1e12, 3),
                                  "peak_fp32_valu_tflops": FP32_VALU_PEAK_TFLOPS,
-                                 "note": "53.7 M wave-level VALU instructions per launch, LDS 22.5 M active cycles (profiles/r3_blend_pmc.txt); "
+                                 "note": "54.0 M wave-level VALU instructions per launch, LDS 22.5 M active cycles (profiles/r3_blend_pmc.txt); "
                                          "lanes = pixels of an 8x8 quadrant cannot exceed 0.53 lane use on this scene (tools/blend_sim.py)"}
             del splan
             out["stage_ms"] = {k: round(x, 5) for k, x in stage.items()}
