@@ -179,24 +179,27 @@ __device__ __forceinline__ void rowss_prefetch(const GemmP &p, RowSsPrefetch<MT>
 template <int EPI, int MT, int FN, bool PRE, bool RSSPRE>
 __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[FN][MT], const ResidualPrefetch<MT> *pre,
                                               const RowSsPrefetch<MT> *rss, int mrow0, int ncol0, int lane, float *emit_part = nullptr,
-                                              const f32x4 *bias_pre = nullptr, const f32x4 *qkw_pre = nullptr)
+                                              const f32x4 *bias_pre = nullptr, const f32x4 *qkw_pre = nullptr,
+                                              float *qk_mine = nullptr, const float *qk_other = nullptr)
 {
     static_assert(FN == 4 || FN == 2, "a wave owns 64 or 32 columns");
     const int M = p.M, N = p.N;
     // epilogue: lane holds acc[i][j][r] = C[m = mrow0 + j*16 + (lane&15)][n = ncol0 + i*16 + (lane>>4)*4 + r];
     // with FN = 4 the 64 columns of a wave are one attention head: its 64 values of row m sit in 4 fragments x 4 lane-groups x 4
     // registers, so the per-head RMSNorm is an in-lane sum plus two xor-shuffles
+    // (FN = 2: the wave holds one half of the head; the two waves of the 64-column workgroup tile exchange their halves of the sum
+    //  of squares through LDS -- qk_mine / qk_other, MT * 16 floats each -- with one workgroup barrier)
     const int nhead = ncol0, g = lane >> 4;
     const float *qkw = nullptr;
-    if (EPI == GA_GEMM_EPI_STORE_BF16 && FN == 4) {
+    if (EPI == GA_GEMM_EPI_STORE_BF16) {
         if (nhead < p.qk_cols0) qkw = p.qk_w0;
         else if (nhead < p.qk_cols1) qkw = p.qk_w1;
+        if (qkw && FN == 2) qkw += nhead & 63;
     }
-    const bool to_vt = EPI == GA_GEMM_EPI_STORE_BF16 && FN == 4 && p.vt && nhead >= p.vt_col0;  // wave-uniform (vt_col0 % 64 == 0)
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
+    const bool to_vt = EPI == GA_GEMM_EPI_STORE_BF16 && p.vt && nhead >= p.vt_col0;  // wave-uniform (vt_col0 % 64 == 0)
+    // bias and the folded row scale of row fragment j, applied to v
+    auto prepare = [&](int j, f32x4 (&v)[FN]) __attribute__((always_inline)) {
         const int m = mrow0 + j * 16 + (lane & 15);
-        f32x4 v[FN];
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
             const int n = nhead + i * 16 + g * 4;
@@ -224,12 +227,47 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[FN][M
 #pragma unroll
             for (int i = 0; i < FN; ++i) { v[i][0] *= rs; v[i][1] *= rs; v[i][2] *= rs; v[i][3] *= rs; }
         }
-        if (EPI == GA_GEMM_EPI_STORE_BF16 && FN == 4 && qkw) {  // wave-uniform
+    };
+    const bool halves = EPI == GA_GEMM_EPI_STORE_BF16 && FN == 2 && qk_mine != nullptr;   // workgroup-uniform
+    if (halves) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            f32x4 v[FN];
+            prepare(j, v);
             float ss = 0.f;
 #pragma unroll
-            for (int i = 0; i < FN; ++i) ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+            for (int i = 0; i < FN; ++i) {
+                acc[i][j] = v[i];
+                ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+            }
             ss += __shfl_xor(ss, 16, 64);
             ss += __shfl_xor(ss, 32, 64);
+            if (g == 0) qk_mine[j * 16 + (lane & 15)] = ss;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int m = mrow0 + j * 16 + (lane & 15);
+        f32x4 v[FN];
+        if (halves) {
+#pragma unroll
+            for (int i = 0; i < FN; ++i) v[i] = acc[i][j];
+        } else {
+            prepare(j, v);
+        }
+        if (EPI == GA_GEMM_EPI_STORE_BF16 && qkw && (FN == 4 || halves)) {  // wave-uniform
+            float ss;
+            if (FN == 4) {
+                ss = 0.f;
+#pragma unroll
+                for (int i = 0; i < FN; ++i) ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+                ss += __shfl_xor(ss, 16, 64);
+                ss += __shfl_xor(ss, 32, 64);
+            } else {   // (lower half first: the same sum in both waves)
+                const float mine = qk_mine[j * 16 + (lane & 15)], other = qk_other[j * 16 + (lane & 15)];
+                ss = (nhead & 32) ? other + mine : mine + other;
+            }
             const float rs = rsqrtf(ss * (1.0f / 64.0f) + 1e-5f);
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
@@ -556,12 +594,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
             bias_pre[i] = f32x4{b.x, b.y, b.z, b.w};
         }
     }
-    if (EPI == GA_GEMM_EPI_STORE_BF16 && FN == 4) {
+    if (EPI == GA_GEMM_EPI_STORE_BF16) {
         const float *qkw = ncol0 < p.qk_cols0 ? p.qk_w0 : (ncol0 < p.qk_cols1 ? p.qk_w1 : nullptr);
         if (qkw) {
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
-                const float4 w = *reinterpret_cast<const float4 *>(qkw + i * 16 + lg * 4);
+                const float4 w = *reinterpret_cast<const float4 *>(qkw + (ncol0 & 63) + i * 16 + lg * 4);
                 qkw_pre[i] = f32x4{w.x, w.y, w.z, w.w};
             }
         }
@@ -688,9 +726,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
         static_assert(WN == 2, "a 64-column tile is two 32-column waves");
         float *part = reinterpret_cast<float *>(smem) + (wn * WM + wm) * FM * 16;
         const bool emit = EPI == GA_GEMM_EPI_RESIDUAL && p.emit_ss;   // kernel-uniform
-        if (emit) __syncthreads();
+        // the workgroup's 64 columns are a q or k head with a per-head RMSNorm: its two waves exchange their halves of the row sums
+        const bool qk2 = EPI == GA_GEMM_EPI_STORE_BF16 && n0 < p.qk_cols1;   // workgroup-uniform
+        if (emit || qk2) __syncthreads();
         gemm_epilogue<EPI, FM, 2, PRE, RSS>(p, acc, reinterpret_cast<const ResidualPrefetch<FM> *>(&pre),
-                                            reinterpret_cast<const RowSsPrefetch<FM> *>(&rss), mrow0, ncol0, lane, part, bias_pre, qkw_pre);
+                                            reinterpret_cast<const RowSsPrefetch<FM> *>(&rss), mrow0, ncol0, lane, part, bias_pre, qkw_pre,
+                                            qk2 ? part : nullptr,
+                                            reinterpret_cast<const float *>(smem) + ((wn ^ 1) * WM + wm) * FM * 16);
         if (emit) {
             __syncthreads();
             const float *all = reinterpret_cast<const float *>(smem);
@@ -746,21 +788,24 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
     // Round 3: the ring kernel where its K loop applies (K a multiple of 256, at least 512).  Tile by how many workgroups it puts
     // on the 256 CUs (tools/gemm_lab.hip, tools/gemm_sweep.py): 192 x 128 / 8 waves when that fills at least 5/8 of the chip
     // (fc1, qkv, everything at M >= 6144), else 96 x 64 (proj, fc2: 256 workgroups at M = 1536), else 64 x 64 (the M = 768
-    // cross-attention projections).  The 96 x 64 tile has 32-column waves: not for the per-head q/k norm or the V^T store.
+    // cross-attention projections).  The 96 x 64 tile has 32-column waves: for the per-head q/k norm its two waves exchange
+    // their halves of the row sums of squares through LDS.
     {
         const int nk = a->K / BK;
         const long long wg_big = (long long)((a->N + 127) / 128) * ((a->M + 191) / 192);
         const long long wg_mid = (long long)((a->N + 63) / 64) * ((a->M + 95) / 96);
         const long long wg_small = (long long)((a->N + 63) / 64) * ((a->M + 63) / 64);
-        const bool wave64 = a->vt || a->qk_cols0 || a->qk_cols1;
         int ring = 0;
         if (nk % 4 == 0 && nk >= 8) {
             if (wg_big >= 160) ring = 1;
-            else if (!wave64 && wg_mid >= 160) ring = 2;
+            // (per-head norm on the 96 x 64 tile: its two 32-column waves exchange their sums through LDS, a barrier more than the
+            //  64-column waves of the other tiles need -- worth it while the grid is one residency round, 2 x 256 workgroups:
+            //  DiT-L's qkv at M = 768 13.4 -> 12.1 us; DiT-B's at M = 1536, 576 workgroups, is faster on 64 x 64, same-box A/B)
+            else if (wg_mid >= 160 && (!(a->qk_cols0 || a->qk_cols1) || wg_mid <= 512)) ring = 2;
             else if (wg_small >= 96) ring = 3;
         }
 #ifdef GA_TUNING  // tuning builds only: GA_GEMM_RING = 0 old kernel, 1 / 2 / 3 force a ring tile
-        if (const char *e = getenv("GA_GEMM_RING")) { const int c = atoi(e); if (c == 0 || (nk % 4 == 0 && nk >= 8 && c >= 1 && c <= 3 && !(c == 2 && wave64))) ring = c; }
+        if (const char *e = getenv("GA_GEMM_RING")) { const int c = atoi(e); if (c == 0 || (nk % 4 == 0 && nk >= 8 && c >= 1 && c <= 3)) ring = c; }
 #endif
         if (ring) {
             static bool ring_attr_set = false;

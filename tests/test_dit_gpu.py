@@ -83,6 +83,34 @@ def test_gemm_fused_qk_rmsnorm(gpu_device):
     assert rel_l2(out.float(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("M,H,K,L", [(768, 16, 1024, 768), (1536, 16, 1024, 768), (1536, 12, 768, 768), (400, 4, 512, 200)])
+def test_qkv_projection_with_head_norm_and_transposed_v_on_every_tile(gpu_device, M, H, K, L):
+    """The QKV projection as the DiT calls it -- per-head RMSNorm of q and k, V stored transposed -- at the shapes that pick the
+    96 x 64 tile (32-column waves: the head's sum of squares is exchanged between two waves through LDS; M = 768 of DiT-L,
+    M = 1536 of DiT-B), the 192 x 128 tile (M = 1536 of DiT-L) and the 64 x 64 one."""
+    from gaussiananything_amd import dit_ops as ops
+    D = H * 64
+    g = torch.Generator(device="cpu").manual_seed(M + H)
+    A = torch.randn(M, K, generator=g).to(gpu_device).bfloat16()
+    W = (torch.randn(3 * D, K, generator=g) / math.sqrt(K)).to(gpu_device).bfloat16()
+    bias = torch.randn(3 * D, generator=g).to(gpu_device)
+    wq = (1 + 0.3 * torch.randn(64, generator=g)).to(gpu_device)
+    wk = (1 + 0.3 * torch.randn(64, generator=g)).to(gpu_device)
+    B = M // L
+    Lp = (L + 63) // 64 * 64
+    vt = torch.zeros(B * D, Lp, device=gpu_device, dtype=torch.bfloat16)
+    out = ops.gemm(A, W, bias, ops.EPI_STORE_BF16, rows_per_batch=L, vt=vt, vt_col0=2 * D, qk_w0=wq, qk_cols0=D, qk_w1=wk, qk_cols1=2 * D)
+    ref = (A.float() @ W.float().T + bias).reshape(M, 3, H, 64)
+    nrm = lambda t, w: t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-5) * w  # noqa: E731
+    qk = torch.stack([nrm(ref[:, 0], wq), nrm(ref[:, 1], wk)], 1).reshape(M, 2 * D)
+    assert out.shape == (M, 2 * D) and rel_l2(out.float(), qk) < 1e-2
+    for h in (0, H - 1):     # no head's columns ended up under another head's norm
+        assert rel_l2(out[:, h * 64:(h + 1) * 64].float(), qk[:, h * 64:(h + 1) * 64]) < 1e-2
+    vref = ref[:, 2].reshape(B, L, H, 64).permute(0, 2, 3, 1).reshape(B * D, L)
+    assert rel_l2(vt[:, :L].float(), vref) < 1e-2
+    assert L == Lp or float(vt[:, L:].abs().max()) == 0.0
+
+
 def test_gemm_is_transpose_sensitive(gpu_device):
     """A = I with an asymmetric W: a swapped row/column mapping in the epilogue cannot pass."""
     from gaussiananything_amd import dit_ops as ops
