@@ -694,3 +694,30 @@ def test_ode_oracle_tableau_against_scipy_rk45():
         yi = y0 + h * sum(cc * kk for cc, kk in zip(oo.B[i], k))
         k.append(f(t0 + oo.A[i] * h, yi))
     assert np.allclose(yi, y_sp, rtol=1e-14, atol=1e-15)
+
+
+def test_backward_segment_numbers_in_closed_form_do_not_collide():
+    """csrc/surfel_backward.hip numbers the 128-entry segments of tile t's list from floor(tile_start[t] / 128) + t (and the blend
+    that leaves the transmittance table for it, csrc/surfel_blend.hip, does the same): no scan over the tiles.  The numbers of
+    consecutive tiles must not overlap, leave at most one number unused between two tiles, and stay below the row count both
+    sides allocate (capacity / 128 + tiles + 1) -- checked here on random list lengths including empty and exactly-full ones."""
+    rng = np.random.default_rng(7)
+    for trial in range(200):
+        tiles = int(rng.integers(1, 400))
+        kind = trial % 4
+        if kind == 0:
+            n = rng.integers(0, 700, tiles)
+        elif kind == 1:
+            n = rng.integers(0, 3, tiles) * 128            # empty and exactly full segments
+        elif kind == 2:
+            n = (rng.random(tiles) < 0.1) * rng.integers(1, 6000, tiles)     # mostly empty, a few long lists
+        else:
+            n = rng.integers(120, 137, tiles)
+        start = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+        first = start[:-1] // 128 + np.arange(tiles)
+        nseg = (n + 127) // 128
+        nxt = start[1:] // 128 + np.arange(tiles) + 1       # the next tile's first number (one past the last for the last tile)
+        assert np.all(first + nseg <= nxt)                   # no overlap
+        assert np.all(nxt - (first + nseg) <= 1)             # at most one unused number
+        capacity = int(start[-1])
+        assert int(nxt[-1]) <= capacity // 128 + tiles       # < the capacity / 128 + tiles + 1 rows allocated
