@@ -112,7 +112,35 @@ def default_capacity(n, v):
 
 _WS_CACHE_SLOTS = 8          # most recently used (device, N, V, H, W) workspaces kept alive; older ones are released
 _ws_cache = OrderedDict()
-_autograd_pool = {}           # (device, N, V, H, W) -> idle workspaces of the differentiable path (at most two kept per key)
+_AUTOGRAD_POOL_KEYS = 4       # shapes whose idle workspaces are kept (least recently used shape dropped first), two per shape
+_autograd_pool = OrderedDict()  # (device, N, V, H, W) -> idle workspaces of the differentiable path
+
+
+class _WorkspaceLease:
+    """Ownership of one workspace by one differentiable forward.  The backward reads the tile lists and transmittances of exactly
+    that forward, possibly several times (``retain_graph=True``: the reference's adaptive loss weight runs ``autograd.grad`` twice
+    before the final backward, dnnlib/util.py ``calculate_adaptive_weight``), so the workspace goes back to the pool when the
+    autograd node is FREED, not when a backward has run; stream order protects the reuse by a later forward."""
+
+    def __init__(self, ws, key):
+        self.ws, self.key = ws, key
+
+    def __del__(self):
+        try:
+            pool = _autograd_pool.setdefault(self.key, [])
+            _autograd_pool.move_to_end(self.key)
+            if len(pool) < 2 and not any(w is self.ws for w in pool):
+                pool.append(self.ws)
+            while len(_autograd_pool) > _AUTOGRAD_POOL_KEYS:
+                _autograd_pool.popitem(last=False)
+        except Exception:   # interpreter shutdown
+            pass
+
+
+def clear_workspaces():
+    """drop every cached / pooled rasterizer workspace (their device memory returns to the caching allocator)"""
+    _ws_cache.clear()
+    _autograd_pool.clear()
 
 
 def _get_workspace(device, n, v, h, w, replacement=None):
@@ -173,9 +201,9 @@ class _RasterizeViews(torch.autograd.Function):
         n, v = means3D.shape[0], vm.shape[0]
         # a workspace of its own until the backward has read it; taken from / returned to a small pool instead of a fresh
         # allocation per call
-        pool = _autograd_pool.setdefault((str(means3D.device), n, v, h, w), [])
+        key = (str(means3D.device), n, v, h, w)
+        pool = _autograd_pool.get(key) or []
         ws = pool.pop() if pool else SurfelWorkspace(means3D.device, n, v, h, w, default_capacity(n, v))
-        ws.generation = getattr(ws, "generation", 0) + 1
         while True:
             color, radii, allmap, _ = _rasterize_views_nograd(means3D, opacities, colors, scales, rotations, vm, pm, bg, h, w,
                                                               scale_modifier, workspace=ws, check_overflow=False, for_backward=True)
@@ -183,9 +211,8 @@ class _RasterizeViews(torch.autograd.Function):
             if int(st[_lib.GA_STATUS_OVERFLOW]) == 0:
                 break
             ws = ws.grown(st)
-            ws.generation = 1
         ctx.save_for_backward(means3D, opacities, colors, scales, rotations, vm, pm, bg, color, allmap, radii)
-        ctx.ws, ctx.ws_generation, ctx.geom = ws, ws.generation, (n, v, h, w, float(scale_modifier))
+        ctx.lease, ctx.geom = _WorkspaceLease(ws, key), (n, v, h, w, float(scale_modifier))
         ctx.seg_T = getattr(ws, "seg_T", None) if os.environ.get("GA_SURFEL_SEG_T", "1") != "0" else None
         ctx.mark_non_differentiable(radii)
         return color, radii, allmap
@@ -194,10 +221,7 @@ class _RasterizeViews(torch.autograd.Function):
     def backward(ctx, g_color, g_radii, g_allmap):
         means3D, opacities, colors, scales, rotations, vm, pm, bg, color, allmap, radii = ctx.saved_tensors
         n, v, h, w, mod = ctx.geom
-        ws, dev = ctx.ws, means3D.device
-        if ws.generation != ctx.ws_generation:
-            raise RuntimeError("the rasterizer workspace of this forward has been handed to a later forward: a second backward "
-                               "through the same graph (retain_graph=True) is not supported")
+        ws, dev = ctx.lease.ws, means3D.device   # (owned by this node until it is freed: any number of backwards)
         g_color = torch.zeros_like(color) if g_color is None else g_color.detach().float().contiguous()
         g_allmap = torch.zeros_like(allmap) if g_allmap is None else g_allmap.detach().float().contiguous()
         L = _lib.lib()
@@ -217,9 +241,6 @@ class _RasterizeViews(torch.autograd.Function):
         with torch.cuda.device(dev):
             stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             _lib.check(L.ga_surfel_backward(ctypes.byref(args), stream), "ga_surfel_backward")
-        pool = _autograd_pool.setdefault((str(dev), n, v, h, w), [])   # stream order protects the reuse by a later forward
-        if len(pool) < 2:
-            pool.append(ws)
         return d_means, d_op, d_col, d_sc, d_rot, None, None, None, None, None, None
 
 

@@ -1,1 +1,1 @@
-from .transport import ModelType, PathType, Sampler, SNRType, Transport, WeightType, create_transport  # noqa: F401
+from .sampler import Sampler, VelocityTransport, bind_reference_transport, create_transport, integrate  # noqa: F401

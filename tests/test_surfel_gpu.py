@@ -495,6 +495,46 @@ def test_rasterizer_module_is_differentiable(gpu_device):
         assert t.grad is not None and bool(torch.isfinite(t.grad).all()) and float(t.grad.abs().max()) > 0
 
 
+def test_retained_graphs_and_forwards_in_flight_keep_their_own_workspaces(gpu_device):
+    """The reference's training step (dnnlib/util.py calculate_adaptive_weight) runs autograd.grad(..., retain_graph=True) on one
+    render before the final backward, with other renders of the step alive: every differentiable forward owns its workspace until
+    its autograd node is freed -- several backwards through one node, and forwards issued between them, all see their own lists."""
+    from gaussiananything_amd import diff_surfel_rasterization as dsr
+    cams = synthetic.eval_cameras(2)
+    vm, pm = cams["cam_view"].to(gpu_device), cams["cam_view_proj"].to(gpu_device)
+    bg = torch.ones(3, device=gpu_device)
+    dsr.clear_workspaces()
+
+    def scene(seed):
+        g = synthetic.random_surfels(700, seed=seed)[0].to(gpu_device)
+        return [t.clone().requires_grad_(True) for t in synthetic.split_gaussians(g)]
+
+    def render(ins):
+        m, op, sc, rot, rgb = ins
+        color, _, allmap, _ = dsr.rasterize_views(m, op, rgb, sc, rot, vm, pm, bg, 64, 64)
+        return color.mean() + allmap[:, 1].mean() + 0.1 * allmap[:, 6].mean()
+
+    a, b = scene(1), scene(2)
+    want_a = torch.autograd.grad(render(a), a)
+    want_b = torch.autograd.grad(render(b), b)
+    la = render(a)                                            # forward A in flight
+    g1 = torch.autograd.grad(la, a, retain_graph=True)        # first backward through A
+    lb = render(b)                                            # forward B between two backwards of A
+    g2 = torch.autograd.grad(la, a, retain_graph=True)        # second backward through A
+    gb = torch.autograd.grad(lb, b)
+    g3 = torch.autograd.grad(la, a)                           # final backward through A
+    for got in (g1, g2, g3):
+        for x, y in zip(got, want_a):
+            assert torch.equal(x, y)
+    for x, y in zip(gb, want_b):
+        assert torch.equal(x, y)
+    del la, lb
+    import gc
+    gc.collect()
+    pool = dsr._autograd_pool[(str(a[0].device), 700, 2, 64, 64)]
+    assert 1 <= len(pool) <= 2 and len({id(w) for w in pool}) == len(pool)     # returned once each, bounded
+
+
 def test_renderer_is_differentiable_end_to_end(gpu_device):
     """GaussianRenderer2DGS.render with a Gaussian tensor that requires grad (training call sites, nsr/gs_surfel.py:41-202):
     same outputs as the inference path, and the gradient of a loss on image + alpha + normal + distortion reaches it."""
