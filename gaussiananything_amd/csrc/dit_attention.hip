@@ -402,12 +402,17 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
 template <int NW, int KS>
 static void launch_attention(const GaAttentionArgs &a, hipStream_t s)
 {
+    // K normalised while it is staged (not on the DiT path, which normalises K once per conditioning tensor): ONE instantiation, eight
+    // query waves and a single key group -- <8,2,true> / <4,3,true> spilt registers and <4,1,true> carried a private segment (round-3 review)
+    constexpr int QW = 8;
+    const bool knorm = a.k_norm_weight != nullptr;
+    const int rows = (knorm ? QW : NW) * 16;
 #if GA_ATTN_HEAD_MAJOR
-    const dim3 grid(a.heads * a.batch, (a.Lq + NW * 16 - 1) / (NW * 16), 1);
+    const dim3 grid(a.heads * a.batch, (a.Lq + rows - 1) / rows, 1);
 #else
-    const dim3 grid((a.Lq + NW * 16 - 1) / (NW * 16), a.heads, a.batch);
+    const dim3 grid((a.Lq + rows - 1) / rows, a.heads, a.batch);
 #endif
-    if (a.k_norm_weight) hipLaunchKernelGGL((attention_fwd_kernel<NW, KS, true>), grid, dim3(NW * KS * 64), 0, s, a);
+    if (knorm) hipLaunchKernelGGL((attention_fwd_kernel<QW, 1, true>), grid, dim3(QW * 64), 0, s, a);
     else hipLaunchKernelGGL((attention_fwd_kernel<NW, KS, false>), grid, dim3(NW * KS * 64), 0, s, a);
 }
 

@@ -1050,9 +1050,10 @@ extern "C" int ga_surfel_backward(const GaSurfelBackwardArgs *a, void *stream_v)
     Dims d;
     if (!bwd_dims(f, d)) return GA_ERR_BAD_SHAPE;
     GaSurfelWorkspaceLayout L;
-    const int rc = ga_surfel_workspace_layout(d.N, d.V, d.H, d.W, f.capacity, &L);
+    const int rc = ga_surfel_workspace_layout2(d.N, d.V, d.H, d.W, f.capacity, f.seg_capacity, &L);   // (the forward's own layout)
     if (rc != GA_OK) return rc;
-    if (!f.workspace || f.workspace_bytes < L.total_bytes || !f.out_color || !f.out_others || !f.radii || !f.bg || !f.viewmatrix ||
+    if (f.workspace && f.workspace_bytes < L.total_bytes) return GA_ERR_WORKSPACE;
+    if (!f.workspace || !f.out_color || !f.out_others || !f.radii || !f.bg || !f.viewmatrix ||
         !f.projmatrix || !a->grad_color || !a->grad_others || !a->scratch || !a->grad_means3D || !a->grad_opacities ||
         !a->grad_colors || !a->grad_scales || !a->grad_rotations)
         return GA_ERR_NULL_ARG;

@@ -1,4 +1,4 @@
-"""world_size-2 gloo run (CPU) of the multi-GPU layout: sample sharding + the single gather to rank 0."""
+"""world_size-2 and world_size-8 gloo runs (CPU) of the multi-GPU layout: sample sharding + the single gather to rank 0."""
 import os
 import socket
 import sys
@@ -69,6 +69,7 @@ def _cascade_per_rank_with_stand_ins(gd, rank, world):
 
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     from gaussiananything_amd import distributed as gd
@@ -90,22 +91,32 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_world_size_two_gloo():
+def _run_world(world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=300) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     assert all(r[0] for r in res)
-    assert sorted(sum((r[1] for r in res), [])) == list(range(5))
-    assert all(abs(r[2] - 2.0) < 1e-9 for r in res)
+    assert sorted(sum((r[1] for r in res), [])) == list(range(5))      # shard_samples(5, ...): every sample exactly once
+    assert all(abs(r[2] - float(world)) < 1e-9 for r in res)           # max over ranks of 1 + rank
+
+
+def test_world_size_two_gloo():
+    _run_world(2)
+
+
+def test_world_size_eight_gloo():
+    """the world size of BASELINE configs[4]: the [world, rounds, ...] -> sample-order reshuffle of cascade_per_rank and the gather
+    with eight ranks (two sample rounds per rank)"""
+    _run_world(8)
 
 
 def test_bench_gpus_n_starts_its_own_ranks():

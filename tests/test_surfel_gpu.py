@@ -523,11 +523,12 @@ def test_retained_graphs_and_forwards_in_flight_keep_their_own_workspaces(gpu_de
     g2 = torch.autograd.grad(la, a, retain_graph=True)        # second backward through A
     gb = torch.autograd.grad(lb, b)
     g3 = torch.autograd.grad(la, a)                           # final backward through A
+    close = lambda x, y: float((x - y).norm()) <= 1e-5 * float(y.norm()) + 1e-12   # noqa: E731  (float atomics: summation order)
     for got in (g1, g2, g3):
         for x, y in zip(got, want_a):
-            assert torch.equal(x, y)
+            assert close(x, y)
     for x, y in zip(gb, want_b):
-        assert torch.equal(x, y)
+        assert close(x, y)
     del la, lb
     import gc
     gc.collect()
