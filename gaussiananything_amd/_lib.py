@@ -41,7 +41,7 @@ class GaSurfelForwardArgs(ctypes.Structure):
 class GaSurfelWorkspaceLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_size_t) for n in (
         "status", "seg_sync", "tile_count", "tile_start", "tile_cursor", "tile_order", "run_table", "rect", "depth", "record", "keys",
-        "point_list", "seg_table", "seg_scratch", "total_bytes")]
+        "point_list", "seg_table", "seg_scratch", "view_total", "total_bytes")]
 
 
 class GaSurfelBackwardArgs(ctypes.Structure):

@@ -26,7 +26,7 @@ bool make_dims(int32_t N, int32_t V, int32_t H, int32_t W, ga::Dims *d)
 
 extern "C" {
 
-const char *ga_surfel_version(void) { return "ga_mi355 surfel gfx950 r3"; }
+const char *ga_surfel_version(void) { return "ga_mi355 surfel gfx950 r4"; }
 
 int ga_surfel_workspace_layout(int32_t num_points, int32_t num_views, int32_t image_height, int32_t image_width,
                                int64_t capacity, GaSurfelWorkspaceLayout *out)
@@ -47,8 +47,9 @@ int ga_surfel_workspace_layout2(int32_t num_points, int32_t num_views, int32_t i
     out->status = off;      off += align256(GA_STATUS_WORDS * sizeof(int64_t));
     out->seg_sync = off;    off += align256(8 * (cap / 1024 + 1) * 4);
     out->tile_count = off;  off += align256(nt * 4);
-    out->tile_start = off;  off += align256((nt + 1) * 4);
+    out->view_total = off;  off += align256((size_t)d.V * ga::kViewSlots * 8);
     out->tile_cursor = off; off += align256(nt * 4);
+    out->tile_start = off;  off += align256((nt + 1) * 4);   /* everything in front of it is cleared by the memset of a forward */
     out->tile_order = off;  off += align256(nt * 16);   /* uint4 (tile, begin, length, 0) per schedule slot */
     out->run_table = off;   off += align256((cap / GA_SURFEL_SORT_RUN + 1) * 16);  /* uint4 (tile, run, begin, length) */
     out->rect = off;        off += align256(nv * 4 * sizeof(uint16_t));
@@ -88,6 +89,7 @@ int ga_surfel_forward(const GaSurfelForwardArgs *a, void *stream_v)
     ws.tile_count = reinterpret_cast<uint32_t *>(w + L.tile_count);
     ws.tile_start = reinterpret_cast<uint32_t *>(w + L.tile_start);
     ws.tile_cursor = reinterpret_cast<uint32_t *>(w + L.tile_cursor);
+    ws.view_total = reinterpret_cast<unsigned long long *>(w + L.view_total);
     ws.tile_order = reinterpret_cast<uint4 *>(w + L.tile_order);
     ws.run_table = reinterpret_cast<uint4 *>(w + L.run_table);
     ws.rect = reinterpret_cast<uint16_t *>(w + L.rect);

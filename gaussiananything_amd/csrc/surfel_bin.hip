@@ -36,15 +36,38 @@ constexpr int kScanPer = 8;         // counters per thread and chunk
 constexpr int kClasses = 33;
 constexpr int kBigStash = 1024;     // (tile, count) of the lists longer than one sort run kept in LDS for the run table
 
-__global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(uint32_t *__restrict__ tile_count,
-                                                                uint32_t *__restrict__ seg_sync, uint32_t seg_sync_words,
-                                                                uint32_t *__restrict__ tile_start,
-                                                                uint32_t *__restrict__ tile_cursor,
-                                                                uint4 *__restrict__ tile_order,
-                                                                uint4 *__restrict__ run_table, int n,
-                                                                int64_t capacity, int64_t seg_capacity, uint32_t *__restrict__ seg_table,
-                                                                int64_t *__restrict__ status)
+struct ScanArgs {
+    uint32_t *__restrict__ tile_count;
+    uint32_t *__restrict__ seg_sync;
+    uint32_t seg_sync_words;
+    uint32_t *__restrict__ tile_start;
+    uint32_t *__restrict__ tile_cursor;
+    uint4 *__restrict__ tile_order;
+    uint4 *__restrict__ run_table;
+    int n;
+    int64_t capacity, seg_capacity;
+    uint32_t *__restrict__ seg_table;
+    int64_t *__restrict__ status;
+};
+
+// kOwnLaunch: the scan is a launch of its own in front of the fill (views of more than kLdsTiles tiles): it also sets the fill's
+// cursors to the list begins and clears the tile counters it has consumed.  Otherwise it is ONE WORKGROUP OF THE FILL LAUNCH
+// (surfel_fill_scan_kernel): the fill workgroups read the counters at the same time and work with relative cursors, and counters
+// and cursors are cleared by the per-tile sort.
+template <bool kOwnLaunch>
+__device__ __forceinline__ void tile_scan_body(const ScanArgs &a)
 {
+    uint32_t *__restrict__ tile_count = a.tile_count;
+    uint32_t *__restrict__ seg_sync = a.seg_sync;
+    const uint32_t seg_sync_words = a.seg_sync_words;
+    uint32_t *__restrict__ tile_start = a.tile_start;
+    uint32_t *__restrict__ tile_cursor = a.tile_cursor;
+    uint4 *__restrict__ tile_order = a.tile_order;
+    uint4 *__restrict__ run_table = a.run_table;
+    const int n = a.n;
+    const int64_t capacity = a.capacity, seg_capacity = a.seg_capacity;
+    uint32_t *__restrict__ seg_table = a.seg_table;
+    int64_t *__restrict__ status = a.status;
     __shared__ uint32_t wt[kScanPer * 16], wt_ex[kScanPer * 16];
     __shared__ uint32_t hist[16][kClasses];       // wave-private class counts, later wave-private rank counters
     __shared__ uint32_t wave_off[16][kClasses];   // class start + population of the lower waves
@@ -104,7 +127,7 @@ __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(uint32_t *__rest
         for (int k = 0; k < kScanPer; ++k) {
             const int i = cbase + k * 1024 + tid;
             ex[k] = wt_ex[k * 16 + wid] + x[k] - cnt[k];
-            if (i < n) { tile_start[i] = ex[k]; tile_cursor[i] = ex[k]; }
+            if (i < n) { tile_start[i] = ex[k]; if (kOwnLaunch) tile_cursor[i] = ex[k]; }
         }
     }
     // ---- totals (64-bit: the uint32 running offsets above wrap past 2^32; that case is reported as overflow) -------
@@ -256,10 +279,13 @@ __global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(uint32_t *__rest
     // Leave the accumulating words of the workspace head clean for the NEXT launch (the tile counters this kernel has consumed;
     // the arrival / saturation words, ticket and statistics words the blend of THIS launch starts from): a caller that passes
     // GA_SURFEL_FLAG_WORKSPACE_CLEAN then needs no clearing memset in front of the next forward (4.7 us + a launch boundary).
-    for (int i = tid; i < n; i += 1024) tile_count[i] = 0u;
+    if (kOwnLaunch)
+        for (int i = tid; i < n; i += 1024) tile_count[i] = 0u;
     for (uint32_t i = tid; i < seg_sync_words; i += 1024) seg_sync[i] = 0u;
     if (tid >= 4 && tid < GA_STATUS_WORDS && tid != GA_STATUS_LONG_TILES && tid != GA_STATUS_SEG_WORK) status[tid] = 0;
 }
+
+__global__ __launch_bounds__(1024) void surfel_tile_scan_kernel(ScanArgs a) { tile_scan_body<true>(a); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // 3. fill.  One workgroup = 256 threads x kBinSplats consecutive Gaussians of one view (blockIdx.y), three LDS-aggregated
@@ -312,6 +338,121 @@ __global__ __launch_bounds__(256) void surfel_fill_kernel(const uint16_t *__rest
                 const int t = ty * dm.gx + tx;
                 const uint32_t pos = kLds ? basep[t] + atomicAdd(cnt + t, 1u) : atomicAdd(cur + t, 1u);
                 keys[pos] = key;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 2 + 3 in ONE launch (views of at most kLdsTiles tiles -- every practical size).  The single-workgroup scan above is 17 us of
+// pure latency in front of a fill that is 17 us of latency itself (round 3: 36 us of the 105 us front-end); neither needs the
+// other's RESULT if every fill workgroup derives the list begins it needs on its own:
+//   begin(v, t) = sum of the entry counts of the views before v  (view_total[], accumulated by the preprocess: 64 V words)
+//               + exclusive scan of view v's OWN tile counters up to t (<= kLdsTiles words, read from L2, scanned in LDS)
+// -- a few microseconds of redundant work per workgroup, all workgroups in parallel.  Slots inside a list are claimed from a
+// RELATIVE cursor (zero between launches).  The schedule of the later kernels (tile_order by length class, run table, segment table,
+// status words, tile_start[] for everybody else) is still one workgroup's scan over all V * tiles counters: row 0 of this grid, running
+// beside the fill instead of in front of it.  Grid (x, 1 + V) x 1024 threads: row 0 = (block 0) the schedule, row 1 + v = fill of view v,
+// kFillSplats consecutive Gaussians per thread.
+constexpr int kFillSplats = 2;
+
+__global__ __launch_bounds__(1024) void surfel_fill_scan_kernel(ScanArgs sa, const uint16_t *__restrict__ rect,
+                                                                const float *__restrict__ depth, Dims dm,
+                                                                const unsigned long long *__restrict__ view_total,
+                                                                uint64_t *__restrict__ keys)
+{
+    extern __shared__ uint32_t lds[];  // [tiles] counts -> ranks, [tiles] list begins -> segment bases of this workgroup
+    __shared__ uint32_t wave_sum[16];
+    __shared__ unsigned long long wave_base[16], wave_all[16];
+    if (blockIdx.y == 0) {
+        if (blockIdx.x == 0) tile_scan_body<false>(sa);
+        return;
+    }
+    const int v = (int)blockIdx.y - 1, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int T = dm.tiles;
+    uint32_t *cnt = lds, *basep = lds + T;
+    const uint32_t *tcv = sa.tile_count + (size_t)v * T;
+    uint32_t *cur = sa.tile_cursor + (size_t)v * T;
+    // everything this workgroup reads from memory, requested together
+    ushort4 rcs[kFillSplats];
+#pragma unroll
+    for (int k = 0; k < kFillSplats; ++k) {
+        const int i = (blockIdx.x * kFillSplats + k) * 1024 + tid;
+        rcs[k] = i < dm.N ? *reinterpret_cast<const ushort4 *>(rect + 4 * ((size_t)v * dm.N + i)) : make_ushort4(0, 0, 0, 0);
+    }
+    const int per = (T + 1023) / 1024;          // consecutive tile counters per thread (<= kLdsTiles / 1024 = 8)
+    uint32_t tc[kLdsTiles / 1024];
+#pragma unroll
+    for (int j = 0; j < kLdsTiles / 1024; ++j) {
+        const int t = tid * per + j;
+        tc[j] = (j < per && t < T) ? tcv[t] : 0u;
+    }
+    unsigned long long before = 0, all = 0;     // entries of the views before mine / of all views
+    for (int u = tid; u < dm.V * kViewSlots; u += 1024) {
+        const unsigned long long c = view_total[u];
+        all += c;
+        if (u < v * kViewSlots) before += c;
+    }
+    for (int t = tid; t < T; t += 1024) cnt[t] = 0;
+    // exclusive scan of my view's counters: thread-local, wave (shuffles), 16 wave totals
+    uint32_t loc = 0;
+#pragma unroll
+    for (int j = 0; j < kLdsTiles / 1024; ++j) loc += tc[j];
+    uint32_t x = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        before += __shfl_down(before, o, 64);
+        all += __shfl_down(all, o, 64);
+    }
+    if (lane == 63) wave_sum[wid] = x;
+    if (lane == 0) { wave_base[wid] = before; wave_all[wid] = all; }
+    __syncthreads();
+    unsigned long long vbase = 0, total = 0;
+    uint32_t wbase = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        vbase += wave_base[w];
+        total += wave_all[w];
+        wbase += w < wid ? wave_sum[w] : 0u;
+    }
+    // the overflow the schedule workgroup reports in the status words (D > capacity): nothing may be written
+    if (total > (unsigned long long)sa.capacity || total > 0xFFFFFFFFull) return;
+    {
+        uint32_t run = (uint32_t)vbase + wbase + x - loc;
+#pragma unroll
+        for (int j = 0; j < kLdsTiles / 1024; ++j) {
+            const int t = tid * per + j;
+            if (j < per && t < T) basep[t] = run;
+            run += tc[j];
+        }
+    }
+    // a) the workgroup's entries per tile
+#pragma unroll
+    for (int k = 0; k < kFillSplats; ++k)
+        for (int ty = rcs[k].y; ty < rcs[k].w; ++ty)
+            for (int tx = rcs[k].x; tx < rcs[k].z; ++tx) atomicAdd(cnt + ty * dm.gx + tx, 1u);
+    __syncthreads();
+    // b) reserve [base, base + count) in each touched tile's list: ONE returning atomic on the tile's relative cursor
+    for (int t = tid; t < T; t += 1024) {
+        const uint32_t c = cnt[t];
+        if (c) { basep[t] += atomicAdd(cur + t, c); cnt[t] = 0; }
+    }
+    __syncthreads();
+    // c) ranks inside the workgroup from returning LDS atomics; keys
+#pragma unroll
+    for (int k = 0; k < kFillSplats; ++k) {
+        const ushort4 rc = rcs[k];
+        if (rc.z <= rc.x || rc.w <= rc.y) continue;
+        const int i = (blockIdx.x * kFillSplats + k) * 1024 + tid;
+        const uint64_t key = ((uint64_t)__float_as_uint(depth[(size_t)v * dm.N + i]) << 32) | (uint32_t)i;
+        for (int ty = rc.y; ty < rc.w; ++ty)
+            for (int tx = rc.x; tx < rc.z; ++tx) {
+                const int t = ty * dm.gx + tx;
+                keys[basep[t] + atomicAdd(cnt + t, 1u)] = key;
             }
     }
 }
@@ -466,11 +607,12 @@ __device__ __forceinline__ void bitonic_sort_lds(double *s, int np, int tid)
 __device__ __forceinline__ bool sort_block_assignment(const uint4 *__restrict__ tile_order,
                                                       const uint4 *__restrict__ run_table,
                                                       const int64_t *__restrict__ status, uint32_t max_extra,
-                                                      uint32_t b, uint32_t &run, uint32_t &beg, int &n)
+                                                      uint32_t b, uint32_t &run, uint32_t &beg, int &n, uint32_t *tile_out = nullptr)
 {
     const bool extra = b < max_extra;
     const uint4 rec = extra ? run_table[b] : tile_order[b - max_extra];
     const int64_t overflow = status[GA_STATUS_OVERFLOW], extra_runs = status[GA_STATUS_EXTRA_RUNS];
+    if (tile_out) *tile_out = extra ? 0xFFFFFFFFu : rec.x;   // (schedule slots: written by the scan whatever the overflow state)
     if (overflow || (extra && (int64_t)b >= extra_runs)) return false;
     run = extra ? rec.y : 0u;
     beg = extra ? rec.z : rec.y;
@@ -482,13 +624,21 @@ __global__ __launch_bounds__(256) void surfel_run_sort_kernel(const uint4 *__res
                                                               const uint4 *__restrict__ run_table,
                                                               uint32_t max_extra, uint64_t *__restrict__ keys,
                                                               uint32_t *__restrict__ point_list,
-                                                              const int64_t *__restrict__ status)
+                                                              const int64_t *__restrict__ status,
+                                                              uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_cursor,
+                                                              unsigned long long *__restrict__ view_total, int nviews)
 {
     __shared__ __attribute__((aligned(16))) double s[kSortCap];  // raw key bits (see bitonic_sort_blocked)
-    uint32_t run, beg;
+    uint32_t run, beg, vt;
     int n;
-    if (!sort_block_assignment(tile_order, run_table, status, max_extra, blockIdx.x, run, beg, n)) return;
-    if (n <= 0) return;
+    const bool go = sort_block_assignment(tile_order, run_table, status, max_extra, blockIdx.x, run, beg, n, &vt);
+    // Leave the accumulating words of the binning clean for the NEXT launch (GA_SURFEL_FLAG_WORKSPACE_CLEAN): every schedule slot's
+    // workgroup clears its tile's counter and fill cursor -- the fill launch that read them is complete -- and the first one the
+    // view totals.  (The segment / status words are cleared by the scan workgroup.)
+    if (vt != 0xFFFFFFFFu && threadIdx.x == 0) { tile_count[vt] = 0u; tile_cursor[vt] = 0u; }
+    if (blockIdx.x == max_extra)
+        for (int u = threadIdx.x; u < nviews * kViewSlots; u += 256) view_total[u] = 0ull;
+    if (!go || n <= 0) return;
     const int tid = threadIdx.x;
     if (n == 1) { if (tid == 0) point_list[beg] = (uint32_t)keys[beg]; return; }
     const int rb = (int)run * kSortCap, rn = min(kSortCap, n - rb);
@@ -589,16 +739,17 @@ __global__ __launch_bounds__(256) void surfel_run_merge_kernel(const uint4 *__re
 void launch_binning(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &ws, hipStream_t s)
 {
     const int nt = d.V * d.tiles;
-    hipLaunchKernelGGL(surfel_tile_scan_kernel, dim3(1), dim3(1024), 0, s, ws.tile_count, ws.seg_sync,
-                       (uint32_t)(8 * ((size_t)a.capacity / 1024 + 1)), ws.tile_start,
-                       ws.tile_cursor, ws.tile_order, ws.run_table, nt, a.capacity, seg_items(a.capacity, a.seg_capacity), ws.seg_table, ws.status);
+    const ScanArgs sa{ws.tile_count, ws.seg_sync, (uint32_t)(8 * ((size_t)a.capacity / 1024 + 1)), ws.tile_start, ws.tile_cursor,
+                      ws.tile_order, ws.run_table, nt, a.capacity, seg_items(a.capacity, a.seg_capacity), ws.seg_table, ws.status};
+    if (d.tiles <= kLdsTiles) {
+        const unsigned nbx = (unsigned)std::max(1, (d.N + 1024 * kFillSplats - 1) / (1024 * kFillSplats));
+        hipLaunchKernelGGL(surfel_fill_scan_kernel, dim3(nbx, (unsigned)d.V + 1u), dim3(1024), 2 * d.tiles * sizeof(uint32_t), s, sa,
+                           ws.rect, ws.depth, d, ws.view_total, ws.keys);
+        return;
+    }
+    hipLaunchKernelGGL(surfel_tile_scan_kernel, dim3(1), dim3(1024), 0, s, sa);
     const dim3 grid((unsigned)((d.N + 256 * kBinSplats - 1) / (256 * kBinSplats)), (unsigned)d.V);
-    if (d.tiles <= kLdsTiles)
-        hipLaunchKernelGGL(surfel_fill_kernel<true>, grid, dim3(256), 2 * d.tiles * sizeof(uint32_t), s, ws.rect,
-                           ws.depth, d, ws.tile_cursor, ws.keys, ws.status);
-    else
-        hipLaunchKernelGGL(surfel_fill_kernel<false>, grid, dim3(256), 0, s, ws.rect, ws.depth, d, ws.tile_cursor,
-                           ws.keys, ws.status);
+    hipLaunchKernelGGL(surfel_fill_kernel<false>, grid, dim3(256), 0, s, ws.rect, ws.depth, d, ws.tile_cursor, ws.keys, ws.status);
 }
 
 void launch_tile_sort(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &ws, hipStream_t s)
@@ -606,7 +757,7 @@ void launch_tile_sort(const GaSurfelForwardArgs &a, const Dims &d, const Workspa
     const uint32_t nt = (uint32_t)(d.V * d.tiles);
     const uint32_t max_extra = (uint32_t)(a.capacity / kSortCap + 1);
     hipLaunchKernelGGL(surfel_run_sort_kernel, dim3(nt + max_extra), dim3(256), 0, s, ws.tile_order,
-                       ws.run_table, max_extra, ws.keys, ws.point_list, ws.status);
+                       ws.run_table, max_extra, ws.keys, ws.point_list, ws.status, ws.tile_count, ws.tile_cursor, ws.view_total, d.V);
     // lists longer than one run sit at the front of tile_order and there are fewer than capacity / kSortCap of them
     const uint32_t max_big = (uint32_t)std::min<int64_t>(nt, a.capacity / kSortCap);
     hipLaunchKernelGGL(surfel_run_merge_kernel, dim3((max_big + max_extra) * kMergeParts), dim3(256), 0, s, ws.tile_order,

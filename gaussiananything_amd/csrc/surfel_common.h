@@ -34,6 +34,7 @@ constexpr int kBinSplats = GA_BIN_SPLATS;           // splats per thread in the 
 #define GA_PRE_SPLATS 2
 #endif
 constexpr int kPreSplats = GA_PRE_SPLATS;  // splats per thread in the preprocess kernel
+constexpr int kViewSlots = 64;          // words the per-view entry count is spread over (same-address atomics serialise)
 constexpr int kLdsTiles = 8192;         // per-view tile counters aggregated in LDS up to this many tiles (32 KiB)
 // Segmented blend: lists of >= kLongList entries (length class >= kSegClass; class b holds 2^(b-1) <= n < 2^b) are cut into
 // seg_count(b) segments of 256..512 entries, each blended by its own workgroup; a segment (<= kItemChunks chunks of 64)
@@ -69,6 +70,7 @@ struct Workspace {
     uint32_t *seg_table;  // [2 * 40] per class b: (first tile_order slot, first segment work item)
     unsigned long long *seg_scratch;   // (value, launch epoch) words, see surfel_blend.hip
     uint32_t *tile_count, *tile_start, *tile_cursor;
+    unsigned long long *view_total;   // [V][kViewSlots] entries per view (sum of its tile counters) in kViewSlots partial counts
     uint4 *tile_order;   // schedule of the per-tile kernels, longest lists first: (tile, list begin, list length, 0)
     uint4 *run_table;    // runs 1.. of the lists longer than one sort run: (tile, run, list begin, list length)
     uint16_t *rect;

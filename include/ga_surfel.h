@@ -106,7 +106,7 @@ typedef struct GaSurfelWorkspaceLayout {
                            saturation word of the segmented blend; cleared with the status words */
     size_t tile_count;  /* uint32[V*tiles]   entries per (view, tile)                             */
     size_t tile_start;  /* uint32[V*tiles+1] exclusive scan of tile_count                         */
-    size_t tile_cursor; /* uint32[V*tiles]   scratch of the fill pass                             */
+    size_t tile_cursor; /* uint32[V*tiles]   scratch of the fill pass: slots of the tile's list handed out so far (zero between launches) */
     size_t tile_order;  /* uint32[V*tiles]   (view,tile) ids, longest lists first: workgroup -> tile schedule */
     size_t run_table;   /* uint32[2*(capacity/GA_SURFEL_SORT_RUN+1)] (tile id, run index) of the 2nd.. sort runs of long lists */
     size_t rect;        /* uint16[V*N*4]     tile rect min.x min.y max.x max.y (0 when culled)    */
@@ -119,6 +119,8 @@ typedef struct GaSurfelWorkspaceLayout {
                            value) */
     size_t seg_scratch; /* uint64[seg_capacity * 15 * 256] per segment: transmittance + 14 partial sums per pixel,
                            each word (value, launch epoch) */
+    size_t view_total;  /* uint64[V][64]     entries per view (sum of its tile counters) as 64 partial counts, accumulated by the
+                           preprocess; in the head region that is cleared with the status words */
     size_t total_bytes;
 } GaSurfelWorkspaceLayout;
 

@@ -410,7 +410,10 @@ def test_workspace_layout_and_argument_errors_without_a_gpu():
     lay = _lib.GaSurfelWorkspaceLayout()
     assert L.ga_surfel_workspace_layout(100000, 8, 512, 512, 3_200_000, ctypes.byref(lay)) == 0
     offs = [getattr(lay, n) for n, _ in lay._fields_]
-    assert offs == sorted(offs) and all(o % 256 == 0 for o in offs) and lay.total_bytes < 2 ** 31
+    assert len(set(offs)) == len(offs) and all(o % 256 == 0 for o in offs) and lay.total_bytes == max(offs) < 2 ** 31
+    # the words a forward accumulates into sit in front of tile_start: one memset clears them (or the previous forward left them clean)
+    head = ("status", "seg_sync", "tile_count", "view_total", "tile_cursor")
+    assert max(getattr(lay, n) for n in head) < lay.tile_start == min(getattr(lay, n) for n, _ in lay._fields_ if n not in head)
     assert L.ga_surfel_workspace_layout(-1, 8, 512, 512, 10, ctypes.byref(lay)) == -2       # GA_ERR_BAD_SHAPE
     assert L.ga_surfel_workspace_layout(10, 1, 16 * 70000, 16, 10, ctypes.byref(lay)) == -2
     assert L.ga_surfel_forward(None, None) == -1                                            # GA_ERR_NULL_ARG

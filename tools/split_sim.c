@@ -14,7 +14,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#define NPOL 12
+static const int polK[NPOL] = {8, 8, 10, 10, 12, 12, 16, 16, 24, 32, 10, 12};
+static const int polF[NPOL] = {4, 8, 4, 8, 4, 8, 4, 8, 8, 8, 1000, 1000};
 typedef struct {
+    double polslots[NPOL], polflush[NPOL], quad_iters, quad_chunks;
     double cand_all, pass_all, cand_walk, pass_walk, candA, passA, slotsB_quad, slotsB_sorted, slotsB_sorted_tile, groups, itersA,
         max_group_pairs, entriesA;
 } SplitOut;
@@ -41,6 +45,9 @@ void split_sim(int H, int W_img, int ntx, int nty, const uint32_t *ranges, const
                 }
             int tot[256];
             memset(tot, 0, sizeof(tot));
+            int pc[NPOL][256], pmax[NPOL][4], plast[NPOL][4];   /* policy state: per-pixel counts, per-quadrant max, chunk of the last flush */
+            memset(pc, 0, sizeof(pc)); memset(pmax, 0, sizeof(pmax)); memset(plast, 0, sizeof(plast));
+            int qpairs[4] = {0, 0, 0, 0}, qchunk = -1;
             static int gcnt[4096][256];   /* per group per pixel passing-and-walked count */
             const int ngroups = (n + G - 1) / G;
             if (ngroups > 4096) continue;
@@ -51,6 +58,19 @@ void split_sim(int H, int W_img, int ntx, int nty, const uint32_t *ranges, const
                 double gp = 0;
                 for (int j = gb; j < ge; ++j) {
                     const uint32_t id = point_list[r0 + j];
+                    if (G == 64 && kU == 1) {   /* (policies are evaluated once: in the G = 64, kU = 1 run) */
+                        const int ch = j / 64;
+                        if (ch != qchunk) {
+                            for (int q = 0; q < 4; ++q) { if (qchunk >= 0 && j <= maxwalk + 63) { out->quad_iters += (qpairs[q] + 63) / 64; out->quad_chunks += 1; } qpairs[q] = 0; }
+                            qchunk = ch;
+                            for (int p = 0; p < NPOL; ++p)
+                                for (int q = 0; q < 4; ++q)
+                                    if (pmax[p][q] > 0 && ch - plast[p][q] >= polF[p]) {   /* forced flush: the record ring wraps */
+                                        out->polslots[p] += 64.0 * pmax[p][q]; out->polflush[p] += 1; pmax[p][q] = 0; plast[p][q] = ch;
+                                        for (int l = 0; l < 64; ++l) pc[p][((q >> 1) * 8 + (l >> 3)) * 16 + (q & 1) * 8 + (l & 7)] = 0;
+                                    }
+                        }
+                    }
                     const float *Tu = trans + 9 * id, *Tv = Tu + 3, *Tw = Tu + 6;
                     for (int y = 0; y < 16; ++y) {
                         const float pyf = (float)(ty * 16 + y);
@@ -76,6 +96,18 @@ void split_sim(int H, int W_img, int ntx, int nty, const uint32_t *ranges, const
                             out->cand_walk += w; out->pass_walk += pass && w;
                             if (evaluated) { out->candA += 1; out->passA += pass; gp += 1; }
                             if (pass && w) { gcnt[g][y * 16 + x]++; tot[y * 16 + x]++; }
+                            if (G == 64 && kU == 1) {
+                                const int q = (y >> 3) * 2 + (x >> 3);
+                                if (evaluated) qpairs[q]++;
+                                if (pass && w)
+                                    for (int p = 0; p < NPOL; ++p) {
+                                        if (pc[p][y * 16 + x] == polK[p]) {   /* full: flush the quadrant now, then append */
+                                            out->polslots[p] += 64.0 * pmax[p][q]; out->polflush[p] += 1; pmax[p][q] = 0; plast[p][q] = j / 64;
+                                            for (int l = 0; l < 64; ++l) pc[p][((q >> 1) * 8 + (l >> 3)) * 16 + (q & 1) * 8 + (l & 7)] = 0;
+                                        }
+                                        if (++pc[p][y * 16 + x] > pmax[p][q]) pmax[p][q] = pc[p][y * 16 + x];
+                                    }
+                            }
                         }
                     }
                 }
@@ -83,6 +115,12 @@ void split_sim(int H, int W_img, int ntx, int nty, const uint32_t *ranges, const
                     out->groups += 1; out->itersA += ceil(gp / 64.0); out->entriesA += ge - gb;
                     if (gp > out->max_group_pairs) out->max_group_pairs = gp;
                 }
+            }
+            if (G == 64 && kU == 1) {
+                for (int q = 0; q < 4; ++q) { if (qchunk >= 0) { out->quad_iters += (qpairs[q] + 63) / 64; out->quad_chunks += 1; } }
+                for (int p = 0; p < NPOL; ++p)
+                    for (int q = 0; q < 4; ++q)
+                        if (pmax[p][q] > 0) { out->polslots[p] += 64.0 * pmax[p][q]; out->polflush[p] += 1; }
             }
             /* phase B lane slots */
             int ord[256];

@@ -16,8 +16,14 @@ FIELDS = ("cand_all", "pass_all", "cand_walk", "pass_walk", "candA", "passA", "s
           "groups", "itersA", "max_group_pairs", "entriesA")
 
 
+NPOL = 12
+POLK = (8, 8, 10, 10, 12, 12, 16, 16, 24, 32, 10, 12)
+POLF = (4, 8, 4, 8, 4, 8, 4, 8, 8, 8, 1000, 1000)
+
+
 class SplitOut(ctypes.Structure):
-    _fields_ = [(k, ctypes.c_double) for k in FIELDS]
+    _fields_ = [("polslots", ctypes.c_double * NPOL), ("polflush", ctypes.c_double * NPOL), ("quad_iters", ctypes.c_double),
+                ("quad_chunks", ctypes.c_double)] + [(k, ctypes.c_double) for k in FIELDS]
 
 
 def main():
@@ -39,12 +45,16 @@ def main():
     for G in (64, 128, 256, 512, 1024):
         for kU in (1, 4):
             acc = dict.fromkeys(FIELDS, 0.0)
+            pol = [0.0] * NPOL; polf = [0.0] * NPOL; qi = qc = 0.0
             for o, rx, ry in views:
                 r = SplitOut()
                 cx, cy = np.ascontiguousarray(o["xy"][:, 0]), np.ascontiguousarray(o["xy"][:, 1])
                 opa = np.ascontiguousarray(o["normal_opacity"][:, 3])
                 lib.split_sim(H, W, W // 16, H // 16, P(o["ranges"]), P(o["point_list"]), P(cx), P(cy), P(rx), P(ry), P(o["trans"]), P(opa),
                               P(o["n_walked"]), G, kU, ctypes.byref(r))
+                for i in range(NPOL):
+                    pol[i] += r.polslots[i]; polf[i] += r.polflush[i]
+                qi += r.quad_iters; qc += r.quad_chunks
                 for k in FIELDS:
                     acc[k] = max(acc[k], getattr(r, k)) if k == "max_group_pairs" else acc[k] + getattr(r, k)
             m = lambda k: acc[k] * sc / 1e6  # noqa: E731
@@ -52,6 +62,10 @@ def main():
                   f"A: cand {m('candA'):6.2f}M pass {m('passA'):6.2f}M iters {m('itersA') * 1e3:7.1f}K (util {acc['candA'] / 64 / acc['itersA']:.3f}) groups {m('groups') * 1e3:6.1f}K "
                   f"entries {m('entriesA'):5.2f}M maxpairs {acc['max_group_pairs']:.0f} | B slots/64: quad {m('slotsB_quad') / 64 * 1e3:7.1f}K sorted/group {m('slotsB_sorted') / 64 * 1e3:7.1f}K "
                   f"sorted/tile {m('slotsB_sorted_tile') / 64 * 1e3:7.1f}K  (ideal {m('pass_walk') / 64 * 1e3:7.1f}K)")
+            if G == 64 and kU == 1:
+                print(f"   per-quadrant streams: A iterations {qi * sc / 1e3:.1f}K over {qc * sc / 1e3:.1f}K (chunk, quadrant) visits")
+                for i in range(NPOL):
+                    print(f"   flush policy K {POLK[i]:3d} forced every {POLF[i]:4d} chunks: B slots/64 {pol[i] * sc / 64e3:7.1f}K  flushes {polf[i] * sc / 1e3:7.1f}K")
 
 
 if __name__ == "__main__":
