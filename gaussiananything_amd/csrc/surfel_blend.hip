@@ -458,6 +458,7 @@ struct BlendArgs {
     uint32_t epoch;
     int flags;
     float *__restrict__ seg_T;   // GaSurfelForwardArgs.seg_T (the STORE instantiation only)
+    int64_t *__restrict__ prof;  // (GA_SPLIT_PROFILE builds) one row of section cycles per wave
 };
 
 // A segment's quadrant has published what it has to: count it; the last one of the tile's segments to arrive adds the partial
@@ -606,6 +607,436 @@ __device__ __forceinline__ void blend_item(Ring &ring, const BlendArgs &k, const
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// SPLIT WALK (round 4) of an unsegmented list: evaluate with lanes = PAIRS, composite with lanes = pixels.
+//
+// The fused walk above spends 78 VALU instructions per entry slot with 44 % of the lane slots doing work (round 3 counters): a
+// lane = pixel waits for the longest survivor list of its wave, and evaluates (25 instructions, two transcendentals) inside that
+// lock step.  Here a wavefront still owns one 8x8 quadrant -- so everything below is private to the wave, no barrier and no
+// cross-wave protocol beyond the record ring -- but it walks the list in two interleaved phases:
+//   A  lanes = (entry, pixel of the entry's cull box inside my quadrant).  Per 64-entry chunk the wave forms the boxes' areas
+//      (lanes = entries), their prefix sums and a compact table of the entries that touch the quadrant, then runs over the pairs
+//      64 at a time at ~90 % lane use: find my entry (run-start bits + v_mbcnt), my pixel (one multiply-shift division), fetch the
+//      record (broadcast LDS reads: ~5 distinct entries per instruction), evaluate alpha and depth.  Pairs that pass are appended
+//      to their PIXEL's list in LDS, in list order: pairs are enumerated entry-major, so inside one instruction the lower lane is the
+//      earlier entry -- a lane's rank among the passing pairs of its pixel in this instruction is the number of lower lanes in a
+//      64-bit mask the lanes OR their own bit into (DS operations of one wave execute in order: OR, read back, count with v_mbcnt),
+//      its position is the pixel's tail + rank.  Lists are rank-major (row r = the r-th pending item of every pixel), kRows deep.
+//   B  lanes = pixels: composite rows 0 .. (longest pending list) -- the only sequential part, 28 instructions per item and no
+//      filter-failed slots -- whenever a pixel's list is full, before the ring of the records' colour / normal quads wraps, and at
+//      the end.  tools/split_sim.py prices both phases on the bench scene's real lists.
+// The record ring is split: q0..q3 (what A reads) in kSA chunk slots, q4 / q5 (what B gathers by slot) in kSB.
+#ifndef GA_BLEND_SPLIT
+#define GA_BLEND_SPLIT 1
+#endif
+#ifndef GA_SPLIT_A
+#define GA_SPLIT_A 3
+#endif
+#ifndef GA_SPLIT_B
+#define GA_SPLIT_B 7
+#endif
+#ifndef GA_SPLIT_ROWS
+#define GA_SPLIT_ROWS 8
+#endif
+#ifndef GA_SPLIT_AU
+#define GA_SPLIT_AU 1       // pair instructions per trip of phase A
+#endif
+#ifndef GA_SPLIT_BU
+#define GA_SPLIT_BU 2       // rows per trip of phase B
+#endif
+#ifndef GA_SPLIT_RANK_ATOMIC
+#define GA_SPLIT_RANK_ATOMIC 1   // 1: a pixel's list position from ONE returning LDS atomic (lane order, tools/lds_atomic_order.hip); 0: mask + v_mbcnt
+#endif
+#ifndef GA_SPLIT_THRESH
+#define GA_SPLIT_THRESH 32       // composite opportunistically while at least this many pixels of the quadrant have a pending item
+#endif
+constexpr int kSA = GA_SPLIT_A, kSB = GA_SPLIT_B, kRows = GA_SPLIT_ROWS, kAU = GA_SPLIT_AU, kBU = GA_SPLIT_BU;
+
+struct WaveLists {                     // private to one wavefront (its quadrant)
+    float alpha[kRows][64];            // pending items: item number t of pixel p sits in row t % kRows ([row][pixel])
+    float depth[kRows][64];
+#if !GA_SPLIT_RANK_ATOMIC
+    unsigned long long mask[64];       // per pixel: lanes of the current instruction holding a passing pair of it (zero between)
+#endif
+    unsigned long long centry[64];     // compact table of the chunk's entries that touch the quadrant
+    uint32_t tail[64];                 // per pixel: items appended so far
+    uint32_t head[64];                 // per pixel: items composited so far (the pixel's lane keeps the live value in a register)
+    uint32_t bits[128];                // bit p: pair slot p of the chunk is the first pair of its entry
+    unsigned short slot[kRows][64];    // composite-ring slot of the item's entry
+};
+static_assert((kRows & (kRows - 1)) == 0, "rows are addressed modulo kRows");
+
+struct __attribute__((aligned(16))) Ring2 {
+    float4 pa[4][kSA * 64];            // q0 .. q3 (tile-relative, see stage_chunk2)
+    float4 pb4[kSB * 64];              // q4: normal, red
+    f2 pb5[kSB * 64];                  // q5: green, blue
+    WaveLists wl[4];
+    uint32_t stamp[kSA];               // k + 1 once chunk k is staged
+    uint32_t doneA[4];                 // chunks wave q has finished evaluating (kGone: it needs nothing any more)
+    uint32_t doneB[4];                 // oldest chunk wave q still holds uncomposited items of
+};
+#ifndef GA_SPLIT_WGS_PER_CU
+#define GA_SPLIT_WGS_PER_CU 3
+#endif
+// (measured: three workgroups of 53 808 bytes do NOT fit a CU -- the launch then runs two per CU -- three of 52 272 do)
+static_assert(GA_SPLIT_WGS_PER_CU != 3 || sizeof(Ring2) <= 52272, "three workgroups per CU");
+static_assert(GA_SPLIT_WGS_PER_CU * (sizeof(Ring2) + 64) <= 160 * 1024, "workgroups per CU");
+
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t x)   // (lanes without a source read 0)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWS, 0xf, true);
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
+{
+    x += dpp_u32<0x111>(x); x += dpp_u32<0x112>(x); x += dpp_u32<0x114>(x); x += dpp_u32<0x118>(x);   // row_shr 1, 2, 4, 8
+    x += dpp_u32<0x142, 0xa>(x);   // row_bcast:15 into rows 1, 3
+    x += dpp_u32<0x143, 0xc>(x);   // row_bcast:31 into rows 2, 3
+    return x;
+}
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m)   // set bits of m in lanes below mine
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// records of chunk k into their ring slots (rebased to the tile origin as in stage_chunk; no masks: the boxes are formed by the
+// consumers).  An entry beyond the list's end gets the "never" box.
+__device__ __forceinline__ void stage_chunk2(Ring2 &ring, int lane, uint32_t k, const ChunkRegs &g, bool valid, float tx0, float ty0)
+{
+    const float ex0 = g.g2.x - tx0, ey0 = g.g2.y - ty0;
+    const float ux = tx0 - rintf(g.g2.x), uy = ty0 - rintf(g.g2.y);
+    const int ja = (int)(k % kSA) * 64 + lane, jb = (int)(k % kSB) * 64 + lane;
+    ring.pa[0][ja] = g.g0;
+    ring.pa[1][ja] = make_float4(fmaf(uy, g.g0.z, fmaf(ux, g.g0.x, g.g1.x)), fmaf(uy, g.g0.w, fmaf(ux, g.g0.y, g.g1.y)), g.g1.z, g.g1.w);
+    ring.pa[2][ja] = make_float4(ex0, ey0, fmaf(uy, g.g1.w, fmaf(ux, g.g1.z, g.g2.z)), g.g2.w);
+    ring.pa[3][ja] = make_float4(g.g3.x, g.g3.y, g.g3.z, valid ? g.g3.w : __uint_as_float(0xBC00BC00u));   // (fp16 -1, -1)
+    ring.pb4[jb] = g.g4;
+    ring.pb5[jb] = g.g5;
+    GA_LDS_ORDER();
+    if (lane == 0) lds_store(&ring.stamp[k % kSA], k + 1);
+    GA_LDS_ORDER();
+}
+
+// Staging duties as above (chunk k by wave k % 4), against the two rings: chunk k takes the evaluation slot of chunk k - kSA and the
+// composite slot of chunk k - kSB, so every wave must have evaluated the former and composited every item of the latter.
+__device__ __forceinline__ void duty_prologue2(Ring2 &ring, Duty &d, int lane, int quad, uint32_t nch)
+{
+    const uint32_t k0 = (uint32_t)quad;
+    d.next = k0;
+    if (k0 >= nch) { d.next = nch; return; }
+    if (k0 < (uint32_t)kSA) {
+        const uint32_t ida = d.point_list[duty_entry(d, k0, lane)];
+        d.next = k0 + 4;
+        if (d.next < nch) d.id1 = d.point_list[duty_entry(d, d.next, lane)];
+        const ChunkRegs ga = load_chunk(d.rec4, ida);
+        if (d.next < nch) d.id2 = d.point_list[duty_entry(d, d.next + 4 < nch ? d.next + 4 : d.next, lane)];
+        stage_chunk2(ring, lane, k0, ga, d.sbeg + k0 * 64 + lane < d.send, d.tx0, d.ty0);
+    } else {
+        d.id1 = d.point_list[duty_entry(d, d.next, lane)];
+        d.id2 = d.point_list[duty_entry(d, d.next + 4 < nch ? d.next + 4 : d.next, lane)];
+    }
+    if (d.next < nch) d.g = load_chunk(d.rec4, d.id1);
+}
+
+__device__ __forceinline__ bool duty_stage2(Ring2 &ring, Duty &d, int lane, uint32_t nch)
+{
+    const uint32_t k = d.next;
+    for (;;) {
+        const uint32_t a0 = lds_load(&ring.doneA[0]), a1 = lds_load(&ring.doneA[1]), a2 = lds_load(&ring.doneA[2]), a3 = lds_load(&ring.doneA[3]);
+        const uint32_t b0 = lds_load(&ring.doneB[0]), b1 = lds_load(&ring.doneB[1]), b2 = lds_load(&ring.doneB[2]), b3 = lds_load(&ring.doneB[3]);
+        const uint32_t amin = min(min(a0, a1), min(a2, a3)), bmin = min(min(b0, b1), min(b2, b3));
+        if (amin == kGone) return false;
+        if (amin + kSA > k && bmin + kSB > k) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    GA_LDS_ORDER();
+    stage_chunk2(ring, lane, k, d.g, d.sbeg + k * 64 + lane < d.send, d.tx0, d.ty0);
+    d.next = k + 4;
+    if (d.next < nch) {
+        d.id1 = d.id2;
+        d.g = load_chunk(d.rec4, d.id1);
+        d.id2 = d.point_list[duty_entry(d, d.next + 4 < nch ? d.next + 4 : d.next, lane)];
+    }
+    return true;
+}
+
+// one pending item of my pixel (B).  `go`: the item exists and my pixel's walk has not ended.
+__device__ __forceinline__ void composite_item(float alpha, float depth_raw, const float4 &q4, const f2 &q5, PixelAcc &a, bool &done, bool go)
+{
+    const float kM = kFar / (kFar - kNear);
+    const float test_T = a.T * (1.0f - alpha);
+    const bool stop = go && test_T < 0.0001f;               // upstream: done = true
+    const bool use = go && !stop;
+    done = done || stop;
+    const float depth = use ? depth_raw : 1.0f;
+    const float w = use ? alpha * a.T : 0.0f;
+    const float A = 1.0f - a.T;
+    const float m = kM * (1.0f - kNear * __builtin_amdgcn_rcpf(depth));
+    const f2 mm = f2{m, m * m};
+    a.dist += (mm.y * A + a.M.y - 2.0f * m * a.M.x) * w;
+    a.Dp += depth * w;
+    a.M += mm * w;
+    a.median = (use && a.T > 0.5f) ? depth : a.median;
+    a.N01 += lo2(q4) * w;
+    a.N2C0 += hi2(q4) * w;
+    a.C12 += q5 * w;
+    a.T = use ? test_T : a.T;
+}
+
+struct SplitStats {
+    unsigned a_iters, a_pairs, b_rows, b_items;
+};
+// GA_SPLIT_PROFILE (measurement builds): cycles a wave spends per section, one row per wave in the binning's depth array (tools/split_profile.py)
+#ifdef GA_SPLIT_PROFILE
+#define GA_PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define GA_PROF(sec) do { const unsigned long long prof_n = __builtin_readcyclecounter(); prof_acc[sec] += prof_n - prof_t; prof_t = prof_n; } while (0)
+#else
+#define GA_PROF_DECL
+#define GA_PROF(sec)
+#endif
+
+__device__ __forceinline__ void blend_tile_split(Ring2 &ring, const BlendArgs &k, const Dims &dm, int lane, int wave, const uint4 sched,
+                                                 SplitStats &st)
+{
+    const uint32_t vt = sched.x;
+    const int v = (int)(vt / (uint32_t)dm.tiles), tile = (int)(vt - (uint32_t)v * dm.tiles);
+    const int tx = tile % dm.gx, ty = tile / dm.gx;
+    const uint32_t beg = sched.y, n = sched.z, nch = (n + 63) / 64;
+    const float4 *rec4 = reinterpret_cast<const float4 *>(k.record) + (size_t)v * dm.N * (kRec / 4);
+    WaveLists &wl = ring.wl[wave];
+    GA_PROF_DECL;
+#if !GA_SPLIT_RANK_ATOMIC
+    wl.mask[lane] = 0ull;
+#endif
+    wl.tail[lane] = 0u; wl.head[lane] = 0u; wl.bits[lane] = 0u; wl.bits[64 + lane] = 0u;
+
+    Duty duty;
+    duty.sbeg = beg; duty.send = beg + n; duty.point_list = k.point_list; duty.rec4 = rec4;
+    duty.tx0 = (float)(tx * kTile); duty.ty0 = (float)(ty * kTile);
+    duty_prologue2(ring, duty, lane, wave, nch);
+    GA_PROF(0);
+
+    const int qx = (wave & 1) * 8, qy = (wave >> 1) * 8;          // my quadrant inside the tile
+    const int pxi = tx * kTile + qx + (lane & 7), pyi = ty * kTile + qy + (lane >> 3);
+    const bool inside = pxi < dm.W && pyi < dm.H;
+    PixelAcc a = fresh_pixel(1.0f);
+    bool done = !inside;
+    unsigned long long done_mask = __builtin_amdgcn_ballot_w64(done);
+#if !GA_SPLIT_RANK_ATOMIC
+    const unsigned long long lanebit = 1ull << lane;
+#endif
+    const float qxf = (float)qx, qyf = (float)qy;
+    bool pending = false;        // (wave-uniform) items appended since the last composite pass
+    uint32_t oldest = 0;         // ... the chunk of the first of them
+
+    // B: composite pending items, one per pixel and step, kBU steps per trip.  all: until nothing is pending; otherwise at least one
+    // trip and on while at least kThresh pixels have something (a step costs the same however many lanes have work).  Returns whether
+    // every list is empty afterwards.
+    uint32_t hd = 0;             // items of my pixel composited so far
+    auto drain = [&](bool all) -> bool {
+#ifdef GA_SPLIT_PROFILE
+        const unsigned long long fl_t0 = __builtin_readcyclecounter();
+#endif
+        // (a tail may run ahead of what is stored: the pairs of the current instruction that found their list full are written
+        // after this pass -- only the kRows items from my head on are there)
+        uint32_t cnt = min(wl.tail[lane] - hd, (uint32_t)kRows);
+        bool first = true;
+        unsigned long long act;
+        for (;;) {
+            act = __builtin_amdgcn_ballot_w64(cnt != 0u);
+            if (act == 0ull) break;
+            if (!all && !first && __builtin_popcountll(act) < GA_SPLIT_THRESH) break;
+            first = false;
+            float al[kBU], dp[kBU];
+            uint32_t sl[kBU];
+            bool g[kBU];
+#pragma unroll
+            for (int u = 0; u < kBU; ++u) {
+                const uint32_t row = (hd + (uint32_t)u) & (uint32_t)(kRows - 1);
+                al[u] = wl.alpha[row][lane]; dp[u] = wl.depth[row][lane];
+                g[u] = (uint32_t)u < cnt;
+                sl[u] = g[u] ? (uint32_t)wl.slot[row][lane] : 0u;   // (rows beyond my list hold stale slots: stay inside the ring)
+            }
+            float4 q4[kBU];
+            f2 q5[kBU];
+#pragma unroll
+            for (int u = 0; u < kBU; ++u) { q4[u] = ring.pb4[sl[u]]; q5[u] = ring.pb5[sl[u]]; }
+#pragma unroll
+            for (int u = 0; u < kBU; ++u) composite_item(al[u], dp[u], q4[u], q5[u], a, done, g[u] && !done);
+            const uint32_t adv = min(cnt, (uint32_t)kBU);
+            hd += adv; cnt -= adv;
+            if (k.flags & GA_SURFEL_FLAG_STATS) {
+                st.b_rows += kBU;
+                uint32_t c = adv;
+                for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+                st.b_items += c;
+            }
+        }
+        wl.head[lane] = hd;
+        GA_LDS_ORDER();
+        done_mask = __builtin_amdgcn_ballot_w64(done);
+#ifdef GA_SPLIT_PROFILE
+        { const unsigned long long fl_n = __builtin_readcyclecounter(); prof_acc[5] += fl_n - fl_t0; prof_t += fl_n - fl_t0; }
+#endif
+        return act == 0ull;
+    };
+
+    uint32_t i = 0;
+    for (; i < nch; ++i) {
+        if (done_mask == ~0ull) break;
+        // the composite ring is about to wrap onto entries my pending items point at
+        if (pending && oldest + (uint32_t)(kSB - kSA) <= i) { drain(true); pending = false; }
+        GA_LDS_ORDER();
+        if (lane == 0) { lds_store(&ring.doneA[wave], i); lds_store(&ring.doneB[wave], pending ? oldest : i); }
+        GA_LDS_ORDER();
+        GA_PROF(4);
+        while (duty.next < nch && duty.next <= i + (uint32_t)kSA - 1u && duty_stage2(ring, duty, lane, nch)) {}
+        GA_PROF(1);
+        const int sa = (int)(i % kSA) * 64;
+        while (lds_load(&ring.stamp[i % kSA]) != i + 1) __builtin_amdgcn_s_sleep(1);
+        GA_LDS_ORDER();
+        GA_PROF(2);
+        // ---- lanes = entries: cull box inside my quadrant, pair prefix, compact table
+        uint32_t total;
+        {
+            const float4 c2 = ring.pa[2][sa + lane];
+            const uint32_t cull = __float_as_uint(ring.pa[3][sa + lane].w);
+            const float rx = __half2float(__ushort_as_half((unsigned short)(cull & 0xffffu)));
+            const float ry = __half2float(__ushort_as_half((unsigned short)(cull >> 16)));
+            // pixel columns c with |c - ex0| <= rx are ceil(ex0 - rx) .. floor(ex0 + rx)  (+inf: all; negative: none)
+            const float xlo = fmaxf(ceilf(c2.x - rx), qxf), xhi = fminf(floorf(c2.x + rx), qxf + 7.0f);
+            const float ylo = fmaxf(ceilf(c2.y - ry), qyf), yhi = fminf(floorf(c2.y + ry), qyf + 7.0f);
+            const int w = (int)(xhi - xlo) + 1, h = (int)(yhi - ylo) + 1;
+            const bool nz = xhi >= xlo && yhi >= ylo;
+            const uint32_t area = nz ? (uint32_t)(w * h) : 0u;
+            const uint32_t incl = wave_inclusive_scan(area);
+            total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (total != 0) {
+                const unsigned long long nzm = __builtin_amdgcn_ballot_w64(nz);
+                if (nz) {
+                    const uint32_t base = incl - area;
+                    const uint32_t magic = (uint32_t)ceilf(65536.0f * __builtin_amdgcn_rcpf((float)w));   // (k * magic) >> 16 == k / w for k < 64
+                    const uint32_t lo = (uint32_t)lane | ((uint32_t)((int)xlo - qx) << 6) | ((uint32_t)((int)ylo - qy) << 9) | ((uint32_t)w << 12) | (base << 16);
+                    wl.centry[lanes_below(nzm)] = ((unsigned long long)magic << 32) | lo;
+                    __hip_atomic_fetch_or(&wl.bits[base >> 5], 1u << (base & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        GA_LDS_ORDER();
+        GA_PROF(3);
+        // ---- lanes = pairs, kAU instructions' worth per trip: their table look-ups, record fetches and evaluations are independent of
+        // each other (the LDS round trips overlap), the appends follow in order
+        uint32_t cbase = 0;
+        const uint32_t bslot0 = (i % (uint32_t)kSB) * 64u;
+        for (uint32_t p0 = 0; p0 < total; p0 += 64u * kAU) {
+            bool valid[kAU];
+            uint32_t lo[kAU], pq[kAU];
+            Rec r[kAU];
+            f2 dxy[kAU];
+#pragma unroll
+            for (int u = 0; u < kAU; ++u) {
+                const uint32_t p = p0 + 64u * u + (uint32_t)lane;
+                valid[u] = p < total;
+                const uint32_t word = wl.bits[(p >> 5) & 127u];
+                const bool start = valid[u] && ((word >> (p & 31u)) & 1u) != 0u;
+                const unsigned long long S = __builtin_amdgcn_ballot_w64(start);
+                const uint32_t c = valid[u] ? cbase + lanes_below(S) + (start ? 1u : 0u) - 1u : 0u;
+                cbase += (uint32_t)__builtin_popcountll(S);
+                const unsigned long long ce = wl.centry[c];
+                lo[u] = (uint32_t)ce;
+                const uint32_t magic = (uint32_t)(ce >> 32);
+                const uint32_t kk = valid[u] ? p - (lo[u] >> 16) : 0u, w = (lo[u] >> 12) & 15u;
+                const uint32_t dy = __umul24(kk, magic) >> 16, dx = kk - __umul24(dy, w);
+                const uint32_t px = ((lo[u] >> 6) & 7u) + dx, py = ((lo[u] >> 9) & 7u) + dy;
+                pq[u] = (py * 8u + px) & 63u;
+                dxy[u] = f2{(float)(qx + (int)px), (float)(qy + (int)py)};
+                const int j = sa + (int)(lo[u] & 63u);
+                r[u].q0 = ring.pa[0][j]; r[u].q1 = ring.pa[1][j]; r[u].q2 = ring.pa[2][j]; r[u].q3 = ring.pa[3][j];
+            }
+            Alpha e[kAU];
+            float depth[kAU];
+            bool pass[kAU];
+#pragma unroll
+            for (int u = 0; u < kAU; ++u) {
+                e[u] = eval_alpha(r[u], dxy[u]);
+                depth[u] = pair_depth(r[u], e[u]);
+                pass[u] = valid[u] && e[u].pass && !(depth[u] < kNear);
+                if (done_mask != 0ull) pass[u] = pass[u] && ((done_mask >> pq[u]) & 1ull) == 0ull;   // (pixels whose walk has ended take nothing)
+                if (k.flags & GA_SURFEL_FLAG_STATS) {
+                    const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid[u]);
+                    st.a_iters += vm != 0ull; st.a_pairs += (unsigned)__builtin_popcountll(vm);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kAU; ++u) {
+                if (__builtin_amdgcn_ballot_w64(pass[u]) == 0ull) continue;
+                if (!pending) { pending = true; oldest = i; }
+                uint32_t hq = wl.head[pq[u]];
+#if GA_SPLIT_RANK_ATOMIC
+                // my place in my pixel's list from one returning atomic: the LDS serves the lanes of an instruction that hit the same
+                // address in lane order (tools/lds_atomic_order.hip: 5.1 M conflicting lanes, none out of order; tests/test_surfel_gpu.py
+                // runs it), and pairs are enumerated entry-major -- the lower lane is the earlier entry
+                uint32_t pos = 0;
+                if (pass[u]) pos = __hip_atomic_fetch_add(&wl.tail[pq[u]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+                // my place in my pixel's list: its tail + the passing pairs of the same pixel in lower lanes (= earlier entries)
+                if (pass[u]) __hip_atomic_fetch_or(&wl.mask[pq[u]], lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                GA_LDS_ORDER();
+                const unsigned long long m = wl.mask[pq[u]];
+                const uint32_t t = wl.tail[pq[u]];
+                GA_LDS_ORDER();
+                const uint32_t rank = lanes_below(m);
+                if (pass[u] && rank == 0u) { wl.tail[pq[u]] = t + (uint32_t)__builtin_popcountll(m); wl.mask[pq[u]] = 0ull; }
+                GA_LDS_ORDER();
+                uint32_t pos = t + rank;
+#endif
+                bool pend = pass[u];
+                for (;;) {
+                    const bool fit = pend && pos - hq < (uint32_t)kRows;
+                    if (fit) {
+                        const uint32_t row = pos & (uint32_t)(kRows - 1);
+                        wl.alpha[row][pq[u]] = e[u].alpha; wl.depth[row][pq[u]] = depth[u];
+                        wl.slot[row][pq[u]] = (unsigned short)(bslot0 + (lo[u] & 63u));
+                    }
+                    pend = pend && !fit;
+                    GA_LDS_ORDER();
+                    if (__builtin_amdgcn_ballot_w64(pend) == 0ull) break;
+                    drain(false);          // a list is full: composite (at least one trip), the rest of this instruction's pairs follow
+                    hq = wl.head[pq[u]];
+                }
+            }
+        }
+        // composite now if most of the quadrant has something pending (full lanes for the sequential part)
+        if (pending) {
+            const unsigned long long has = __builtin_amdgcn_ballot_w64(wl.tail[lane] != hd);
+            if (__builtin_popcountll(has) >= GA_SPLIT_THRESH && drain(false)) pending = false;
+        }
+        // the run-start bits of this chunk
+        for (uint32_t wd = (uint32_t)lane; wd * 32u < total; wd += 64u) wl.bits[wd] = 0u;
+        GA_LDS_ORDER();
+    }
+    GA_PROF(4);
+    if (pending) drain(true);
+    GA_LDS_ORDER();
+    if (lane == 0) { lds_store(&ring.doneA[wave], kGone); lds_store(&ring.doneB[wave], kGone); }
+    GA_LDS_ORDER();
+    if (inside) write_pixel(a, k.bg, dm, v, pxi, pyi, k.out_color, k.out_others);
+    GA_PROF(4);
+    while (duty.next < nch && duty_stage2(ring, duty, lane, nch)) {}   // the others may still need my chunks
+    GA_PROF(6);
+#ifdef GA_SPLIT_PROFILE
+    // sections: 0 prologue, 1 staging duty (with its waits), 2 stamp wait, 3 chunk table, 4 pair instructions (+ bookkeeping),
+    // 5 composite passes, 6 trailing duties; word 11: waves
+    if (lane == 0) {   // one row of 8 words per wave in the (dead by now) depth array of the binning: plain stores, summed by tools/split_profile.py
+        int64_t *row = k.prof + ((size_t)blockIdx.x * 4 + wave) * 8;
+        unsigned long long tot = 0;
+        for (int q = 0; q < 7; ++q) { row[q] = (int64_t)prof_acc[q]; tot += prof_acc[q]; }
+        row[7] = (int64_t)(tot | (0x5A5Aull << 48));   // (tag: the array also holds what the binning left there)
+    }
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Grid: [ segment region | one workgroup per (view, tile) ].  The kSegWGs workgroups of the segment region take tickets
 // (status[GA_STATUS_SEG_TICKET]) until the status[GA_STATUS_SEG_WORK] segment work items are handed out (the host does not
@@ -624,7 +1055,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
                                                            const uint32_t *__restrict__ seg_table,
                                                            int64_t *__restrict__ status)
 {
-    __shared__ Ring ring;
+    // one LDS allocation, two images: the fused walk's ring (segments, the differentiable forward) / the split walk's
+    __shared__ __attribute__((aligned(16))) unsigned char lds_image[sizeof(Ring) > sizeof(Ring2) ? sizeof(Ring) : sizeof(Ring2)];
+    Ring &ring = *reinterpret_cast<Ring *>(lds_image);
     // (requested before the status words are looked at: on overflow the entry is stale but the slot exists)
     // schedule slot of a tile workgroup: runs of 2^GA_BLEND_XCD_RUNS consecutive slots -- tiles of one view and one pair of tile rows that
     // fall into the same length class (the order the tile scan leaves inside a class) -- go to workgroups eight apart, i.e.
@@ -697,10 +1130,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
             if (pxi < dm.W && pyi < dm.H) write_pixel(fresh_pixel(1.0f), k.bg, dm, v, pxi, pyi, k.out_color, k.out_others);
             return;
         }
-        if (threadIdx.x < kItemChunks) ring.stamp[threadIdx.x] = 0;
-        if (threadIdx.x < 4) ring.done[threadIdx.x] = 0;
-        __syncthreads();
-        blend_item<STORE>(ring, k, dm, lane, wave, pos, my_sched, 0u, 1u, 0u, 0u, st);
+#if GA_BLEND_SPLIT
+        if (!STORE && (k.flags & GA_SURFEL_FLAG_SPLIT_WALK)) {
+            Ring2 &ring2 = *reinterpret_cast<Ring2 *>(lds_image);
+            if (threadIdx.x < kSA) ring2.stamp[threadIdx.x] = 0;
+            if (threadIdx.x < 4) { ring2.doneA[threadIdx.x] = 0; ring2.doneB[threadIdx.x] = 0; }
+            __syncthreads();
+            SplitStats ss{};
+            blend_tile_split(ring2, k, dm, lane, wave, my_sched, ss);
+            if (k.flags & GA_SURFEL_FLAG_STATS) {
+                // the counters of the fused walk, in the split walk's terms: wave-level slots = A instructions + B rows; lanes with
+                // work = pairs evaluated + items composited
+                st.iters = ss.a_iters + ss.b_rows; st.useful = ss.a_pairs + ss.b_items; st.chunks = 0; st.lanemax = ss.b_rows;
+                if (lane == 0) {
+                    atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_SPLIT_A_ITERS), (unsigned long long)ss.a_iters);
+                    atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_SPLIT_A_PAIRS), (unsigned long long)ss.a_pairs);
+                    atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_SPLIT_B_ROWS), (unsigned long long)ss.b_rows);
+                    atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_SPLIT_B_ITEMS), (unsigned long long)ss.b_items);
+                }
+            }
+        } else
+#endif
+        {
+            if (threadIdx.x < kItemChunks) ring.stamp[threadIdx.x] = 0;
+            if (threadIdx.x < 4) ring.done[threadIdx.x] = 0;
+            __syncthreads();
+            blend_item<STORE>(ring, k, dm, lane, wave, pos, my_sched, 0u, 1u, 0u, 0u, st);
+        }
     }
     if ((k.flags & GA_SURFEL_FLAG_STATS) && lane == 0) {
         atomicAdd(reinterpret_cast<unsigned long long *>(status + GA_STATUS_BLEND_ITERS), (unsigned long long)st.iters);
@@ -718,7 +1174,7 @@ void launch_blend(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &
     constexpr uint32_t kSegWGs = 512;   // two of the three workgroup slots of a CU; beyond that they loop
     const uint32_t seg_region = (uint32_t)std::min<int64_t>(a.capacity / 256, kSegWGs);
     const BlendArgs k{ws.tile_order, ws.point_list, ws.record, a.bg, ws.seg_sync, ws.seg_scratch, a.out_color, a.out_others,
-                      0u /* the segment workgroups read the launch epoch from the workspace */, a.flags, a.seg_T};
+                      0u /* the segment workgroups read the launch epoch from the workspace */, a.flags, a.seg_T, reinterpret_cast<int64_t *>(ws.depth)};
     if (a.seg_T)
         hipLaunchKernelGGL(surfel_blend_kernel<true>, dim3(seg_region + (unsigned)nt), dim3(256), 0, s, k, d, nt, seg_region,
                            ws.seg_table, ws.status);

@@ -110,6 +110,7 @@ def default_capacity(n, v):
     return max(2 * n * v, 1 << 16)
 
 
+EXTRA_FLAGS = int(os.environ.get("GA_SURFEL_FLAGS", "0"))   # GA_SURFEL_FLAG_* ORed into every forward (4: the split walk of the blend; A/B aid)
 _WS_CACHE_SLOTS = 8          # most recently used (device, N, V, H, W) workspaces kept alive; older ones are released
 _ws_cache = OrderedDict()
 _AUTOGRAD_POOL_KEYS = 4       # shapes whose idle workspaces are kept (least recently used shape dropped first), two per shape
@@ -319,7 +320,7 @@ def _rasterize_views_nograd(means3D, opacities, colors_precomp, scales, rotation
         while True:
             seg_T = _seg_T(ws) if for_backward else None     # (the forward of a differentiable call leaves it for the backward)
             args = _lib.GaSurfelForwardArgs(
-                n, v, h, w, float(scale_modifier), ws.clean_flag(), means3D.data_ptr(), opacities.data_ptr(), colors.data_ptr(),
+                n, v, h, w, float(scale_modifier), ws.clean_flag() | EXTRA_FLAGS, means3D.data_ptr(), opacities.data_ptr(), colors.data_ptr(),
                 scales.data_ptr(), rotations.data_ptr(), vm.data_ptr(), pm.data_ptr(), bg.data_ptr(),
                 color.data_ptr(), allmap.data_ptr(), radii.data_ptr(), ws.ptr, ws.layout.total_bytes, ws.capacity,
                 stage_events, ws.seg_capacity, seg_T.data_ptr() if seg_T is not None else None,
@@ -392,7 +393,7 @@ class SurfelForwardPlan:
         self.bg = _f32c(bg, "bg", device).reshape(3)
         self.h, self.w = int(image_height), int(image_width)
         self.scale_modifier = float(scale_modifier)
-        self.flags = int(flags)
+        self.flags = int(flags) | EXTRA_FLAGS
         self.color = torch.empty((v, 3, self.h, self.w), dtype=torch.float32, device=device)
         self.allmap = torch.empty((v, 7, self.h, self.w), dtype=torch.float32, device=device)
         self.radii = torch.empty((v, n), dtype=torch.int32, device=device)

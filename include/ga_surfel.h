@@ -48,6 +48,10 @@ extern "C" {
 #define GA_STATUS_SEG_TICKET 10   /* next segment work item to hand out (internal)                                     */
 #define GA_STATUS_BLEND_LANE_MAX 11 /* with GA_SURFEL_FLAG_STATS: sum over (wave, work item, pass) of the LONGEST per-pixel survivor
                                      list of the wave: what BLEND_ITERS would be if the 64 pixels did not wait for each other */
+#define GA_STATUS_SPLIT_A_ITERS 12 /* with GA_SURFEL_FLAG_STATS, split walk: wave-level pair-evaluation instructions (64 pair slots each) */
+#define GA_STATUS_SPLIT_A_PAIRS 13 /* ... (entry, pixel) pairs evaluated                                                             */
+#define GA_STATUS_SPLIT_B_ROWS 14  /* ... wave-level composite rows (64 pixel slots each)                                            */
+#define GA_STATUS_SPLIT_B_ITEMS 15 /* ... items composited                                                                           */
 #define GA_STATUS_WORDS 16
 
 typedef struct GaSurfelForwardArgs {
@@ -97,6 +101,10 @@ typedef struct GaSurfelForwardArgs {
                                        enqueued completely (it returned GA_OK): its tile scan left the accumulating words of the
                                        workspace head zeroed, so the clearing memset in front of this forward is skipped.  Never
                                        set it for the first forward on a workspace (or after writing to it) */
+
+#define GA_SURFEL_FLAG_SPLIT_WALK 4  /* blend unsegmented lists with the SPLIT walk (evaluate with lanes = (entry, pixel) pairs, composite
+                                       with lanes = pixels; surfel_blend.hip) instead of the fused lanes = pixels walk.  Built, parity
+                                       green and measured in round 4 -- 175 us against 140 us on BASELINE configs[1] -- hence opt-in */
 
 /* Byte offsets of the workspace sections (all 256-byte aligned).  Tests read the integer artefacts
  * (rect, tile ranges, sorted point list) straight out of the workspace through these offsets. */

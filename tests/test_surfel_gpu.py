@@ -57,6 +57,39 @@ def test_config1_1k_256(gpu_device):
     _run_case(g, cams, [0], 256, 256, gpu_device)
 
 
+@pytest.mark.parametrize("scene", ["surface", "stress", "small"])
+def test_split_walk_of_the_blend_matches_the_oracle(gpu_device, monkeypatch, scene):
+    """GA_SURFEL_FLAG_SPLIT_WALK (round 4; opt-in: measured slower than the fused walk): unsegmented lists evaluated with lanes =
+    (entry, pixel) pairs and composited with lanes = pixels from per-pixel LDS lists -- same pixels as the oracle (the lists' order is
+    the depth order), full lists (the small scene's big splats fill them: composite passes in the middle of a pair instruction),
+    ragged image, and the default walk's images to 1e-5."""
+    from gaussiananything_amd import _lib, diff_surfel_rasterization as dsr
+    cams = synthetic.eval_cameras(8)
+    if scene == "small":
+        g, views, H, W, sm = synthetic.random_surfels(3000, seed=5)[0], [0, 5], 200, 296, 3.0
+    else:
+        g = synthetic.surface_surfels(100_000, seed=1)[0] if scene == "surface" else synthetic.random_surfels(100_000, seed=0)[0]
+        views, H, W, sm = [0, 3], 512, 512, 1.0
+    ref = _util.hip_views(g, cams, views, H, W, gpu_device, scale_modifier=sm)
+    dsr.clear_workspaces()
+    monkeypatch.setattr(dsr, "EXTRA_FLAGS", _lib.GA_SURFEL_FLAG_SPLIT_WALK)
+    _run_case(g, cams, views, H, W, gpu_device, scale_modifier=sm)
+    got = _util.hip_views(g, cams, views, H, W, gpu_device, scale_modifier=sm)
+    assert float((got[0] - ref[0]).abs().max()) < 1e-5 and float((got[2] - ref[2]).abs().max()) < 1e-4
+    dsr.clear_workspaces()
+
+
+def test_lds_atomics_serve_the_lanes_of_an_instruction_in_lane_order(gpu_device):
+    """what the split walk's list append relies on (one returning ds_add per passing pair): tools/lds_atomic_order.hip"""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "_build", "lds_atomic_order")
+    if not os.path.exists(exe):
+        pytest.skip("tools/_build/lds_atomic_order not built (__graft_entry__.build() compiles it)")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+    assert "lane order held in every case" in out, out
+
+
 def test_config1_matches_frozen_golden(gpu_device):
     """HIP output against the committed fixture (tests/golden/surfel_cfg1_oracle.npz), without running the oracle."""
     z = np.load(synthetic.fixture_path("surfel_cfg1_oracle.npz"))

@@ -43,7 +43,7 @@ def main():
                 shutil.copy(os.path.join(ROOT, "tools", "_build", f"libga_{name}.so"), MAIN)
             else:
                 shutil.copy(backup, MAIN)
-            r = subprocess.run([sys.executable, "-c", (CODE % ROOT).replace("FLAGS", str(flags))], capture_output=True, text=True, timeout=300)
+            r = subprocess.run([sys.executable, "-c", (CODE % ROOT).replace("FLAGS", str(flags))], capture_output=True, text=True, timeout=60)
             print(name, "flags", flags, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ("FAILED " + r.stderr[-800:]), flush=True)
     finally:
         shutil.copy(backup, MAIN)
