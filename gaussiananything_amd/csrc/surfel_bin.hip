@@ -555,7 +555,7 @@ __device__ __forceinline__ void sort_group_low(double *s, int base, int p)
     for (int m = 0; m < E; ++m) *reinterpret_cast<double *>(sc + slot[m]) = v[m];
 }
 
-template <int E>
+template <int E, bool kWave = false>
 __device__ __forceinline__ void bitonic_sort_blocked(double *s, int np, int tid)
 {
     constexpr int e = E == 8 ? 3 : (E == 4 ? 2 : 1);
@@ -567,7 +567,7 @@ __device__ __forceinline__ void bitonic_sort_blocked(double *s, int np, int tid)
     // and in the previous one (mirroring stays inside it): no workgroup barrier between two such groups, LDS operations
     // of one wave execute in order.
     auto sync = [&](int p) {
-        if (p > 6 || prev_p > 6) __syncthreads();
+        if (!kWave && (p > 6 || prev_p > 6)) __syncthreads();
         else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
         prev_p = p;
     };
@@ -590,7 +590,8 @@ __device__ __forceinline__ void bitonic_sort_blocked(double *s, int np, int tid)
             if (act) sort_group_low<E>(s, ((tid >> pl) << (pl + e)) | (tid & ((1 << pl) - 1)), pl);
         }
     }
-    __syncthreads();
+    if (kWave) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
 }
 
 __device__ __forceinline__ void bitonic_sort_lds(double *s, int np, int tid)
@@ -601,18 +602,141 @@ __device__ __forceinline__ void bitonic_sort_lds(double *s, int np, int tid)
     else bitonic_sort_blocked<2>(s, np, tid);
 }
 
+
+constexpr int kWaveSort = 512;   // lists shorter than this are sorted by one wavefront with the keys in registers (64 lanes x <= 8 keys)
+
+// ---- wave sort: E keys per lane IN REGISTERS (key index i = lane * E + m), no LDS image at all.
+// The LDS network above costs ~12 VALU instructions per key and stage on short lists (slot arithmetic, 64-bit moves, a quarter of the
+// lanes active for 256 keys): the launch was issue-bound at 14 M wave instructions.  Here the same direction-free network runs on
+// registers: the stages whose partner differs in the low log2(E) index bits are v_min_f64 / v_max_f64 on two registers of the lane; a
+// stage whose partner sits in another lane fetches the partner's key with two cross-lane moves (DPP inside a quad, ds_swizzle inside
+// 32 lanes, ds_bpermute beyond -- no memory access), compares once (v_cmp_lt_u64) and keeps the smaller key in the lower lane.
+template <int MASK>
+__device__ __forceinline__ uint32_t xor_lane_u32(uint32_t x, int lane)
+{
+    if constexpr (MASK == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, true);        // quad_perm [1,0,3,2]
+    else if constexpr (MASK == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    else if constexpr (MASK == 3) return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x1B, 0xf, 0xf, true);   // quad_perm [3,2,1,0]
+    else if constexpr (MASK < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x001F | (MASK << 10));   // bit mode: and 0x1f, xor MASK
+    else return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ MASK) << 2, (int)x);
+}
+template <int MASK>
+__device__ __forceinline__ unsigned long long xor_lane_u64(unsigned long long x, int lane)
+{
+    return ((unsigned long long)xor_lane_u32<MASK>((uint32_t)(x >> 32), lane) << 32) | xor_lane_u32<MASK>((uint32_t)x, lane);
+}
+
+// one cross-lane stage: key[m] against the key[PM(m)] of lane ^ LMASK; the lane whose bit LBIT is clear keeps the smaller one
+template <int E, int LMASK, int LBIT, bool MIRROR>
+__device__ __forceinline__ void wave_stage_cross(unsigned long long (&key)[E], int lane)
+{
+    const bool lower = (lane & LBIT) == 0;
+    constexpr int B = E < 8 ? E : 8;    // keys in flight (registers); a mirrored stage pairs block b with block E/B - 1 - b
+    if constexpr (!MIRROR || E <= B) {
+#pragma unroll
+        for (int m0 = 0; m0 < E; m0 += B) {
+            unsigned long long theirs[B];
+#pragma unroll
+            for (int m = 0; m < B; ++m) theirs[m] = xor_lane_u64<LMASK>(key[MIRROR ? E - 1 - (m0 + m) : m0 + m], lane);
+#pragma unroll
+            for (int m = 0; m < B; ++m) {
+                const bool take = lower ? theirs[m] < key[m0 + m] : theirs[m] > key[m0 + m];
+                key[m0 + m] = take ? theirs[m] : key[m0 + m];
+            }
+        }
+    } else {
+        // register m reads the partner's register E-1-m: the block that is read must not have been overwritten yet, so a pair of
+        // mirrored blocks is fetched together
+#pragma unroll
+        for (int m0 = 0; m0 < E / 2; m0 += B) {
+            unsigned long long ta[B], tb[B];
+#pragma unroll
+            for (int m = 0; m < B; ++m) {
+                ta[m] = xor_lane_u64<LMASK>(key[E - 1 - (m0 + m)], lane);       // partners of registers m0 + m
+                tb[m] = xor_lane_u64<LMASK>(key[m0 + m], lane);               // partners of registers E - 1 - (m0 + m)
+            }
+#pragma unroll
+            for (int m = 0; m < B; ++m) {
+                const int x = m0 + m, y = E - 1 - (m0 + m);
+                const bool takex = lower ? ta[m] < key[x] : ta[m] > key[x];
+                const bool takey = lower ? tb[m] < key[y] : tb[m] > key[y];
+                key[x] = takex ? ta[m] : key[x];
+                key[y] = takey ? tb[m] : key[y];
+            }
+        }
+    }
+}
+
+// in-register compare-exchange: key[a] <= key[b] afterwards (keys are bit patterns of positive doubles, see key_min)
+template <int E>
+__device__ __forceinline__ void wave_ce(unsigned long long (&key)[E], int a, int b)
+{
+    const double x = __longlong_as_double((long long)key[a]), y = __longlong_as_double((long long)key[b]);
+    key[a] = (unsigned long long)__double_as_longlong(key_min(x, y));
+    key[b] = (unsigned long long)__double_as_longlong(key_max(x, y));
+}
+
+// ordinary stages j = J, J / 2, ..., 1 of a merge block (partner i ^ j, ascending), J a compile-time power of two
+template <int E, int J>
+__device__ __forceinline__ void wave_stages_down(unsigned long long (&key)[E], int lane)
+{
+    if constexpr (J >= 1) {
+        if constexpr (J >= E) wave_stage_cross<E, J / E, J / E, false>(key, lane);
+        else {
+#pragma unroll
+            for (int m = 0; m < E; ++m)
+                if ((m & J) == 0) wave_ce<E>(key, m, m | J);
+        }
+        wave_stages_down<E, J / 2>(key, lane);
+    }
+}
+
+// merge blocks K = 2, 4, ..., 64 E: the flip stage (partner i ^ (K - 1)), then the ordinary stages K / 4 .. 1
+template <int E, int K>
+__device__ __forceinline__ void wave_blocks(unsigned long long (&key)[E], int lane)
+{
+    if constexpr (K <= 64 * E) {
+        if constexpr (K <= E) {
+#pragma unroll
+            for (int m = 0; m < E; ++m)
+                if ((m & (K / 2)) == 0) wave_ce<E>(key, m, m ^ (K - 1));
+        } else {
+            wave_stage_cross<E, K / E - 1, K / (2 * E), true>(key, lane);    // lane ^ (K/E - 1), register E-1-m; lower: index bit K/2 clear
+        }
+        wave_stages_down<E, K / 4>(key, lane);
+        wave_blocks<E, K * 2>(key, lane);
+    }
+}
+
+// sort keys[beg, beg + n) (n <= 64 E) into point_list
+template <int E>
+__device__ __forceinline__ void wave_sort_list(const uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list, uint32_t beg, int n, int lane)
+{
+    unsigned long long key[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+        const int t = lane * E + m;
+        key[m] = t < n ? keys[beg + t] : kSortPad;
+    }
+    wave_blocks<E, 2>(key, lane);
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+        const int t = lane * E + m;
+        if (t < n) point_list[beg + t] = (uint32_t)key[m];
+    }
+}
+
 // Workgroup -> (run, list begin, list length): one 16-byte load.  The first `max_extra` workgroups take the runs 1.. of
 // the long lists from the run table (so the long lists start first), the rest take run 0 of schedule slot b - max_extra.
 // The status words are read together with it (independent loads, one latency).
 __device__ __forceinline__ bool sort_block_assignment(const uint4 *__restrict__ tile_order,
                                                       const uint4 *__restrict__ run_table,
                                                       const int64_t *__restrict__ status, uint32_t max_extra,
-                                                      uint32_t b, uint32_t &run, uint32_t &beg, int &n, uint32_t *tile_out = nullptr)
+                                                      uint32_t b, uint32_t &run, uint32_t &beg, int &n)
 {
     const bool extra = b < max_extra;
     const uint4 rec = extra ? run_table[b] : tile_order[b - max_extra];
     const int64_t overflow = status[GA_STATUS_OVERFLOW], extra_runs = status[GA_STATUS_EXTRA_RUNS];
-    if (tile_out) *tile_out = extra ? 0xFFFFFFFFu : rec.x;   // (schedule slots: written by the scan whatever the overflow state)
     if (overflow || (extra && (int64_t)b >= extra_runs)) return false;
     run = extra ? rec.y : 0u;
     beg = extra ? rec.z : rec.y;
@@ -620,27 +744,64 @@ __device__ __forceinline__ bool sort_block_assignment(const uint4 *__restrict__ 
     return true;
 }
 
+// Grid: [ max_extra workgroups: runs 1.. of the lists longer than one run (run table) | nbig workgroups: run 0 of schedule slot j if its
+// list has kWaveSort entries or more (the schedule is longest first; at most capacity / kWaveSort lists are that long, and a slot whose
+// list is shorter leaves at once) | ceil(slots / 4) workgroups: slots 4 g .. 4 g + 3, ONE WAVEFRONT PER LIST with the keys in registers,
+// lists shorter than kWaveSort ].  Round 3 gave every list a 256-thread workgroup and the LDS network: a typical short list (64 .. 256
+// keys) ran it with 16 .. 32 active lanes.  Measured (tools/sort_stamps.py): the launch is bound by the lists of 512 .. 2048 entries in
+// their workgroups (three quarters of all keys, 17 .. 24 us of life each, four of them per CU at a time); one wave per list of ANY length
+// (32 keys per lane for a 2048-key run: 64-bit cross-lane stages cost ~30 cycles per key, a single wave's chain was 30 .. 40 us) was
+// built and measured: 53 us instead of 36 for sort + merge -- not kept.
 __global__ __launch_bounds__(256) void surfel_run_sort_kernel(const uint4 *__restrict__ tile_order,
                                                               const uint4 *__restrict__ run_table,
-                                                              uint32_t max_extra, uint64_t *__restrict__ keys,
+                                                              uint32_t max_extra, uint32_t nbig, uint32_t nslots,
+                                                              uint64_t *__restrict__ keys,
                                                               uint32_t *__restrict__ point_list,
                                                               const int64_t *__restrict__ status,
                                                               uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_cursor,
-                                                              unsigned long long *__restrict__ view_total, int nviews)
+                                                              unsigned long long *__restrict__ view_total, int nviews,
+                                                              unsigned long long *__restrict__ dbg)
 {
     __shared__ __attribute__((aligned(16))) double s[kSortCap];  // raw key bits (see bitonic_sort_blocked)
-    uint32_t run, beg, vt;
-    int n;
-    const bool go = sort_block_assignment(tile_order, run_table, status, max_extra, blockIdx.x, run, beg, n, &vt);
-    // Leave the accumulating words of the binning clean for the NEXT launch (GA_SURFEL_FLAG_WORKSPACE_CLEAN): every schedule slot's
-    // workgroup clears its tile's counter and fill cursor -- the fill launch that read them is complete -- and the first one the
-    // view totals.  (The segment / status words are cleared by the scan workgroup.)
-    if (vt != 0xFFFFFFFFu && threadIdx.x == 0) { tile_count[vt] = 0u; tile_cursor[vt] = 0u; }
-    if (blockIdx.x == max_extra)
-        for (int u = threadIdx.x; u < nviews * kViewSlots; u += 256) view_total[u] = 0ull;
-    if (!go || n <= 0) return;
     const int tid = threadIdx.x;
-    if (n == 1) { if (tid == 0) point_list[beg] = (uint32_t)keys[beg]; return; }
+#ifdef GA_SORT_STAMPS   // measurement build: (start, end, list length) per wave in the (dead by now) depth array, 100 MHz clock
+    struct StampExit {
+        unsigned long long *p, t0; int n;
+        __device__ ~StampExit() { p[0] = t0; p[1] = __builtin_amdgcn_s_memrealtime(); p[2] = 0x5A5A000000000000ull | (unsigned)n; }
+    } stamp{dbg + ((size_t)blockIdx.x * 4 + (tid >> 6)) * 4, __builtin_amdgcn_s_memrealtime(), -1};
+#define GA_STAMP_N(x) stamp.n = (x)
+#else
+#define GA_STAMP_N(x)
+#endif
+    if (blockIdx.x >= max_extra + nbig) {
+        // ---- one wavefront per list
+        const int lane = tid & 63, wave = tid >> 6;
+        const uint32_t g = blockIdx.x - max_extra - nbig, j = 4u * g + (uint32_t)wave;
+        const uint4 rec = tile_order[j < nslots ? j : 0u];
+        const int64_t overflow = status[GA_STATUS_OVERFLOW];
+        if (j >= nslots) return;
+        // Leave the accumulating words of the binning clean for the NEXT launch (GA_SURFEL_FLAG_WORKSPACE_CLEAN): every schedule slot's
+        // wave clears its tile's counter and fill cursor -- the fill launch that read them is complete -- and the first workgroup the
+        // view totals.  (The segment / status words are cleared by the scan workgroup; the schedule is written whatever the overflow state.)
+        if (lane == 0) { tile_count[rec.x] = 0u; tile_cursor[rec.x] = 0u; }
+        if (g == 0)
+            for (int u = tid; u < nviews * kViewSlots; u += 256) view_total[u] = 0ull;
+        const uint32_t beg = rec.y;
+        const int n = (int)rec.z;
+        GA_STAMP_N(n < kWaveSort ? n : -2);
+        if (overflow || n <= 0 || n >= kWaveSort) return;
+        if (n == 1) { if (lane == 0) point_list[beg] = (uint32_t)keys[beg]; return; }
+        if (n <= 64) wave_sort_list<1>(keys, point_list, beg, n, lane);
+        else if (n <= 128) wave_sort_list<2>(keys, point_list, beg, n, lane);
+        else if (n <= 256) wave_sort_list<4>(keys, point_list, beg, n, lane);
+        else wave_sort_list<8>(keys, point_list, beg, n, lane);
+        return;
+    }
+    uint32_t run, beg;
+    int n;
+    if (!sort_block_assignment(tile_order, run_table, status, max_extra, blockIdx.x, run, beg, n)) return;
+    if (n < kWaveSort) return;     // (a wavefront of the last grid region sorts it)
+    GA_STAMP_N(n);
     const int rb = (int)run * kSortCap, rn = min(kSortCap, n - rb);
     int np = 2; while (np < rn) np <<= 1;
     for (int t = tid; t < np; t += 256) s[sort_slot(t)] = __longlong_as_double((long long)(t < rn ? keys[beg + rb + t] : kSortPad));
@@ -756,8 +917,10 @@ void launch_tile_sort(const GaSurfelForwardArgs &a, const Dims &d, const Workspa
 {
     const uint32_t nt = (uint32_t)(d.V * d.tiles);
     const uint32_t max_extra = (uint32_t)(a.capacity / kSortCap + 1);
-    hipLaunchKernelGGL(surfel_run_sort_kernel, dim3(nt + max_extra), dim3(256), 0, s, ws.tile_order,
-                       ws.run_table, max_extra, ws.keys, ws.point_list, ws.status, ws.tile_count, ws.tile_cursor, ws.view_total, d.V);
+    const uint32_t nbig = (uint32_t)std::min<int64_t>(nt, a.capacity / kWaveSort + 1);   // lists of kWaveSort entries or more
+    hipLaunchKernelGGL(surfel_run_sort_kernel, dim3(max_extra + nbig + (nt + 3) / 4), dim3(256), 0, s, ws.tile_order,
+                       ws.run_table, max_extra, nbig, nt, ws.keys, ws.point_list, ws.status, ws.tile_count, ws.tile_cursor, ws.view_total, d.V,
+                       reinterpret_cast<unsigned long long *>(ws.depth));
     // lists longer than one run sit at the front of tile_order and there are fewer than capacity / kSortCap of them
     const uint32_t max_big = (uint32_t)std::min<int64_t>(nt, a.capacity / kSortCap);
     hipLaunchKernelGGL(surfel_run_merge_kernel, dim3((max_big + max_extra) * kMergeParts), dim3(256), 0, s, ws.tile_order,
