@@ -322,6 +322,10 @@ __global__ __launch_bounds__(256) void final_layer_kernel(FinalArgs a)
         float mine = 0.f;
 #pragma unroll
         for (int o = 0; o < 16; ++o) mine = lane == o ? v[o] : mine;
+        if (a.dt == nullptr) {    // GaDitSamplerStep.velocity: the velocity itself, both halves
+            for (int h = 0; h < (a.cfg ? 2 : 1); ++h) a.state[(size_t)(row + h * half) * a.Cout + lane] = mine;
+            return;
+        }
         const float dtv = *a.dt;
         float *slice = a.traj ? a.traj + (size_t)(*a.counter + 1) * a.traj_stride : nullptr;
         for (int h = 0; h < (a.cfg ? 2 : 1); ++h) {
@@ -420,7 +424,7 @@ static bool model_ok(const GaDitModel *m)
 
 }  // namespace gadit
 
-extern "C" const char *ga_dit_version(void) { return "ga_mi355 dit gfx950 r3"; }
+extern "C" const char *ga_dit_version(void) { return "ga_mi355 dit gfx950 r4"; }
 
 extern "C" size_t ga_dit_workspace_bytes(const GaDitModel *m, int32_t batch, int32_t tokens, int32_t ctx_tokens)
 {
@@ -567,11 +571,16 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
                     0.f, 0, nullptr, nullptr, nullptr, 0, nullptr};
         int rows = Mrows;
         if (const GaDitSamplerStep *st = a->step) {
-            if (!st->dt || !st->state || !st->counter || (st->cfg && (B % 2 != 0)) || st->state != a->x ||
-                m->out_channels != m->in_channels)
-                return GA_DIT_ERR_BAD_SHAPE;
-            f.cfg_scale = st->cfg_scale; f.cfg = st->cfg ? 1 : 0; f.dt = st->dt; f.state = st->state; f.traj = st->traj;
-            f.traj_stride = st->traj_stride; f.counter = st->counter;
+            if (st->velocity) {     // the (guided) velocity alone: dt == nullptr tells the kernel
+                if (st->cfg && (B % 2 != 0)) return GA_DIT_ERR_BAD_SHAPE;
+                f.cfg_scale = st->cfg_scale; f.cfg = st->cfg ? 1 : 0; f.state = st->velocity;
+            } else {
+                if (!st->dt || !st->state || !st->counter || (st->cfg && (B % 2 != 0)) || st->state != a->x ||
+                    m->out_channels != m->in_channels)
+                    return GA_DIT_ERR_BAD_SHAPE;
+                f.cfg_scale = st->cfg_scale; f.cfg = st->cfg ? 1 : 0; f.dt = st->dt; f.state = st->state; f.traj = st->traj;
+                f.traj_stride = st->traj_stride; f.counter = st->counter;
+            }
             rows = st->cfg ? Mrows / 2 : Mrows;
         }
         hipLaunchKernelGGL(final_layer_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, f);

@@ -318,7 +318,7 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         tvec = torch.empty(B, dtype=torch.float32, device=dev)
         dt = torch.empty(1, dtype=torch.float32, device=dev)
         step = ops.GaDitSamplerStep(float(cfg_scale), 1 if cfg else 0, dt.data_ptr(), y.data_ptr(), out.data_ptr(),
-                                    y.numel(), counter.data_ptr())
+                                    y.numel(), counter.data_ptr(), None)
         Lib = ops.lib()
 
         def one_step():
@@ -348,6 +348,85 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         for _ in range(n - 1):
             graph.replay()
         self._fused_keep = (y, t_arr, dt_arr, counter, tvec, dt, step, graph)   # alive until the replays have run
+        return out
+
+
+    @torch.no_grad()
+    def sample_dopri5_device(self, y0, t_grid, context, cfg_scale=1.0, cfg=True, atol=1e-6, rtol=1e-3, stats=None, max_steps=1 << 16):
+        """The reference's DEFAULT sampler -- torchdiffeq's dopri5 behind ``ode.sample`` (transport/integrators.py:100-119,
+        flow_matching_trainer.py:715) -- with the adaptive loop on the device (csrc/ode_dopri5.hip): one attempted step = six
+        (stage input, function evaluation with the guided velocity leaving through the final-layer kernel) pairs, the error norm, a
+        one-thread controller and a predicated accept kernel with the dense output, captured into ONE HIP graph and replayed; time,
+        step size, decisions and counters live in a device block and the host only reads the ``done`` word after a replay.  Same
+        decisions as ``transport/odeint.py`` / ``oracle/ode.py`` (the initial step size is chosen on the host as there: two
+        evaluations).  Returns the states at every requested time."""
+        from ..transport.odeint import _initial_step
+        dev = y0.device
+        tt = [float(v) for v in t_grid]
+        ng = len(tt)
+        y = y0.detach().float().contiguous().clone()
+        out = torch.empty((ng,) + tuple(y.shape), dtype=torch.float32, device=dev)
+        out[0].copy_(y)
+        B, n = y.shape[0], y.numel()
+        Lib = ops.lib()
+        k = [torch.empty_like(y) for _ in range(7)]
+        ystage, tvec = torch.empty_like(y), torch.empty(B, dtype=torch.float32, device=dev)
+        ctl = torch.zeros(ops.GA_ODE_CTL_WORDS, dtype=torch.float64, device=dev)
+        tg = torch.tensor(tt, dtype=torch.float64, device=dev)
+        nfe = [0]
+
+        def velocity_into(dst, x, tv):
+            nfe[0] += 1
+            self.forward(x, tv, context, _step=ops.GaDitSamplerStep(float(cfg_scale), 1 if cfg else 0, None, None, None, 0, None, dst.data_ptr()))
+
+        def rhs(ts, yy):      # (the two host-side evaluations of the initial step size)
+            r = torch.empty_like(y)
+            velocity_into(r, yy.contiguous(), torch.full((B,), float(ts), dtype=torch.float32, device=dev))
+            return r
+
+        tvec.fill_(tt[0])
+        velocity_into(k[0], y, tvec)
+        dt0 = _initial_step(rhs, tt[0], y, k[0], rtol, atol)
+        head = torch.zeros(ops.GA_ODE_CTL_WORDS, dtype=torch.float64)
+        head[ops.GA_ODE_T], head[ops.GA_ODE_DT], head[ops.GA_ODE_ATOL], head[ops.GA_ODE_RTOL], head[ops.GA_ODE_JNEXT] = tt[0], dt0, atol, rtol, 1
+        ctl.copy_(head)
+        ode = ops.GaOdeDopri5(n, B, ng, y.data_ptr(), (ops.c_p * 7)(*[t.data_ptr() for t in k]), ystage.data_ptr(), tvec.data_ptr(),
+                              ctl.data_ptr(), tg.data_ptr(), out.data_ptr())
+
+        def attempt():
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            for i in range(6):
+                ops.check(Lib.ga_ode_dopri5_stage(ctypes.byref(ode), i, stream), "ga_ode_dopri5_stage")
+                velocity_into(k[i + 1], ystage, tvec)
+            ops.check(Lib.ga_ode_dopri5_finish(ctypes.byref(ode), stream), "ga_ode_dopri5_finish")
+
+        host = torch.empty(ops.GA_ODE_CTL_WORDS, dtype=torch.float64).pin_memory()
+        done_evt = torch.cuda.Event()
+        evals_before = nfe[0]
+        if ng > 1:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):     # (capture executes nothing; the evaluations above were the warm-up)
+                attempt()
+            nfe[0] = evals_before
+            while True:
+                graph.replay()
+                host.copy_(ctl, non_blocking=True)
+                done_evt.record()
+                done_evt.synchronize()
+                if host[ops.GA_ODE_DONE] != 0 or host[ops.GA_ODE_STEPS] >= max_steps:
+                    break
+            self._dopri5_keep = (graph, y, k, ystage, tvec, ctl, tg, ode)
+            err, steps = int(host[ops.GA_ODE_ERROR]), int(host[ops.GA_ODE_STEPS])
+            if err == 1:
+                raise FloatingPointError(f"dopri5: non-finite error ratio at t = {float(host[ops.GA_ODE_T])}: the model returned NaN/inf")
+            if err == 2:
+                raise FloatingPointError(f"dopri5: step size underflow at t = {float(host[ops.GA_ODE_T])}")
+            if host[ops.GA_ODE_DONE] == 0:
+                raise RuntimeError(f"dopri5: more than {max_steps} attempted steps")
+            if stats is not None:
+                stats.update(nfe=evals_before + 6 * steps, steps=steps, rejected=int(host[ops.GA_ODE_REJECTED]), graph=True, device_loop=True)
+        elif stats is not None:
+            stats.update(nfe=evals_before, steps=0, rejected=0, graph=True, device_loop=True)
         return out
 
 

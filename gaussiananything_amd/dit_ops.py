@@ -57,7 +57,19 @@ class GaDitModel(ctypes.Structure):
 class GaDitSamplerStep(ctypes.Structure):
     """include/ga_dit.h: GaDitSamplerStep"""
     _fields_ = [("cfg_scale", ctypes.c_float), ("cfg", i32), ("dt", c_p), ("state", c_p), ("traj", c_p),
-                ("traj_stride", ctypes.c_int64), ("counter", c_p)]
+                ("traj_stride", ctypes.c_int64), ("counter", c_p), ("velocity", c_p)]
+
+
+class GaOdeDopri5(ctypes.Structure):
+    """include/ga_dit.h: GaOdeDopri5"""
+    _fields_ = [("n", ctypes.c_int64), ("batch", i32), ("grid_len", i32), ("y", c_p), ("k", c_p * 7), ("ystage", c_p), ("timesteps", c_p),
+                ("ctl", c_p), ("t_grid", c_p), ("out", c_p)]
+
+
+# indices into GaOdeDopri5.ctl (include/ga_dit.h)
+(GA_ODE_T, GA_ODE_DT, GA_ODE_SUMSQ, GA_ODE_ATOL, GA_ODE_RTOL, GA_ODE_DONE, GA_ODE_STEPS, GA_ODE_REJECTED, GA_ODE_ACCEPT, GA_ODE_TA,
+ GA_ODE_TB, GA_ODE_DT_USED, GA_ODE_JNEXT, GA_ODE_JBEG, GA_ODE_JCOUNT, GA_ODE_ERROR, GA_ODE_RATIO) = range(17)
+GA_ODE_CTL_WORDS = 24
 
 
 class GaDitForwardArgs(ctypes.Structure):
@@ -67,7 +79,8 @@ class GaDitForwardArgs(ctypes.Structure):
 
 
 DIT_EXPORTS = ("ga_gemm_bf16", "ga_attention_bf16", "ga_rmsnorm_modulate", "ga_small_linear", "ga_dit_workspace_bytes",
-               "ga_dit_cache_context", "ga_dit_forward", "ga_dit_sampler_advance", "ga_dit_version")
+               "ga_dit_cache_context", "ga_dit_forward", "ga_dit_sampler_advance", "ga_ode_dopri5_stage", "ga_ode_dopri5_finish",
+               "ga_dit_version")
 _ERR = {-1: "GA_DIT_ERR_NULL_ARG", -2: "GA_DIT_ERR_BAD_SHAPE", -4: "GA_DIT_ERR_LAUNCH"}
 _bound = False
 
@@ -90,6 +103,10 @@ def lib():
         L.ga_dit_forward.argtypes = [ctypes.POINTER(GaDitModel), ctypes.POINTER(GaDitForwardArgs), c_p]
         L.ga_dit_sampler_advance.restype = ctypes.c_int
         L.ga_dit_sampler_advance.argtypes = [c_p, c_p, c_p, i32, c_p, i32, c_p, c_p]
+        L.ga_ode_dopri5_stage.restype = ctypes.c_int
+        L.ga_ode_dopri5_stage.argtypes = [ctypes.POINTER(GaOdeDopri5), i32, c_p]
+        L.ga_ode_dopri5_finish.restype = ctypes.c_int
+        L.ga_ode_dopri5_finish.argtypes = [ctypes.POINTER(GaOdeDopri5), c_p]
         _bound = True
     return L
 

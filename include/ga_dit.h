@@ -198,6 +198,9 @@ typedef struct GaDitSamplerStep {
     float *traj;              /* trajectory base (slice 0 = initial state, written by the caller) or NULL */
     int64_t traj_stride;      /* floats per slice = B' * L * Cout                                        */
     const int32_t *counter;   /* device: index of the grid interval this step integrates                */
+    float *velocity;          /* NULL: the Euler step above.  Otherwise ONLY the velocity of the evaluation -- the model output, or with
+                                 cfg the guided combination u + s (c - u) in BOTH halves (forward_with_cfg's return value) -- is written
+                                 here, [B', L, Cout]; dt / state / traj / counter are not used (the stages of ga_ode_dopri5_*)           */
 } GaDitSamplerStep;
 
 typedef struct GaDitForwardArgs {
@@ -235,6 +238,48 @@ int ga_dit_forward(const GaDitModel *model, const GaDitForwardArgs *args, void *
  * *dt = dt_grid[*counter] (both grids fp32 device arrays of num_steps - 1 entries; reads past the end are clamped). */
 int ga_dit_sampler_advance(int32_t *counter, const float *t_grid, const float *dt_grid, int32_t grid_len, float *timesteps,
                            int32_t batch, float *dt, void *stream);
+
+/* ---- device-resident Dormand-Prince 5(4): the reference's default sampler (Sampler.sample_ode(sampling_method="dopri5"),
+ * /root/reference/transport/transport.py:384-431 -> torchdiffeq.odeint, transport/integrators.py:111-118).  One attempted step is
+ *     for i in 0..5:  ga_ode_dopri5_stage(o, i);  ga_dit_forward(x = o->ystage, timesteps = o->timesteps, step.velocity = o->k[i + 1])
+ *     ga_ode_dopri5_finish(o)
+ * -- a fixed launch sequence (capture it into a hipGraph and replay it) that keeps time, step size, the accept / reject decision and
+ * the counters in `ctl`; the host only reads ctl[GA_ODE_DONE] after a replay.  Before the first step the caller puts the initial
+ * state into y, f(t0, y0) into k[0], and t0 / the first step size / atol / rtol / JNEXT = 1 (out[0] = y0 is the caller's) into ctl. */
+#define GA_ODE_T 0          /* time of the state y (fp64)                                  */
+#define GA_ODE_DT 1         /* size of the NEXT attempted step                             */
+#define GA_ODE_SUMSQ 2      /* accumulator of the error norm (zero between steps)          */
+#define GA_ODE_ATOL 3
+#define GA_ODE_RTOL 4
+#define GA_ODE_DONE 5       /* 1: the last requested time has been produced (or ERROR set) */
+#define GA_ODE_STEPS 6      /* attempted steps                                             */
+#define GA_ODE_REJECTED 7
+#define GA_ODE_ACCEPT 8     /* the step just attempted was accepted                        */
+#define GA_ODE_TA 9         /* its interval                                                */
+#define GA_ODE_TB 10
+#define GA_ODE_DT_USED 11
+#define GA_ODE_JNEXT 12     /* next requested time not produced yet                        */
+#define GA_ODE_JBEG 13      /* requested times inside the accepted step: first, count      */
+#define GA_ODE_JCOUNT 14
+#define GA_ODE_ERROR 15     /* 1: non-finite error ratio (NaN / inf model output), 2: step size underflow */
+#define GA_ODE_RATIO 16     /* error ratio of the step just attempted (diagnostic)         */
+#define GA_ODE_CTL_WORDS 24
+
+typedef struct GaOdeDopri5 {
+    int64_t n;              /* floats of the state: B' * L * C                             */
+    int32_t batch;          /* B': entries of `timesteps`                                  */
+    int32_t grid_len;       /* requested times                                             */
+    float *y;               /* [n] state at ctl[T]                                         */
+    float *k[7];            /* [n] each: k[0] = f(t, y) (FSAL), k[1..6] the stage derivatives */
+    float *ystage;          /* [n] input of the next function evaluation; after stage 5: the 5th-order solution */
+    float *timesteps;       /* [B'] time of the next function evaluation (fp32, as the reference passes it)     */
+    double *ctl;            /* [GA_ODE_CTL_WORDS] device scalars, see above                */
+    const double *t_grid;   /* [grid_len] requested times, increasing                     */
+    float *out;             /* [grid_len, n] dense output (slice 0 is the caller's)        */
+} GaOdeDopri5;
+
+int ga_ode_dopri5_stage(const GaOdeDopri5 *ode, int32_t stage, void *stream);
+int ga_ode_dopri5_finish(const GaOdeDopri5 *ode, void *stream);
 
 const char *ga_dit_version(void);
 

@@ -440,6 +440,30 @@ def test_dopri5_on_the_golden_model_against_the_ode_oracle(gpu_device):
     assert rel_l2(out.cpu().double(), torch.from_numpy(ref)) < 3e-2
 
 
+def test_device_resident_dopri5_takes_the_decisions_of_the_host_loop(gpu_device, monkeypatch):
+    """csrc/ode_dopri5.hip (one attempted step = one replayed HIP graph; controller, accept / reject and dense output on the device)
+    against the host loop of transport/odeint.py on the same denoiser: same evaluations, accepted and rejected steps, same states
+    -- with and without guidance, and on a grid whose first output times fall inside one accepted step."""
+    from gaussiananything_amd.transport import Sampler, create_transport
+    z, model, ctx = _load_golden(1, gpu_device)
+    x = z["x"].to(gpu_device)
+    sampler = Sampler(create_transport("GVP", "velocity", None, None, None, snr_type="uniform"))
+    for fwd, n_out in ((model.forward_with_cfg, 9), (model.forward_cond, 9), (model.forward_with_cfg, 250)):
+        got = {}
+        for flag in ("0", "1"):
+            monkeypatch.setenv("GA_ODE_GRAPH", flag)
+            fn = sampler.sample_ode(sampling_method="dopri5", num_steps=n_out, atol=1e-6, rtol=1e-3)
+            with torch.no_grad():
+                out = fn(x, fwd, context=ctx, cfg_scale=z["cfg_scale"])
+            got[flag] = (out, dict(sampler.last_ode.last_stats))
+        (a, sa), (b, sb) = got["0"], got["1"]
+        assert sb.get("device_loop") and not sa.get("device_loop")
+        assert (sa["nfe"], sa["steps"], sa["rejected"]) == (sb["nfe"], sb["steps"], sb["rejected"]), (sa, sb)
+        assert a.shape == b.shape == (n_out,) + tuple(x.shape)
+        assert rel_l2(b, a) < 2e-3, rel_l2(b, a)      # (bf16 function: an ulp of the fp32 state can round an operand the other way)
+        assert torch.equal(b[0], x.float())
+
+
 def test_cpu_tensors_raise(gpu_device):
     z, model, ctx = _load_golden(1, gpu_device)
     with pytest.raises(RuntimeError):
