@@ -12,7 +12,7 @@
 //                                (bitonic network, 16 KiB so 8+ workgroups share a CU).  Keys are unique per tile, so
 //                                the result equals the stable radix sort by depth with index as the tie-break -- the
 //                                order upstream's stable sort yields.  A tile that fits one run is finished here;
-//   5. surfel_run_merge_kernel : longer lists (several runs, sorted in parallel by different workgroups) are merged
+//   5. (last grid region of 4) : longer lists (several runs, sorted in parallel by different workgroups) are merged
 //                                by rank counting: final position = index in own run + sum over the other runs of
 //                                lower_bound(key) -- correct for any length, and the longest list of a real scene
 //                                (~5 k entries) costs one 2048-sort plus 22 L2 probes per entry instead of a serial
@@ -246,12 +246,11 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs &a)
     const uint32_t table_cap = (uint32_t)(capacity / kSortCap + 1);
     for (uint32_t base = 0; base < nbig; base += 1024) {
         const uint32_t p = base + tid;
-        uint32_t t = 0, extra = 0, c = 0, tb = 0;
+        uint32_t extra = 0, c = 0, tb = 0;
         if (p < nbig) {
-            if (p < (uint32_t)kBigStash) { t = big_tile[p]; c = big_cnt[p]; tb = big_beg[p]; }
+            if (p < (uint32_t)kBigStash) { c = big_cnt[p]; tb = big_beg[p]; }
             else {
                 const uint32_t *rec = reinterpret_cast<const uint32_t *>(tile_order + p);
-                t = __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 tb = __hip_atomic_load(rec + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 c = __hip_atomic_load(rec + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -270,7 +269,7 @@ __device__ __forceinline__ void tile_scan_body(const ScanArgs &a)
         const uint32_t carry = carry_s;
         uint32_t dst = carry + wbase + x - extra;
         for (uint32_t r = 1; r <= extra; ++r, ++dst)
-            if (dst < table_cap) run_table[dst] = make_uint4(t, r, tb, c);
+            if (dst < table_cap) run_table[dst] = make_uint4(p, r, tb, c);   // (schedule slot of the list, run, list begin, list length)
         __syncthreads();
         if (tid == 1023) carry_s = carry + wbase + x;
         __syncthreads();
@@ -744,6 +743,71 @@ __device__ __forceinline__ bool sort_block_assignment(const uint4 *__restrict__ 
     return true;
 }
 
+// Rank merge of the sorted runs of a long list (keys unique inside a tile => ranks are a permutation), as the LAST GRID REGION of the
+// sort launch (round 3: a launch of its own, 10 us behind the sort).  A run is split over kMergeParts workgroups (2 keys per thread);
+// the other runs are copied into LDS one at a time, then every thread binary-searches its keys in them, branch-free.  The runs are
+// sorted by earlier workgroups of the same launch: each of them, having written its run, fences and counts itself in word 5 of the
+// list's seg_sync group (zero at launch: the scan clears it); a merge workgroup waits for the count to reach the number of runs --
+// everything it waits for was dispatched before it (workgroups are dispatched in index order), so the wait cannot deadlock.
+constexpr int kMergeParts = 4;
+
+__device__ __forceinline__ void merge_runs(uint64_t *__restrict__ other, const uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
+                                           const uint32_t *__restrict__ run_count, uint32_t run, uint32_t beg, int n, int part)
+{
+    const int nruns = (n + kSortCap - 1) / kSortCap;
+    if (threadIdx.x == 0)
+        while (__hip_atomic_load(run_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)nruns) __builtin_amdgcn_s_sleep(8);
+    __syncthreads();
+    // (no fence: an agent-scope fence on gfx950 writes back / invalidates the XCD's whole L2 -- measured here: the launch went from 25 to
+    // 78 us.  The runs are WRITTEN with agent-scope stores (through the L2) that have completed before their workgroup counts itself,
+    // and READ with agent-scope loads, which do not take a line another workgroup of this XCD may have cached before the run was sorted.)
+    const int rb = (int)run * kSortCap, rn = min(kSortCap, n - rb);
+    const uint64_t *k = keys + beg;
+    constexpr int kPer = kSortCap / kMergeParts / 256;  // keys of my part of the run per thread
+    uint64_t mine[kPer];
+    int rank[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+        const int e = part * (kSortCap / kMergeParts) + (int)threadIdx.x + 256 * i;
+        mine[i] = e < rn ? __hip_atomic_load(k + rb + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+        rank[i] = e;
+    }
+    for (int j = 0; j < nruns - 1; ++j) {  // the other runs, skipping my own
+        const int r = j < (int)run ? j : j + 1;
+        const int ob = r * kSortCap, on = min(kSortCap, n - ob);
+        if (j) __syncthreads();
+        uint64_t tmp[kSortCap / 256];
+#pragma unroll
+        for (int i = 0; i < kSortCap / 256; ++i) {
+            const int t = (int)threadIdx.x + 256 * i;
+            tmp[i] = t < on ? __hip_atomic_load(k + ob + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+        }
+#pragma unroll
+        for (int i = 0; i < kSortCap / 256; ++i) other[threadIdx.x + 256 * i] = tmp[i];
+        __syncthreads();
+        int lo[kPer], hi[kPer];
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) { lo[i] = 0; hi[i] = on; }
+        for (int step = 0; step < 12; ++step) {  // 2^11 = kSortCap: 12 halvings reach lo == hi
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                const bool open = lo[i] < hi[i];
+                const int mid = (lo[i] + hi[i]) >> 1;       // < kSortCap whenever the interval is open
+                const bool less = other[mid & (kSortCap - 1)] < mine[i];
+                lo[i] = (open && less) ? mid + 1 : lo[i];
+                hi[i] = (open && !less) ? mid : hi[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) rank[i] += lo[i];
+    }
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+        const int e = part * (kSortCap / kMergeParts) + (int)threadIdx.x + 256 * i;
+        if (e < rn) point_list[beg + rank[i]] = (uint32_t)mine[i];
+    }
+}
+
 // Grid: [ max_extra workgroups: runs 1.. of the lists longer than one run (run table) | nbig workgroups: run 0 of schedule slot j if its
 // list has kWaveSort entries or more (the schedule is longest first; at most capacity / kWaveSort lists are that long, and a slot whose
 // list is shorter leaves at once) | ceil(slots / 4) workgroups: slots 4 g .. 4 g + 3, ONE WAVEFRONT PER LIST with the keys in registers,
@@ -760,7 +824,7 @@ __global__ __launch_bounds__(256) void surfel_run_sort_kernel(const uint4 *__res
                                                               const int64_t *__restrict__ status,
                                                               uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_cursor,
                                                               unsigned long long *__restrict__ view_total, int nviews,
-                                                              unsigned long long *__restrict__ dbg)
+                                                              uint32_t *__restrict__ seg_sync, unsigned long long *__restrict__ dbg)
 {
     __shared__ __attribute__((aligned(16))) double s[kSortCap];  // raw key bits (see bitonic_sort_blocked)
     const int tid = threadIdx.x;
@@ -773,6 +837,19 @@ __global__ __launch_bounds__(256) void surfel_run_sort_kernel(const uint4 *__res
 #else
 #define GA_STAMP_N(x)
 #endif
+    const uint32_t nsort = max_extra + nbig + (nslots + 3u) / 4u;
+    if (blockIdx.x >= nsort) {
+        // ---- last region: merge of the runs of the lists longer than one run (see merge_runs)
+        const uint32_t b = (blockIdx.x - nsort) / kMergeParts;
+        uint32_t run, beg;
+        int n;
+        const uint32_t pos = b < max_extra ? run_table[b].x : b - max_extra;
+        if (!sort_block_assignment(tile_order, run_table, status, max_extra, b, run, beg, n)) return;
+        if (n <= kSortCap) return;
+        merge_runs(reinterpret_cast<uint64_t *>(s), keys, point_list, seg_sync + 8 * (size_t)pos + 5, run, beg, n,
+                   (int)((blockIdx.x - nsort) % kMergeParts));
+        return;
+    }
     if (blockIdx.x >= max_extra + nbig) {
         // ---- one wavefront per list
         const int lane = tid & 63, wave = tid >> 6;
@@ -799,8 +876,9 @@ __global__ __launch_bounds__(256) void surfel_run_sort_kernel(const uint4 *__res
     }
     uint32_t run, beg;
     int n;
+    const uint32_t pos = blockIdx.x < max_extra ? run_table[blockIdx.x].x : blockIdx.x - max_extra;   // schedule slot of my list
     if (!sort_block_assignment(tile_order, run_table, status, max_extra, blockIdx.x, run, beg, n)) return;
-    if (n < kWaveSort) return;     // (a wavefront of the last grid region sorts it)
+    if (n < kWaveSort) return;     // (a wavefront of the next grid region sorts it)
     GA_STAMP_N(n);
     const int rb = (int)run * kSortCap, rn = min(kSortCap, n - rb);
     int np = 2; while (np < rn) np <<= 1;
@@ -810,90 +888,12 @@ __global__ __launch_bounds__(256) void surfel_run_sort_kernel(const uint4 *__res
     if (n <= kSortCap) {
         for (int t = tid; t < rn; t += 256) point_list[beg + t] = (uint32_t)__double_as_longlong(s[sort_slot(t)]);   // single run: final order
     } else {
-        for (int t = tid; t < rn; t += 256) keys[beg + rb + t] = (uint64_t)__double_as_longlong(s[sort_slot(t)]);              // sorted run, merged by the next kernel
-    }
-}
-
-// Rank merge of the sorted runs of a long list (keys unique inside a tile => ranks are a permutation).  A run is split
-// over kMergeParts workgroups (2 keys per thread); the other runs are copied into LDS three at a time with all global
-// loads in flight together, then every thread binary-searches its keys in them, all searches interleaved and
-// branch-free.  (History: chasing 8 x 22 dependent L2 loads per thread took 34 us for a handful of lists; one other run
-// at a time with 8 keys per thread 25 us, profiles/r1b_*, r1c_*.)
-constexpr int kMergeParts = 4;
-constexpr int kMergeGroup = 3;
-
-__global__ __launch_bounds__(256) void surfel_run_merge_kernel(const uint4 *__restrict__ tile_order,
-                                                               const uint4 *__restrict__ run_table,
-                                                               uint32_t max_extra, const uint64_t *__restrict__ keys,
-                                                               uint32_t *__restrict__ point_list,
-                                                               const int64_t *__restrict__ status)
-{
-    __shared__ __attribute__((aligned(16))) uint64_t other[kMergeGroup][kSortCap];
-    uint32_t run, beg;
-    int n;
-    if (!sort_block_assignment(tile_order, run_table, status, max_extra, blockIdx.x / kMergeParts, run, beg, n)) return;
-    if (n <= kSortCap) return;
-    const int part = (int)(blockIdx.x % kMergeParts);
-    const int nruns = (n + kSortCap - 1) / kSortCap;
-    const int rb = (int)run * kSortCap, rn = min(kSortCap, n - rb);
-    const uint64_t *k = keys + beg;
-    constexpr int kPer = kSortCap / kMergeParts / 256;  // keys of my part of the run per thread
-    uint64_t mine[kPer];
-    int rank[kPer];
-#pragma unroll
-    for (int i = 0; i < kPer; ++i) {
-        const int e = part * (kSortCap / kMergeParts) + (int)threadIdx.x + 256 * i;
-        mine[i] = e < rn ? k[rb + e] : ~0ull;
-        rank[i] = e;
-    }
-    for (int g0 = 0; g0 < nruns - 1; g0 += kMergeGroup) {  // other runs g0 .. g0+2 (skipping my own)
-        int ob[kMergeGroup], on[kMergeGroup];
-#pragma unroll
-        for (int q = 0; q < kMergeGroup; ++q) {
-            const int j = g0 + q, r = j < (int)run ? j : j + 1;
-            ob[q] = r * kSortCap;
-            on[q] = j < nruns - 1 ? min(kSortCap, n - ob[q]) : 0;
-        }
-        if (g0) __syncthreads();
-        uint64_t tmp[kMergeGroup][kSortCap / 256];
-#pragma unroll
-        for (int q = 0; q < kMergeGroup; ++q)
-#pragma unroll
-            for (int i = 0; i < kSortCap / 256; ++i) {
-                const int t = (int)threadIdx.x + 256 * i;
-                tmp[q][i] = t < on[q] ? k[ob[q] + t] : ~0ull;
-            }
-#pragma unroll
-        for (int q = 0; q < kMergeGroup; ++q)
-#pragma unroll
-            for (int i = 0; i < kSortCap / 256; ++i) other[q][threadIdx.x + 256 * i] = tmp[q][i];
+        // sorted run: merged by the last grid region (other workgroups, possibly on another XCD: see merge_runs)
+        for (int t = tid; t < rn; t += 256)
+            __hip_atomic_store(keys + beg + rb + t, (uint64_t)__double_as_longlong(s[sort_slot(t)]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my stores have completed
         __syncthreads();
-        int lo[kMergeGroup][kPer], hi[kMergeGroup][kPer];
-#pragma unroll
-        for (int q = 0; q < kMergeGroup; ++q)
-#pragma unroll
-            for (int i = 0; i < kPer; ++i) { lo[q][i] = 0; hi[q][i] = on[q]; }
-        for (int step = 0; step < 12; ++step) {  // 2^11 = kSortCap: 12 halvings reach lo == hi
-#pragma unroll
-            for (int q = 0; q < kMergeGroup; ++q)
-#pragma unroll
-                for (int i = 0; i < kPer; ++i) {
-                    const bool open = lo[q][i] < hi[q][i];
-                    const int mid = (lo[q][i] + hi[q][i]) >> 1;       // < kSortCap whenever the interval is open
-                    const bool less = other[q][mid & (kSortCap - 1)] < mine[i];
-                    lo[q][i] = (open && less) ? mid + 1 : lo[q][i];
-                    hi[q][i] = (open && !less) ? mid : hi[q][i];
-                }
-        }
-#pragma unroll
-        for (int q = 0; q < kMergeGroup; ++q)
-#pragma unroll
-            for (int i = 0; i < kPer; ++i) rank[i] += lo[q][i];
-    }
-#pragma unroll
-    for (int i = 0; i < kPer; ++i) {
-        const int e = part * (kSortCap / kMergeParts) + (int)threadIdx.x + 256 * i;
-        if (e < rn) point_list[beg + rank[i]] = (uint32_t)mine[i];
+        if (tid == 0) __hip_atomic_fetch_add(seg_sync + 8 * (size_t)pos + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -918,13 +918,11 @@ void launch_tile_sort(const GaSurfelForwardArgs &a, const Dims &d, const Workspa
     const uint32_t nt = (uint32_t)(d.V * d.tiles);
     const uint32_t max_extra = (uint32_t)(a.capacity / kSortCap + 1);
     const uint32_t nbig = (uint32_t)std::min<int64_t>(nt, a.capacity / kWaveSort + 1);   // lists of kWaveSort entries or more
-    hipLaunchKernelGGL(surfel_run_sort_kernel, dim3(max_extra + nbig + (nt + 3) / 4), dim3(256), 0, s, ws.tile_order,
-                       ws.run_table, max_extra, nbig, nt, ws.keys, ws.point_list, ws.status, ws.tile_count, ws.tile_cursor, ws.view_total, d.V,
-                       reinterpret_cast<unsigned long long *>(ws.depth));
     // lists longer than one run sit at the front of tile_order and there are fewer than capacity / kSortCap of them
     const uint32_t max_big = (uint32_t)std::min<int64_t>(nt, a.capacity / kSortCap);
-    hipLaunchKernelGGL(surfel_run_merge_kernel, dim3((max_big + max_extra) * kMergeParts), dim3(256), 0, s, ws.tile_order,
-                       ws.run_table, max_extra, ws.keys, ws.point_list, ws.status);
+    hipLaunchKernelGGL(surfel_run_sort_kernel, dim3(max_extra + nbig + (nt + 3) / 4 + (max_big + max_extra) * kMergeParts), dim3(256), 0, s,
+                       ws.tile_order, ws.run_table, max_extra, nbig, nt, ws.keys, ws.point_list, ws.status, ws.tile_count, ws.tile_cursor,
+                       ws.view_total, d.V, ws.seg_sync, reinterpret_cast<unsigned long long *>(ws.depth));
 }
 
 }  // namespace ga
