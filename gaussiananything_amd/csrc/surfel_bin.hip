@@ -50,10 +50,8 @@ struct ScanArgs {
     int64_t *__restrict__ status;
 };
 
-// kOwnLaunch: the scan is a launch of its own in front of the fill (views of more than kLdsTiles tiles): it also sets the fill's
-// cursors to the list begins and clears the tile counters it has consumed.  Otherwise it is ONE WORKGROUP OF THE FILL LAUNCH
-// (surfel_fill_scan_kernel): the fill workgroups read the counters at the same time and work with relative cursors, and counters
-// and cursors are cleared by the per-tile sort.
+// kOwnLaunch (the only instantiation left): the scan is a launch of its own in front of the fill -- problems beyond the sizes
+// surfel_fill_sched_kernel covers: it also sets the fill's cursors to the list begins and clears the tile counters it has consumed.
 template <bool kOwnLaunch>
 __device__ __forceinline__ void tile_scan_body(const ScanArgs &a)
 {
@@ -342,30 +340,193 @@ __global__ __launch_bounds__(256) void surfel_fill_kernel(const uint16_t *__rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// 2 + 3 in ONE launch (views of at most kLdsTiles tiles -- every practical size).  The single-workgroup scan above is 17 us of
-// pure latency in front of a fill that is 17 us of latency itself (round 3: 36 us of the 105 us front-end); neither needs the
-// other's RESULT if every fill workgroup derives the list begins it needs on its own:
-//   begin(v, t) = sum of the entry counts of the views before v  (view_total[], accumulated by the preprocess: 64 V words)
-//               + exclusive scan of view v's OWN tile counters up to t (<= kLdsTiles words, read from L2, scanned in LDS)
-// -- a few microseconds of redundant work per workgroup, all workgroups in parallel.  Slots inside a list are claimed from a
-// RELATIVE cursor (zero between launches).  The schedule of the later kernels (tile_order by length class, run table, segment table,
-// status words, tile_start[] for everybody else) is still one workgroup's scan over all V * tiles counters: row 0 of this grid, running
-// beside the fill instead of in front of it.  Grid (x, 1 + V) x 1024 threads: row 0 = (block 0) the schedule, row 1 + v = fill of view v,
-// kFillSplats consecutive Gaussians per thread.
+// 2 + 3 in ONE launch (the common sizes: views of at most kLdsTiles tiles, fewer than 65536 (view, tile) counters in all).
+// Round 3 ran a single-workgroup scan (17 us of pure latency) in front of a fill that is ~8 us of latency itself; neither needs the
+// other's RESULT if every workgroup derives what it needs on its own:
+//   fill workgroups (grid rows 1 .. V, one view each, kFillSplats consecutive Gaussians per thread):
+//       begin(v, t) = entries of the views before v  (view_total[], accumulated by the preprocess: 64 V words)
+//                   + exclusive scan of view v's OWN tile counters up to t (<= kLdsTiles words from L2, scanned in LDS);
+//       slots inside a list are claimed from a RELATIVE cursor (zero between launches);
+//   schedule workgroups (grid row 0, the first nsched blocks; the others leave): tile_order (longest lists first, by length class) is
+//       a counting sort over ALL V * tiles counters.  Each of them histograms all counters (lane-private LDS bins), which gives it the
+//       class starts AND, for each class, the number of tiles in front of its own slice of ~1024 tiles; it then writes the schedule
+//       entries, tile_start[] and the run-table entries of its slice (positions inside (class, slice) from LDS atomics: the order
+//       inside a class is irrelevant), clears its share of the segment words, and block 0 writes the status words, the segment table and
+//       the launch epoch.
+// First cut of round 4: ONE schedule workgroup (the round-3 scan) beside the fill -- still the launch's critical path
+// (tools/fill_stamps.py: 17.6 us, the fill workgroups were done after 8); the schedule work inside every fill workgroup (no row 0):
+// 89 VGPRs, one 1024-thread workgroup per CU instead of two, 25 us.
 constexpr int kFillSplats = 2;
+constexpr int kSchedPre = 4;                        // (view, tile) counters per thread a schedule workgroup has in flight
 
-__global__ __launch_bounds__(1024) void surfel_fill_scan_kernel(ScanArgs sa, const uint16_t *__restrict__ rect,
-                                                                const float *__restrict__ depth, Dims dm,
-                                                                const unsigned long long *__restrict__ view_total,
-                                                                uint64_t *__restrict__ keys)
+#ifdef GA_FILL_STAMPS   // measurement build: (start, end, row) per workgroup in the segment scratch (unused until the blend), 100 MHz clock
+struct FillStamp {
+    unsigned long long *p, t0;
+    __device__ ~FillStamp() { if (threadIdx.x == 0) { p[0] = t0; p[1] = __builtin_amdgcn_s_memrealtime(); p[2] = 0x5A5A000000000000ull | blockIdx.y; } }
+};
+#endif
+
+__device__ __forceinline__ void schedule_slice(const ScanArgs &sa, int nall, int nsched, uint32_t *__restrict__ big_scratch)
+{
+    __shared__ uint32_t histl[kClasses][64];     // one copy per lane: low half = tiles of class b, high half = those in front of my slice
+    __shared__ uint32_t cls_all[kClasses], cls_before[kClasses], cls_start[kClasses], cls_work[kClasses], slice_cnt[kClasses];
+    __shared__ uint32_t nbig_sh, long_tiles_sh, seg_total_sh, wave_tot[16], wave_maxc[16];
+    __shared__ unsigned long long wave_front[16], wave_sum64[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int Q = (nall + nsched - 1) / nsched, S = (int)blockIdx.x * Q, S1 = min(nall, S + Q);   // my slice of the global tile index
+    // the lists longer than one sort run (index, length), noted by this workgroup for its own use: at most capacity / kSortCap of them
+    // when nothing overflows -- in my share of point_list, which nobody touches before the sort
+    const uint32_t big_cap = (uint32_t)(sa.capacity / kSortCap + 1);
+    uint32_t *big_i = big_scratch + (size_t)blockIdx.x * 2 * big_cap, *big_c = big_i + big_cap;
+    for (int i = tid; i < kClasses * 64; i += 1024) (&histl[0][0])[i] = 0;
+    if (tid < kClasses) slice_cnt[tid] = 0;
+    if (tid == 0) nbig_sh = 0;
+    __syncthreads();
+    // class histogram of ALL lists (and of those in front of my slice), the entries in front of my slice, the lists longer than one
+    // sort run, the longest list.  64 lane-private copies of the 33 bins: the atomics of one instruction never meet (a wave's 64
+    // counters fall into a handful of classes, and LDS atomics of 64 lanes on ~5 addresses are served one lane at a time)
+    uint32_t maxc = 0;
+    unsigned long long front = 0, sum = 0;
+    auto note = [&](int i, uint32_t c) {
+        if (i < nall) {
+            atomicAdd(&histl[length_class(c)][lane], 1u | (i < S ? 0x10000u : 0u));
+            maxc = max(maxc, c);
+            sum += c;
+            if (i < S) front += c;
+            if (c > (uint32_t)kSortCap) {
+                const uint32_t q = atomicAdd(&nbig_sh, 1u);
+                if (q < big_cap) { big_i[q] = (uint32_t)i; big_c[q] = c; }
+            }
+        }
+    };
+    for (int j0 = 0; j0 * 1024 < nall; j0 += kSchedPre) {   // kSchedPre loads in flight
+        uint32_t ca[kSchedPre];
+#pragma unroll
+        for (int j = 0; j < kSchedPre; ++j) {
+            const int i = (j0 + j) * 1024 + tid;
+            ca[j] = i < nall ? sa.tile_count[i] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < kSchedPre; ++j) note((j0 + j) * 1024 + tid, ca[j]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        maxc = max(maxc, (uint32_t)__shfl_down(maxc, o, 64));
+        front += __shfl_down(front, o, 64);
+        sum += __shfl_down(sum, o, 64);
+    }
+    if (lane == 0) { wave_maxc[wid] = maxc; wave_front[wid] = front; wave_sum64[wid] = sum; }
+    __threadfence_block();    // (the noted lists are read by other threads of this workgroup)
+    __syncthreads();
+    for (int b = wid; b < kClasses; b += 16) {   // a wave sums the 64 copies of a class (both halves at once)
+        uint32_t h = histl[b][lane];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) h += __shfl_down(h, o, 64);
+        if (lane == 0) { cls_all[b] = h & 0xFFFFu; cls_before[b] = h >> 16; }
+    }
+    __syncthreads();
+    if (wid == 0) {   // class starts, longest lists first (lane b owns class 32 - b); segment work items of the classes in front
+        const int b = 32 - lane;
+        const uint32_t pop = lane < kClasses ? cls_all[b] : 0u;
+        uint32_t sx = pop;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(sx, o, 64);
+            if (lane >= o) sx += y;
+        }
+        const uint32_t segs = (lane < kClasses && b >= kSegClass) ? pop * (uint32_t)seg_count(b) : 0u;
+        uint32_t wx = segs;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(wx, o, 64);
+            if (lane >= o) wx += y;
+        }
+        if (lane < kClasses) { cls_start[b] = sx - pop; cls_work[b] = wx - segs; }
+        if (b == kSegClass) { long_tiles_sh = sx; seg_total_sh = wx; }
+    }
+    unsigned long long fsum = 0, total = 0;
+    uint32_t mx = 0;
+#pragma unroll 2
+    for (int w = 0; w < 16; ++w) { fsum += wave_front[w]; total += wave_sum64[w]; mx = max(mx, wave_maxc[w]); }
+    __syncthreads();
+    const uint32_t long_tiles = long_tiles_sh, seg_total = seg_total_sh;
+    const bool overflow = total > (unsigned long long)sa.capacity || total > 0xFFFFFFFFull || (int64_t)seg_total > sa.seg_capacity;
+    const uint32_t nbig = min(nbig_sh, big_cap);
+    const uint32_t table_cap = (uint32_t)(sa.capacity / kSortCap + 1);
+    // the schedule entries, list begins and run-table entries of my slice, 1024 tiles per round
+    uint32_t carry = (uint32_t)fsum;
+    for (int g0 = S; g0 < S1; g0 += 1024) {
+        const int gi = g0 + tid;
+        const uint32_t c = gi < S1 ? sa.tile_count[gi] : 0u;
+        uint32_t x = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wave_tot[wid] = x;
+        __syncthreads();
+        uint32_t wbase = 0, round = 0;
+#pragma unroll 4
+        for (int w = 0; w < 16; ++w) { wbase += w < wid ? wave_tot[w] : 0u; round += wave_tot[w]; }
+        if (gi < S1) {
+            const uint32_t beg = carry + wbase + x - c;
+            const int b = length_class(c);
+            const uint32_t pos = cls_start[b] + cls_before[b] + atomicAdd(&slice_cnt[b], 1u);
+            sa.tile_order[pos] = make_uint4((uint32_t)gi, beg, c, 0u);
+            sa.tile_start[gi] = beg;
+            if (c > (uint32_t)kSortCap) {   // runs 1.. of a list longer than one sort run: table slots in the order of the tile index
+                uint32_t dst = 0;
+                for (uint32_t q = 0; q < nbig; ++q)
+                    if (big_i[q] < (uint32_t)gi) dst += (big_c[q] - 1u) / kSortCap;
+                for (uint32_t r = 1; r <= (c - 1u) / kSortCap; ++r, ++dst)
+                    if (dst < table_cap) sa.run_table[dst] = make_uint4(pos, r, beg, c);
+            }
+        }
+        carry += round;
+        __syncthreads();
+    }
+    // the segment words, cleared in slices for the blend of THIS launch (GA_SURFEL_FLAG_WORKSPACE_CLEAN: see surfel_run_sort_kernel)
+    {
+        const uint32_t w0 = (uint32_t)((uint64_t)sa.seg_sync_words * blockIdx.x / nsched), w1 = (uint32_t)((uint64_t)sa.seg_sync_words * (blockIdx.x + 1) / nsched);
+        for (uint32_t i = w0 + (uint32_t)tid; i < w1; i += 1024) sa.seg_sync[i] = 0u;
+    }
+    if (blockIdx.x == 0) {   // the launch's single words
+        if (tid < kClasses) { sa.seg_table[2 * tid] = cls_start[tid]; sa.seg_table[2 * tid + 1] = cls_work[tid]; }
+        if (tid == 0) {
+            uint32_t extra = 0;
+            for (uint32_t q = 0; q < nbig; ++q) extra += (big_c[q] - 1u) / kSortCap;
+            sa.tile_start[nall] = (uint32_t)total;
+            sa.status[GA_STATUS_NUM_RENDERED] = (int64_t)total;
+            sa.status[GA_STATUS_OVERFLOW] = overflow ? 1 : 0;
+            sa.status[GA_STATUS_MAX_TILE] = (int64_t)mx;
+            sa.status[GA_STATUS_EXTRA_RUNS] = (int64_t)min(extra, table_cap);
+            sa.status[GA_STATUS_LONG_TILES] = (int64_t)long_tiles;
+            sa.status[GA_STATUS_SEG_WORK] = (int64_t)seg_total;
+            uint32_t e = sa.seg_table[kSegEpochWord] + 1u;   // a new epoch for this launch's exchange words (never 0)
+            if (e == 0u) e = 1u;
+            sa.seg_table[kSegEpochWord] = e;
+        }
+        if (tid >= 4 && tid < GA_STATUS_WORDS && tid != GA_STATUS_LONG_TILES && tid != GA_STATUS_SEG_WORK) sa.status[tid] = 0;
+    }
+}
+
+__global__ __launch_bounds__(1024) void surfel_fill_sched_kernel(ScanArgs sa, const uint16_t *__restrict__ rect,
+                                                                 const float *__restrict__ depth, Dims dm,
+                                                                 const unsigned long long *__restrict__ view_total,
+                                                                 uint64_t *__restrict__ keys, int nsched, uint32_t *__restrict__ big_scratch,
+                                                                 unsigned long long *__restrict__ dbg)
 {
     extern __shared__ uint32_t lds[];  // [tiles] counts -> ranks, [tiles] list begins -> segment bases of this workgroup
-    __shared__ uint32_t wave_sum[16];
-    __shared__ unsigned long long wave_base[16], wave_all[16];
+#ifdef GA_FILL_STAMPS
+    FillStamp stamp{dbg + 3300000 + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4, __builtin_amdgcn_s_memrealtime()};   // (behind the words the blend's segments use at BASELINE configs[1])
+#endif
     if (blockIdx.y == 0) {
-        if (blockIdx.x == 0) tile_scan_body<false>(sa);
+        if ((int)blockIdx.x < nsched) schedule_slice(sa, dm.V * dm.tiles, nsched, big_scratch);
         return;
     }
+    __shared__ uint32_t wave_sum[16];
+    __shared__ unsigned long long wave_base[16], wave_all[16];
     const int v = (int)blockIdx.y - 1, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int T = dm.tiles;
     uint32_t *cnt = lds, *basep = lds + T;
@@ -418,7 +579,7 @@ __global__ __launch_bounds__(1024) void surfel_fill_scan_kernel(ScanArgs sa, con
         total += wave_all[w];
         wbase += w < wid ? wave_sum[w] : 0u;
     }
-    // the overflow the schedule workgroup reports in the status words (D > capacity): nothing may be written
+    // the overflow the schedule workgroups report in the status words (D > capacity): nothing may be written
     if (total > (unsigned long long)sa.capacity || total > 0xFFFFFFFFull) return;
     {
         uint32_t run = (uint32_t)vbase + wbase + x - loc;
@@ -902,15 +1063,22 @@ void launch_binning(const GaSurfelForwardArgs &a, const Dims &d, const Workspace
     const int nt = d.V * d.tiles;
     const ScanArgs sa{ws.tile_count, ws.seg_sync, (uint32_t)(8 * ((size_t)a.capacity / 1024 + 1)), ws.tile_start, ws.tile_cursor,
                       ws.tile_order, ws.run_table, nt, a.capacity, seg_items(a.capacity, a.seg_capacity), ws.seg_table, ws.status};
-    if (d.tiles <= kLdsTiles) {
-        const unsigned nbx = (unsigned)std::max(1, (d.N + 1024 * kFillSplats - 1) / (1024 * kFillSplats));
-        hipLaunchKernelGGL(surfel_fill_scan_kernel, dim3(nbx, (unsigned)d.V + 1u), dim3(1024), 2 * d.tiles * sizeof(uint32_t), s, sa,
-                           ws.rect, ws.depth, d, ws.view_total, ws.keys);
+    const unsigned nbx = (unsigned)std::max(1, (d.N + 1024 * kFillSplats - 1) / (1024 * kFillSplats));
+    const int nsched = (int)std::min<unsigned>(nbx, (unsigned)((nt + 1023) / 1024));   // ~1024 schedule slots per workgroup of row 0
+    // (16-bit halves in the schedule's class bins; the schedule workgroups' notes of the long lists fit point_list)
+    if (d.tiles <= kLdsTiles && nt <= 0xFFFF && (int64_t)nsched * 2 * (a.capacity / kSortCap + 1) <= a.capacity) {
+        hipLaunchKernelGGL(surfel_fill_sched_kernel, dim3(nbx, (unsigned)d.V + 1u), dim3(1024), 2 * d.tiles * sizeof(uint32_t), s, sa,
+                           ws.rect, ws.depth, d, ws.view_total, ws.keys, nsched, ws.point_list, ws.seg_scratch);
         return;
     }
+    // larger problems: the single-workgroup scan in front of the fill
     hipLaunchKernelGGL(surfel_tile_scan_kernel, dim3(1), dim3(1024), 0, s, sa);
     const dim3 grid((unsigned)((d.N + 256 * kBinSplats - 1) / (256 * kBinSplats)), (unsigned)d.V);
-    hipLaunchKernelGGL(surfel_fill_kernel<false>, grid, dim3(256), 0, s, ws.rect, ws.depth, d, ws.tile_cursor, ws.keys, ws.status);
+    if (d.tiles <= kLdsTiles)
+        hipLaunchKernelGGL(surfel_fill_kernel<true>, grid, dim3(256), 2 * d.tiles * sizeof(uint32_t), s, ws.rect, ws.depth, d, ws.tile_cursor,
+                           ws.keys, ws.status);
+    else
+        hipLaunchKernelGGL(surfel_fill_kernel<false>, grid, dim3(256), 0, s, ws.rect, ws.depth, d, ws.tile_cursor, ws.keys, ws.status);
 }
 
 void launch_tile_sort(const GaSurfelForwardArgs &a, const Dims &d, const Workspace &ws, hipStream_t s)
