@@ -58,12 +58,65 @@ class HipEvents:
         return ms.value
 
 
+def committed_pmc(name):
+    """profiles/<name> (tools/pmc_to_json.py) if the kernel source it was measured on is still the source in the tree, else None:
+    counters cannot be collected inside this run, and a quotation of a stale pass would drift from the code silently."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    pj = json.load(open(path))
+    for rel, want in pj.get("source_sha256", {}).items():
+        src = os.path.join(ROOT, rel)
+        if not os.path.exists(src) or hashlib.sha256(open(src, "rb").read()).hexdigest() != want:
+            return None
+    return pj
+
+
+def host_threads():
+    """ONE convention for every `cores` on the line: the hardware threads this process may run on; every CPU baseline runs with exactly
+    that many worker threads (OpenMP for the rasterizer oracle, intra-op threads for the PyTorch DiT oracle)."""
+    return len(os.sched_getaffinity(0))
+
+
+def stress_scene_line(cams, n, H, W, dev, steps=20):
+    """SURVEY.md 8d's second scene (uniform random surfels: radius median 8 px, D/N = 4.8) beside the headline one: the same forward,
+    untimed section -- wall time of `steps` back-to-back forwards and the stage times from HIP events."""
+    from gaussiananything_amd import synthetic
+    from gaussiananything_amd.diff_surfel_rasterization import SurfelForwardPlan
+    g = synthetic.random_surfels(n, seed=0)[0]
+    m, o, s, r, c = [t.to(dev) for t in synthetic.split_gaussians(g)]
+    plan = SurfelForwardPlan(m, o, c, s, r, cams["cam_view"].to(dev), cams["cam_view_proj"].to(dev), torch.ones(3, device=dev), H, W)
+    plan.run()
+    plan.ensure_capacity()
+    for _ in range(5):
+        plan.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.run()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    ev = [HipEvents(5) for _ in range(10)]
+    for e in ev:
+        plan.set_stage_events(e.arr)
+        plan.run()
+    torch.cuda.synchronize()
+    plan.set_stage_events(None)
+    names = ["preprocess", "tile_scan_fill", "tile_sort", "blend"]
+    st = plan.ws.status().cpu()
+    V = cams["cam_view"].shape[0]
+    return {"scene": "stress (uniform random surfels, SURVEY.md 8d)", "ms_per_step": round(ms, 4), "Msplats_per_s": round(n * V / ms / 1e3, 1),
+            "num_rendered_D": int(st[0]), "longest_tile_list": int(st[2]),
+            "stage_ms": {nm: round(float(np.mean([e.elapsed(i, i + 1) for e in ev])), 5) for i, nm in enumerate(names)}}
+
+
 def cpu_baseline(g, cams, H, W, min_seconds=3.0):
     """CPU oracle on the host cores: whole views of the SAME scene until >= min_seconds of wall time."""
     from gaussiananything_amd import synthetic
     from oracle import surfel as osurf
     m, o, s, r, c = [t.numpy() for t in synthetic.split_gaussians(g)]
-    cores = osurf.lib().oracle_set_threads(0)
+    cores = osurf.lib().oracle_set_threads(host_threads())
     osurf.rasterize(m[:1000], o[:1000], c[:1000], s[:1000], r[:1000], cams["cam_view"][0].numpy(),
                     cams["cam_view_proj"][0].numpy(), np.ones(3, np.float32), 64, 64)  # warm the library
     t0 = time.perf_counter()
@@ -79,7 +132,8 @@ def cpu_baseline(g, cams, H, W, min_seconds=3.0):
     return {"value": round(m.shape[0] * views / dt / 1e6, 4), "unit": "Msplats/s", "cores": int(cores),
             "kind": "port",
             "sample": f"{views} whole 512x512 views of the same 100k-surfel scene, {dt:.1f} s wall; preprocess+binning "
-                      f"single-threaded, blend OpenMP over tiles ({cores} threads); includes numpy buffer setup"}
+                      f"single-threaded, blend OpenMP over tiles ({cores} threads = every hardware thread of the host, the convention "
+                      f"of all CPU baselines on this line); includes numpy buffer setup"}
 
 
 def dit_flops_per_nfe(D, depth, L, M, ctx, batch, ca_batch=None):
@@ -121,9 +175,10 @@ def bench_attention(dev, reps=50):
         fl = 4.0 * B * H * Lq * Lk * 64
         out[name] = {"us": round(us, 2), "tflops": round(fl / (us * 1e-6) / 1e12, 1),
                      "frac_of_bf16_mfma_peak": round(fl / (us * 1e-6) / 1e12 / 2500.0, 4)}
-    out["mfma_busy_from_counters"] = {"self_attention_2x16x768x768": 0.093, "cross_attention_1x16x768x1369": 0.079,
-                                      "source": "committed rocprofv3 PMC pass of exactly these two launches (profiles/r3_attention_pmc.txt: "
-                                                "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs), not measured in this run"}
+    pj = committed_pmc("r4_attention_pmc.json")
+    out["mfma_busy_from_counters"] = ({"kernels": pj["kernels"], "source": pj["source"] + " (committed rocprofv3 PMC pass of exactly these two "
+                                        "launches: SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs; dit_attention.hip unchanged "
+                                        "since), not measured in this run"} if pj else None)
     out["note"] = "launches on torch's current stream, timed with events on that stream"
     return out
 
@@ -211,7 +266,7 @@ def bench_dit(dev, arch, nfe, warmup, parity_mode=False, samples=1):
             from oracle import dit as odit
             sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
             cctx = {k: v.float().cpu() for k, v in ctx.items()}
-            ncpu = min(64, len(os.sched_getaffinity(0)))   # more intra-op threads than that only add contention
+            ncpu = host_threads()
             torch.set_num_threads(ncpu)
             best = float("inf")
             for _ in range(2):                             # the first call pays the oneDNN primitive set-up
@@ -656,17 +711,22 @@ def main():
             P = H * W
             blend_bytes = 76.0 * int(st[0]) + 40.0 * P * v      # per launch (all V views), SURVEY.md 8d
             achieved = blend_bytes / (stage["blend"] * 1e-3) / 1e9
-            traffic, tsrc = None, None  # PMC counters cannot be collected live: taken from the committed rocprofv3 passes
-            pmc_file = os.path.join(ROOT, "profiles", "r3_blend_pmc.json")
-            if a.scene == "surface" and n == 100_000 and v == 8 and H == 512 and os.path.exists(pmc_file):
-                pj = json.load(open(pmc_file))
-                traffic, tsrc = pj["traffic_bytes_per_launch"], f"committed PMC ({pj['source']}, HEAD {pj.get('head')}), not measured in this run"
-            out["roofline"] = {"bound": "hbm", "kernel": "surfel_blend_kernel", "achieved": round(achieved, 2),
+            traffic, tsrc, valu_frac, valu_insts = None, None, None, None  # PMC counters cannot be collected live: committed rocprofv3 passes
+            pj = committed_pmc("r4_blend_pmc.json") if (a.scene == "surface" and n == 100_000 and v == 8 and H == 512) else None
+            if pj:
+                traffic, valu_frac, valu_insts = pj["traffic_bytes_per_launch"], pj["valu_issue_frac"], pj["SQ_INSTS_VALU"]
+                tsrc = f"committed PMC ({pj['source']}; surfel_blend.hip unchanged since), not measured in this run"
+            # `achieved` / `peak` / `frac` are the HBM pair the contract asks for (algorithmic bytes over the launch duration); what BINDS
+            # the kernel is VALU issue -- `valu_issue_frac` says how much of that roof is in use
+            out["roofline"] = {"bound": "valu", "kernel": "surfel_blend_kernel", "achieved": round(achieved, 2),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                               "valu_issue_frac": valu_frac, "valu_wave_instructions_per_launch": valu_insts,
+                               "valu_issue_frac_is": "SQ_INSTS_VALU x 4 cycles / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs (committed PMC pass)",
                                "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": int(blend_bytes),
                                "avg_launch_ms": round(stage["blend"], 5),
                                "launch_duration_source": "HIP events on the launch stream, separate untimed pass of the same forwards",
-                               "note": "blend is VALU/LDS-bound, not HBM-bound (SURVEY.md 8d): see blend_valu"}
+                               "note": "achieved / peak: algorithmic HBM bytes of the blend against the HBM roof (SURVEY.md 8d); the binding roof is "
+                                       "VALU issue (bound), see valu_issue_frac and blend_valu"}
             # What the blend actually executes (one untimed forward with the statistics flag): (pixel, splat) pairs that
             # survive the cull boxes, the wave-level evaluation slots they were packed into, and the ~60 flop / pair of
             # SURVEY.md 8d -- the bound that matters for this kernel is VALU issue, not HBM.
@@ -682,11 +742,14 @@ def main():
                                  "lane_slot_utilisation": round(pairs / max(slots, 1.0), 4),
                                  "tflops_at_60flop_per_evaluated_pair": round(pairs * 60 / (stage["blend"] * 1e-3) / 1e12, 3),
                                  "peak_fp32_valu_tflops": FP32_VALU_PEAK_TFLOPS,
-                                 "note": "54.0 M wave-level VALU instructions per launch, LDS 22.5 M active cycles (profiles/r3_blend_pmc.txt); "
-                                         "lanes = pixels of an 8x8 quadrant cannot exceed 0.53 lane use on this scene (tools/blend_sim.py)"}
+                                 "note": "lanes = pixels of an 8x8 quadrant cannot exceed 0.53 lane use on this scene (tools/blend_sim.py); the "
+                                         "split walk (lanes = pairs, then lanes = pixels) was built and measured in round 4: 175 us against "
+                                         "140 us (DESIGN.md section 3, GA_SURFEL_FLAG_SPLIT_WALK)"}
             del splan
             out["stage_ms"] = {k: round(x, 5) for k, x in stage.items()}
             out["stage_ms"]["device_total"] = round(total_dev, 5)
+            if a.scene == "surface" and not a.no_extras:
+                out["stress_scene"] = stress_scene_line(cams, a.points, H, W, dev)
         if not a.no_parity:
             out["parity"] = parity_check(g, cams, H, W, dev)
         if world == 1 and not a.no_cpu_baseline:
