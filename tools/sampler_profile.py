@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Runs an N-step Euler sampler of one DiT arch (for rocprofv3 --kernel-trace): prints wall time per step."""
+"""Runs an N-step Euler sampler (or, 4th argument "dopri5", the adaptive default sampler) of one DiT arch (for rocprofv3 --kernel-trace):
+prints wall time per step / per function evaluation."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,7 +24,8 @@ ctx = {"img_crossattn": torch.randn(B, M, 1024, generator=g).to(dev), "img_vecto
 ctx["img_crossattn"][1] = 0   # the unconditional half of a CFG batch (sgm force_uc_zero_embeddings)
 ctx["img_vector"][1] = 0
 sampler = Sampler(create_transport("GVP", "velocity", None, None, None, snr_type="uniform"))
-fn = sampler.sample_ode(sampling_method="euler", num_steps=steps)
+method = sys.argv[3] if len(sys.argv) > 3 else "euler"
+fn = sampler.sample_ode(sampling_method=method, num_steps=steps)
 with torch.no_grad():
     fn(x, model.forward_with_cfg, context=ctx, cfg_scale=4.0)
     torch.cuda.synchronize()
@@ -31,4 +33,8 @@ with torch.no_grad():
     fn(x, model.forward_with_cfg, context=ctx, cfg_scale=4.0)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-print(f"{arch}: {steps} grid points, {dt / (steps - 1) * 1e3:.3f} ms per step wall")
+st = sampler.last_ode.last_stats
+if method == "euler":
+    print(f"{arch}: {steps} grid points, {dt / (steps - 1) * 1e3:.3f} ms per step wall")
+else:
+    print(f"{arch}: {method}, {steps} output times, {st} -> {dt / st['nfe'] * 1e3:.3f} ms per function evaluation wall ({dt:.4f} s)")

@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=${1:-trs}
 mkdir -p $R/gpurun_out/$tag
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$tag -o x -- python $R/tools/sampler_profile.py ${2:-DiT-PixArt-PCD-CLAY-L} ${3:-30} > $R/gpurun_out/$tag/out.txt 2>$R/gpurun_out/$tag/err.txt
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$tag -o x -- python $R/tools/sampler_profile.py ${2:-DiT-PixArt-PCD-CLAY-L} ${3:-30} ${4:-euler} > $R/gpurun_out/$tag/out.txt 2>$R/gpurun_out/$tag/err.txt
 cat $R/gpurun_out/$tag/out.txt
 python $R/tools/rocpd_stats.py $(ls $R/gpurun_out/$tag/*.db | head -1) | python -c "
 import sys
