@@ -31,6 +31,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # the CPU baselines' idle OpenMP workers sleep instead of spinning beside the launch threads
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -74,9 +76,11 @@ def committed_pmc(name):
 
 
 def host_threads():
-    """ONE convention for every `cores` on the line: the hardware threads this process may run on; every CPU baseline runs with exactly
-    that many worker threads (OpenMP for the rasterizer oracle, intra-op threads for the PyTorch DiT oracle)."""
-    return len(os.sched_getaffinity(0))
+    """ONE convention for every `cores` on the line: min(64, hardware threads this process may run on), and every CPU baseline runs with
+    exactly that many worker threads (OpenMP for the rasterizer oracle, intra-op threads for the PyTorch DiT oracle).  More only add
+    contention on the driver's 256-thread host: measured with all 256, the DiT oracle took 117 s per evaluation (64: ~6 s) and the
+    rasterizer oracle 0.45 Msplats/s (less than with 64) -- and the spinning OpenMP pool slowed the launch-bound GPU sections after it."""
+    return min(64, len(os.sched_getaffinity(0)))
 
 
 def stress_scene_line(cams, n, H, W, dev, steps=20):
@@ -132,7 +136,7 @@ def cpu_baseline(g, cams, H, W, min_seconds=3.0):
     return {"value": round(m.shape[0] * views / dt / 1e6, 4), "unit": "Msplats/s", "cores": int(cores),
             "kind": "port",
             "sample": f"{views} whole 512x512 views of the same 100k-surfel scene, {dt:.1f} s wall; preprocess+binning "
-                      f"single-threaded, blend OpenMP over tiles ({cores} threads = every hardware thread of the host, the convention "
+                      f"single-threaded, blend OpenMP over tiles ({cores} threads = min(64, hardware threads), the convention "
                       f"of all CPU baselines on this line); includes numpy buffer setup"}
 
 
@@ -338,7 +342,8 @@ def bench_cascade(dev, cams, rank, world, dist, dopri5=True):
         return gd.cascade_per_rank(m1, m2, dec, cond_fn, c, world, base_seed=42, num_steps=steps, sampling_method=method,
                                    render_all_scale=True, **({"stats": stats} if stats is not None else {}))
 
-    run("euler", 5)   # warm-up: lazy initialisation, workspaces, graph capture paths
+    run("euler", 250)   # warm-up SAMPLE: lazy initialisation, workspaces, and the capture of the two sampler steps -- the timed sample
+                        # below (new conditioning tensors, same shapes) replays them, as every later sample of a serving loop does
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -350,12 +355,17 @@ def bench_cascade(dev, cams, rank, world, dist, dopri5=True):
         dist.barrier()
     sec = gd.max_over_ranks(time.perf_counter() - t0, dev)
     out = {"sec_per_sample": round(sec, 4), "samples": world, "samples_per_sec": round(world / sec, 4),
-           "mode": "euler, 250 grid points = 249 function evaluations per stage",
+           "mode": "euler, 250 grid points = 249 function evaluations per stage; one untimed warm-up sample first (it captures the sampler "
+                   "steps the timed sample replays on its own conditioning)",
            "stages": "DiT-L x 249 NFE, stage-2 DiT-L x 249 NFE (cond_key img-xyz: uc == c), decode -> 73728 surfels, renders 8 views x "
                      "{128,256,384,512}^2, gather of [8,9,512,512] fp32 per rank to rank 0",
            "gathered_shape": list(gathered.shape) if gathered is not None else None}
     if dopri5 and world == 1:
         stats = {}
+        try:
+            run("dopri5", 250)     # warm-up sample (captures the attempted step of both stages)
+        except (FloatingPointError, RuntimeError):
+            pass
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         try:

@@ -236,8 +236,13 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         B, M, C = ctx_tokens.shape
         ctx = ctx_tokens.detach().to(torch.bfloat16).contiguous()
         Mp = (M + 63) // 64 * 64
-        ck = torch.empty((self.depth, B * M, self.embed_dim), dtype=torch.bfloat16, device=ctx.device)
-        cvt = torch.zeros((self.depth, B * self.embed_dim, Mp), dtype=torch.bfloat16, device=ctx.device)
+        old = self._ctx_cache[1] if self._ctx_cache is not None else None
+        if old is not None and old[0].shape == (self.depth, B * M, self.embed_dim) and old[0].device == ctx.device:
+            ck, cvt = old[0], old[1]   # same shapes: projected in place (the pad columns of cvt stay zero), so a captured sampler step
+                                       # that has these addresses baked in serves the next sample's conditioning as well
+        else:
+            ck = torch.empty((self.depth, B * M, self.embed_dim), dtype=torch.bfloat16, device=ctx.device)
+            cvt = torch.zeros((self.depth, B * self.embed_dim, Mp), dtype=torch.bfloat16, device=ctx.device)
         stream = ctypes.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream)
         ops.check(ops.lib().ga_dit_cache_context(ctypes.byref(pack["model"]), B, M, ctx.data_ptr(), ck.data_ptr(),
                                                  cvt.data_ptr(), stream), "ga_dit_cache_context")
@@ -295,6 +300,40 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         guidance is a no-op (unconditional conditioning == conditional one, the release's stage 2; cascade.sample)."""
         return self.forward(x, t, context)
 
+    def _resident_context(self, context):
+        """The conditioning of a sampling call copied into buffers the model owns (one set per shape): every evaluation of the call --
+        and the captured sampler step, which has their addresses baked in -- reads these, so the step captured for one sample is
+        replayed for the next one (capturing ~1 750 launches costs ~10 ms per call)."""
+        held = getattr(self, "_ctx_bufs", None) or {}
+        out = {}
+        for name, t in context.items():
+            want = torch.float32 if name in ("img_vector", "fps-xyz") else t.dtype
+            buf = held.get(name)
+            if buf is None or buf.shape != t.shape or buf.dtype != want or buf.device != t.device:
+                buf = torch.empty(t.shape, dtype=want, device=t.device)
+            buf.copy_(t.detach())
+            out[name] = buf
+        self._ctx_bufs = out
+        return out
+
+    def _replay_signature(self, context, shape, n, cfg, cfg_scale):
+        """What a captured sampler step has baked in besides its own buffers: the model's workspace, the K / V projections of the
+        conditioning tokens (refreshed here, in place when the shapes are those of the previous call), the number of batch items
+        that skip the cross-attention, the resident conditioning vectors -- all by address.  None: nothing to replay against yet."""
+        B, L, _ = shape
+        tok = context["img_crossattn"]
+        pack = self._prepare(tok.device)
+        ck, cvt, ca_batch = self._context_kv(pack, tok)
+        if pack.get("ws") is None or pack["ws_key"] != (B, L, tok.shape[1]):
+            return None
+        sig = [tuple(shape), n, bool(cfg), float(cfg_scale), pack["ws"].data_ptr(), ck.data_ptr(), cvt.data_ptr(), ca_batch]
+        for name in ("img_vector",) + (("fps-xyz",) if self._stage2 else ()):
+            t = context[name]
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                return None   # (forward() would hand the kernels a temporary copy)
+            sig.append((t.data_ptr(), tuple(t.shape)))
+        return tuple(sig)
+
     @torch.no_grad()
     def sample_euler_fused(self, y0, t_grid, context, cfg_scale=1.0, cfg=True):
         """The reference's fixed-grid Euler sampling loop (transport/integrators.py:100-119 with method "euler":
@@ -306,6 +345,18 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         dev = y0.device
         tt = [float(v) for v in t_grid]
         n = len(tt)
+        context = self._resident_context(context)
+        sig = self._replay_signature(context, y0.shape, n, cfg, cfg_scale) if n >= 2 else None
+        held = getattr(self, "_euler_replay", None)
+        if sig is not None and held is not None and held[0] == sig:     # the step captured by an earlier call, on its buffers
+            _, y, out, t_arr, dt_arr, counter, tvec, dt, step, graph, keep = held
+            out[0].copy_(y0.detach().float())
+            t_arr.copy_(torch.tensor(tt[:-1], dtype=torch.float32))
+            dt_arr.copy_(torch.tensor([b - a for a, b in zip(tt[:-1], tt[1:])], dtype=torch.float32))
+            y.copy_(out[0]); counter.zero_(); tvec.fill_(tt[0]); dt.copy_(dt_arr[0:1])
+            for _ in range(n - 1):
+                graph.replay()
+            return out.clone()
         y = y0.detach().float().contiguous().clone()
         out = torch.empty((n,) + tuple(y.shape), dtype=torch.float32, device=dev)
         out[0].copy_(y)
@@ -347,8 +398,10 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         reset()   # (capture does not execute; the state is as before)
         for _ in range(n - 1):
             graph.replay()
-        self._fused_keep = (y, t_arr, dt_arr, counter, tvec, dt, step, graph)   # alive until the replays have run
-        return out
+        # kept for the replays in flight -- and for later calls on the same conditioning tensors (see _replay_signature)
+        sig = self._replay_signature(context, y.shape, n, cfg, cfg_scale)
+        self._euler_replay = (sig, y, out, t_arr, dt_arr, counter, tvec, dt, step, graph, tuple(context.values()))
+        return out.clone() if sig is not None else out
 
 
     @torch.no_grad()
@@ -364,15 +417,25 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         dev = y0.device
         tt = [float(v) for v in t_grid]
         ng = len(tt)
-        y = y0.detach().float().contiguous().clone()
-        out = torch.empty((ng,) + tuple(y.shape), dtype=torch.float32, device=dev)
-        out[0].copy_(y)
-        B, n = y.shape[0], y.numel()
         Lib = ops.lib()
-        k = [torch.empty_like(y) for _ in range(7)]
-        ystage, tvec = torch.empty_like(y), torch.empty(B, dtype=torch.float32, device=dev)
-        ctl = torch.zeros(ops.GA_ODE_CTL_WORDS, dtype=torch.float64, device=dev)
-        tg = torch.tensor(tt, dtype=torch.float64, device=dev)
+        B, n = y0.shape[0], y0.numel()
+        context = self._resident_context(context)
+        sig = self._replay_signature(context, y0.shape, ng, cfg, cfg_scale)
+        held = getattr(self, "_dopri5_replay", None)
+        if sig is not None and held is not None and held["sig"] == sig:     # buffers and captured step of an earlier call
+            st = held
+        else:
+            y = torch.empty(tuple(y0.shape), dtype=torch.float32, device=dev)
+            st = {"sig": None, "y": y, "out": torch.empty((ng,) + tuple(y.shape), dtype=torch.float32, device=dev),
+                  "k": [torch.empty_like(y) for _ in range(7)], "ystage": torch.empty_like(y),
+                  "tvec": torch.empty(B, dtype=torch.float32, device=dev),
+                  "ctl": torch.zeros(ops.GA_ODE_CTL_WORDS, dtype=torch.float64, device=dev),
+                  "tg": torch.empty(ng, dtype=torch.float64, device=dev), "graph": None,
+                  "host": torch.empty(ops.GA_ODE_CTL_WORDS, dtype=torch.float64).pin_memory(), "keep": tuple(context.values())}
+        y, out, k, ystage, tvec, ctl, tg, host = (st[q] for q in ("y", "out", "k", "ystage", "tvec", "ctl", "tg", "host"))
+        y.copy_(y0.detach().float())
+        out[0].copy_(y)
+        tg.copy_(torch.tensor(tt, dtype=torch.float64))
         nfe = [0]
 
         def velocity_into(dst, x, tv):
@@ -390,24 +453,29 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         head = torch.zeros(ops.GA_ODE_CTL_WORDS, dtype=torch.float64)
         head[ops.GA_ODE_T], head[ops.GA_ODE_DT], head[ops.GA_ODE_ATOL], head[ops.GA_ODE_RTOL], head[ops.GA_ODE_JNEXT] = tt[0], dt0, atol, rtol, 1
         ctl.copy_(head)
-        ode = ops.GaOdeDopri5(n, B, ng, y.data_ptr(), (ops.c_p * 7)(*[t.data_ptr() for t in k]), ystage.data_ptr(), tvec.data_ptr(),
-                              ctl.data_ptr(), tg.data_ptr(), out.data_ptr())
-
-        def attempt():
-            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            for i in range(6):
-                ops.check(Lib.ga_ode_dopri5_stage(ctypes.byref(ode), i, stream), "ga_ode_dopri5_stage")
-                velocity_into(k[i + 1], ystage, tvec)
-            ops.check(Lib.ga_ode_dopri5_finish(ctypes.byref(ode), stream), "ga_ode_dopri5_finish")
-
-        host = torch.empty(ops.GA_ODE_CTL_WORDS, dtype=torch.float64).pin_memory()
-        done_evt = torch.cuda.Event()
         evals_before = nfe[0]
         if ng > 1:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):     # (capture executes nothing; the evaluations above were the warm-up)
-                attempt()
-            nfe[0] = evals_before
+            if st["graph"] is None:
+                ode = ops.GaOdeDopri5(n, B, ng, y.data_ptr(), (ops.c_p * 7)(*[t.data_ptr() for t in k]), ystage.data_ptr(), tvec.data_ptr(),
+                                      ctl.data_ptr(), tg.data_ptr(), out.data_ptr())
+
+                def attempt():
+                    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                    for i in range(6):
+                        ops.check(Lib.ga_ode_dopri5_stage(ctypes.byref(ode), i, stream), "ga_ode_dopri5_stage")
+                        velocity_into(k[i + 1], ystage, tvec)
+                    ops.check(Lib.ga_ode_dopri5_finish(ctypes.byref(ode), stream), "ga_ode_dopri5_finish")
+
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):     # (capture executes nothing; the evaluations above were the warm-up)
+                    attempt()
+                st["graph"], st["ode"] = graph, ode
+                nfe[0] = evals_before
+                # (the signature exists once the first evaluations have sized the workspace and cached the K / V)
+                st["sig"] = self._replay_signature(context, y.shape, ng, cfg, cfg_scale)
+                self._dopri5_replay = st
+            graph = st["graph"]
+            done_evt = torch.cuda.Event()
             while True:
                 graph.replay()
                 host.copy_(ctl, non_blocking=True)
@@ -415,7 +483,6 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
                 done_evt.synchronize()
                 if host[ops.GA_ODE_DONE] != 0 or host[ops.GA_ODE_STEPS] >= max_steps:
                     break
-            self._dopri5_keep = (graph, y, k, ystage, tvec, ctl, tg, ode)
             err, steps = int(host[ops.GA_ODE_ERROR]), int(host[ops.GA_ODE_STEPS])
             if err == 1:
                 raise FloatingPointError(f"dopri5: non-finite error ratio at t = {float(host[ops.GA_ODE_T])}: the model returned NaN/inf")
@@ -427,7 +494,7 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
                 stats.update(nfe=evals_before + 6 * steps, steps=steps, rejected=int(host[ops.GA_ODE_REJECTED]), graph=True, device_loop=True)
         elif stats is not None:
             stats.update(nfe=evals_before, steps=0, rejected=0, graph=True, device_loop=True)
-        return out
+        return out.clone()
 
 
 class DiT_I23D_PCD_PixelArt_noclip_clay_stage2(DiT_I23D_PCD_PixelArt_noclip):

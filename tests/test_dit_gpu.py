@@ -462,6 +462,16 @@ def test_device_resident_dopri5_takes_the_decisions_of_the_host_loop(gpu_device,
         assert a.shape == b.shape == (n_out,) + tuple(x.shape)
         assert rel_l2(b, a) < 2e-3, rel_l2(b, a)      # (bf16 function: an ulp of the fp32 state can round an operand the other way)
         assert torch.equal(b[0], x.float())
+        # a second call on the same conditioning tensors replays the step captured by the first (no new capture), on another start
+        # state; the first result is not overwritten
+        held = model._dopri5_replay["graph"]
+        keep = b.clone()
+        fn = sampler.sample_ode(sampling_method="dopri5", num_steps=n_out, atol=1e-6, rtol=1e-3)
+        with torch.no_grad():
+            again = fn(x, fwd, context=ctx, cfg_scale=z["cfg_scale"])
+            other = fn(0.5 * x, fwd, context=ctx, cfg_scale=z["cfg_scale"])
+        assert model._dopri5_replay["graph"] is held and torch.equal(again, keep) and torch.equal(b, keep)
+        assert not torch.equal(other[-1], keep[-1]) and torch.equal(other[0], 0.5 * x.float())
 
 
 def test_cpu_tensors_raise(gpu_device):
@@ -488,6 +498,11 @@ def test_sampler_graph_replay_equals_eager_loop(gpu_device, method, monkeypatch)
     if method == "euler":
         assert torch.equal(outs["0"], outs["1"])
         assert sampler.last_ode.last_stats.get("fused")      # the on-device step (GaDitSamplerStep) was the one replayed
+        held = model._euler_replay[9]                        # a second call on the same conditioning replays the captured step
+        with torch.no_grad():
+            again = fn(x, model.forward_with_cfg, context=ctx, cfg_scale=z["cfg_scale"])
+            other = fn(2.0 * x, model.forward_with_cfg, context=ctx, cfg_scale=z["cfg_scale"])
+        assert model._euler_replay[9] is held and torch.equal(again, outs["1"]) and not torch.equal(other[-1], again[-1])
     else:
         assert rel_l2(outs["1"], outs["0"]) < 1e-5
 
