@@ -263,14 +263,17 @@ __device__ __forceinline__ void duty_prologue(Ring &ring, Duty &d, int lane, int
     const ChunkRegs ga = load_chunk(d.rec4, ida);
     ChunkRegs gb = ga;
     if (k1 < nch) gb = load_chunk(d.rec4, idb);
-    d.next = k1 + 4;
+    // my second chunk is staged here only if its slot is not one of the first round's (a ring of fewer than eight chunks): otherwise it
+    // becomes my first duty of the walk, its records already on their way
+    const bool second = k1 < nch && k1 < (uint32_t)kItemChunks;
+    d.next = second ? k1 + 4 : k1;
     if (d.next < nch) {   // wrapping list: ids of my next two duties
-        d.id1 = d.point_list[duty_entry(d, d.next, lane)];
+        d.id1 = second ? d.point_list[duty_entry(d, d.next, lane)] : idb;
         d.id2 = d.point_list[duty_entry(d, d.next + 4 < nch ? d.next + 4 : d.next, lane)];
     }
     stage_chunk(ring, lane, k0, ga, d.sbeg + k0 * 64 + lane < d.send, d.tx0, d.ty0);
-    if (k1 < nch) stage_chunk(ring, lane, k1, gb, d.sbeg + k1 * 64 + lane < d.send, d.tx0, d.ty0);
-    if (d.next < nch) d.g = load_chunk(d.rec4, d.id1);
+    if (second) stage_chunk(ring, lane, k1, gb, d.sbeg + k1 * 64 + lane < d.send, d.tx0, d.ty0);
+    if (d.next < nch) d.g = second ? load_chunk(d.rec4, d.id1) : gb;
 }
 
 // stage chunk d.next (its slot held chunk d.next - kItemChunks: every wave must have finished that one) and move the
@@ -634,10 +637,10 @@ __device__ __forceinline__ void blend_item(Ring &ring, const BlendArgs &k, const
 #define GA_SPLIT_A 3
 #endif
 #ifndef GA_SPLIT_B
-#define GA_SPLIT_B 7
+#define GA_SPLIT_B (GA_ITEM_CHUNKS >= 8 ? 7 : 6)
 #endif
 #ifndef GA_SPLIT_ROWS
-#define GA_SPLIT_ROWS 8
+#define GA_SPLIT_ROWS (GA_ITEM_CHUNKS >= 8 ? 8 : 4)
 #endif
 #ifndef GA_SPLIT_AU
 #define GA_SPLIT_AU 1       // pair instructions per trip of phase A
@@ -681,6 +684,7 @@ struct __attribute__((aligned(16))) Ring2 {
 #endif
 // (measured: three workgroups of 53 808 bytes do NOT fit a CU -- the launch then runs two per CU -- three of 52 272 do)
 static_assert(GA_SPLIT_WGS_PER_CU != 3 || sizeof(Ring2) <= 52272, "three workgroups per CU");
+static_assert(GA_ITEM_CHUNKS >= 8 || sizeof(Ring2) <= 39 * 1024, "four workgroups per CU");
 static_assert(GA_SPLIT_WGS_PER_CU * (sizeof(Ring2) + 64) <= 160 * 1024, "workgroups per CU");
 
 template <int CTRL, int ROWS = 0xf>

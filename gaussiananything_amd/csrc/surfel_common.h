@@ -39,13 +39,17 @@ constexpr int kLdsTiles = 8192;         // per-view tile counters aggregated in 
 // Segmented blend: lists of >= kLongList entries (length class >= kSegClass; class b holds 2^(b-1) <= n < 2^b) are cut into
 // seg_count(b) segments of 256..512 entries, each blended by its own workgroup; a segment (<= kItemChunks chunks of 64)
 // stays resident in LDS for both of its passes, a shorter unsegmented list streams through the same LDS as a ring.
-constexpr int kItemChunks = 8;
+#ifndef GA_ITEM_CHUNKS
+#define GA_ITEM_CHUNKS 8
+#endif
+constexpr int kItemChunks = GA_ITEM_CHUNKS;   // 8: three blend workgroups per CU (47 KB of LDS each); 6: four (35 KB) -- segments then hold <= 384 entries
 #ifndef GA_SEG_CLASS
 #define GA_SEG_CLASS 12
 #endif
 constexpr int kSegClass = GA_SEG_CLASS;
 constexpr int kLongList = 1 << (GA_SEG_CLASS - 1);
-__host__ __device__ constexpr uint32_t seg_count(int b) { return b < kSegClass ? 1u : (1u << (b - 9)); }
+// class b holds 2^(b-1) <= n < 2^b entries: 2^(b-9) segments of 256 .. 512 entries (8 chunks), or 3 * 2^(b-10) of 171 .. 341 (6 chunks)
+__host__ __device__ constexpr uint32_t seg_count(int b) { return b < kSegClass ? 1u : (kItemChunks >= 8 ? (1u << (b - 9)) : (3u << (b - 10))); }
 // launch epoch of the cross-workgroup exchange words: a DEVICE word (seg_table[kSegEpochWord], behind the 2 x 40 table entries) that
 // the tile scan bumps once per launch and the per-launch memset does not touch -- a host-side counter passed as a kernel
 // argument is frozen under HIP-graph replay, and words of the previous replay would validate
@@ -53,7 +57,7 @@ __host__ __device__ constexpr uint32_t seg_count(int b) { return b < kSegClass ?
 // capacity / 256 (every entry in a list of 2048 or more) plus a floor; the tile scan reports more as an overflow
 __host__ __device__ constexpr int64_t seg_items(int64_t capacity, int64_t seg_capacity)
 {
-    return seg_capacity > 0 ? seg_capacity : capacity / 2048 + 128;
+    return seg_capacity > 0 ? seg_capacity : (kItemChunks >= 8 ? capacity / 2048 : capacity / 1365) + 128;
 }
 constexpr int kSegEpochWord = 96;
 constexpr int kSegTableWords = 128;
