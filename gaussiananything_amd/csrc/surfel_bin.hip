@@ -356,8 +356,12 @@ __global__ __launch_bounds__(256) void surfel_fill_kernel(const uint16_t *__rest
 // First cut of round 4: ONE schedule workgroup (the round-3 scan) beside the fill -- still the launch's critical path
 // (tools/fill_stamps.py: 17.6 us, the fill workgroups were done after 8); the schedule work inside every fill workgroup (no row 0):
 // 89 VGPRs, one 1024-thread workgroup per CU instead of two, 25 us.
-constexpr int kFillSplats = 2;
-constexpr int kSchedPre = 4;                        // (view, tile) counters per thread a schedule workgroup has in flight
+#ifndef GA_FILL_THREADS
+#define GA_FILL_THREADS 512
+#endif
+constexpr int kFT = GA_FILL_THREADS, kFW = kFT / 64;    // threads / waves of a workgroup of the fill launch
+constexpr int kFillSplats = 2048 / kFT;                 // 2048 Gaussians per fill workgroup
+constexpr int kSchedPre = 16;                       // (view, tile) counters per thread a schedule workgroup has in flight (8 views of 512 x 512 at 512 threads: all)
 
 #ifdef GA_FILL_STAMPS   // measurement build: (start, end, row) per workgroup in the segment scratch (unused until the blend), 100 MHz clock
 struct FillStamp {
@@ -370,15 +374,15 @@ __device__ __forceinline__ void schedule_slice(const ScanArgs &sa, int nall, int
 {
     __shared__ uint32_t histl[kClasses][64];     // one copy per lane: low half = tiles of class b, high half = those in front of my slice
     __shared__ uint32_t cls_all[kClasses], cls_before[kClasses], cls_start[kClasses], cls_work[kClasses], slice_cnt[kClasses];
-    __shared__ uint32_t nbig_sh, long_tiles_sh, seg_total_sh, wave_tot[16], wave_maxc[16];
-    __shared__ unsigned long long wave_front[16], wave_sum64[16];
+    __shared__ uint32_t nbig_sh, long_tiles_sh, seg_total_sh, wave_tot[kFW], wave_maxc[kFW];
+    __shared__ unsigned long long wave_front[kFW], wave_sum64[kFW];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int Q = (nall + nsched - 1) / nsched, S = (int)blockIdx.x * Q, S1 = min(nall, S + Q);   // my slice of the global tile index
     // the lists longer than one sort run (index, length), noted by this workgroup for its own use: at most capacity / kSortCap of them
     // when nothing overflows -- in my share of point_list, which nobody touches before the sort
     const uint32_t big_cap = (uint32_t)(sa.capacity / kSortCap + 1);
     uint32_t *big_i = big_scratch + (size_t)blockIdx.x * 2 * big_cap, *big_c = big_i + big_cap;
-    for (int i = tid; i < kClasses * 64; i += 1024) (&histl[0][0])[i] = 0;
+    for (int i = tid; i < kClasses * 64; i += kFT) (&histl[0][0])[i] = 0;
     if (tid < kClasses) slice_cnt[tid] = 0;
     if (tid == 0) nbig_sh = 0;
     __syncthreads();
@@ -399,15 +403,15 @@ __device__ __forceinline__ void schedule_slice(const ScanArgs &sa, int nall, int
             }
         }
     };
-    for (int j0 = 0; j0 * 1024 < nall; j0 += kSchedPre) {   // kSchedPre loads in flight
+    for (int j0 = 0; j0 * kFT < nall; j0 += kSchedPre) {   // kSchedPre loads in flight
         uint32_t ca[kSchedPre];
 #pragma unroll
         for (int j = 0; j < kSchedPre; ++j) {
-            const int i = (j0 + j) * 1024 + tid;
+            const int i = (j0 + j) * kFT + tid;
             ca[j] = i < nall ? sa.tile_count[i] : 0u;
         }
 #pragma unroll
-        for (int j = 0; j < kSchedPre; ++j) note((j0 + j) * 1024 + tid, ca[j]);
+        for (int j = 0; j < kSchedPre; ++j) note((j0 + j) * kFT + tid, ca[j]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -418,7 +422,7 @@ __device__ __forceinline__ void schedule_slice(const ScanArgs &sa, int nall, int
     if (lane == 0) { wave_maxc[wid] = maxc; wave_front[wid] = front; wave_sum64[wid] = sum; }
     __threadfence_block();    // (the noted lists are read by other threads of this workgroup)
     __syncthreads();
-    for (int b = wid; b < kClasses; b += 16) {   // a wave sums the 64 copies of a class (both halves at once)
+    for (int b = wid; b < kClasses; b += kFW) {   // a wave sums the 64 copies of a class (both halves at once)
         uint32_t h = histl[b][lane];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) h += __shfl_down(h, o, 64);
@@ -447,15 +451,15 @@ __device__ __forceinline__ void schedule_slice(const ScanArgs &sa, int nall, int
     unsigned long long fsum = 0, total = 0;
     uint32_t mx = 0;
 #pragma unroll 2
-    for (int w = 0; w < 16; ++w) { fsum += wave_front[w]; total += wave_sum64[w]; mx = max(mx, wave_maxc[w]); }
+    for (int w = 0; w < kFW; ++w) { fsum += wave_front[w]; total += wave_sum64[w]; mx = max(mx, wave_maxc[w]); }
     __syncthreads();
     const uint32_t long_tiles = long_tiles_sh, seg_total = seg_total_sh;
     const bool overflow = total > (unsigned long long)sa.capacity || total > 0xFFFFFFFFull || (int64_t)seg_total > sa.seg_capacity;
     const uint32_t nbig = min(nbig_sh, big_cap);
     const uint32_t table_cap = (uint32_t)(sa.capacity / kSortCap + 1);
-    // the schedule entries, list begins and run-table entries of my slice, 1024 tiles per round
+    // the schedule entries, list begins and run-table entries of my slice, kFT tiles per round
     uint32_t carry = (uint32_t)fsum;
-    for (int g0 = S; g0 < S1; g0 += 1024) {
+    for (int g0 = S; g0 < S1; g0 += kFT) {
         const int gi = g0 + tid;
         const uint32_t c = gi < S1 ? sa.tile_count[gi] : 0u;
         uint32_t x = c;
@@ -468,7 +472,7 @@ __device__ __forceinline__ void schedule_slice(const ScanArgs &sa, int nall, int
         __syncthreads();
         uint32_t wbase = 0, round = 0;
 #pragma unroll 4
-        for (int w = 0; w < 16; ++w) { wbase += w < wid ? wave_tot[w] : 0u; round += wave_tot[w]; }
+        for (int w = 0; w < kFW; ++w) { wbase += w < wid ? wave_tot[w] : 0u; round += wave_tot[w]; }
         if (gi < S1) {
             const uint32_t beg = carry + wbase + x - c;
             const int b = length_class(c);
@@ -489,7 +493,7 @@ __device__ __forceinline__ void schedule_slice(const ScanArgs &sa, int nall, int
     // the segment words, cleared in slices for the blend of THIS launch (GA_SURFEL_FLAG_WORKSPACE_CLEAN: see surfel_run_sort_kernel)
     {
         const uint32_t w0 = (uint32_t)((uint64_t)sa.seg_sync_words * blockIdx.x / nsched), w1 = (uint32_t)((uint64_t)sa.seg_sync_words * (blockIdx.x + 1) / nsched);
-        for (uint32_t i = w0 + (uint32_t)tid; i < w1; i += 1024) sa.seg_sync[i] = 0u;
+        for (uint32_t i = w0 + (uint32_t)tid; i < w1; i += kFT) sa.seg_sync[i] = 0u;
     }
     if (blockIdx.x == 0) {   // the launch's single words
         if (tid < kClasses) { sa.seg_table[2 * tid] = cls_start[tid]; sa.seg_table[2 * tid + 1] = cls_work[tid]; }
@@ -511,7 +515,7 @@ __device__ __forceinline__ void schedule_slice(const ScanArgs &sa, int nall, int
     }
 }
 
-__global__ __launch_bounds__(1024) void surfel_fill_sched_kernel(ScanArgs sa, const uint16_t *__restrict__ rect,
+__global__ __launch_bounds__(kFT) void surfel_fill_sched_kernel(ScanArgs sa, const uint16_t *__restrict__ rect,
                                                                  const float *__restrict__ depth, Dims dm,
                                                                  const unsigned long long *__restrict__ view_total,
                                                                  uint64_t *__restrict__ keys, int nsched, uint32_t *__restrict__ big_scratch,
@@ -525,8 +529,8 @@ __global__ __launch_bounds__(1024) void surfel_fill_sched_kernel(ScanArgs sa, co
         if ((int)blockIdx.x < nsched) schedule_slice(sa, dm.V * dm.tiles, nsched, big_scratch);
         return;
     }
-    __shared__ uint32_t wave_sum[16];
-    __shared__ unsigned long long wave_base[16], wave_all[16];
+    __shared__ uint32_t wave_sum[kFW];
+    __shared__ unsigned long long wave_base[kFW], wave_all[kFW];
     const int v = (int)blockIdx.y - 1, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int T = dm.tiles;
     uint32_t *cnt = lds, *basep = lds + T;
@@ -536,27 +540,27 @@ __global__ __launch_bounds__(1024) void surfel_fill_sched_kernel(ScanArgs sa, co
     ushort4 rcs[kFillSplats];
 #pragma unroll
     for (int k = 0; k < kFillSplats; ++k) {
-        const int i = (blockIdx.x * kFillSplats + k) * 1024 + tid;
+        const int i = (blockIdx.x * kFillSplats + k) * kFT + tid;
         rcs[k] = i < dm.N ? *reinterpret_cast<const ushort4 *>(rect + 4 * ((size_t)v * dm.N + i)) : make_ushort4(0, 0, 0, 0);
     }
-    const int per = (T + 1023) / 1024;          // consecutive tile counters per thread (<= kLdsTiles / 1024 = 8)
-    uint32_t tc[kLdsTiles / 1024];
+    const int per = (T + 1023) / kFT;          // consecutive tile counters per thread (<= kLdsTiles / kFT)
+    uint32_t tc[kLdsTiles / kFT];
 #pragma unroll
-    for (int j = 0; j < kLdsTiles / 1024; ++j) {
+    for (int j = 0; j < kLdsTiles / kFT; ++j) {
         const int t = tid * per + j;
         tc[j] = (j < per && t < T) ? tcv[t] : 0u;
     }
     unsigned long long before = 0, all = 0;     // entries of the views before mine / of all views
-    for (int u = tid; u < dm.V * kViewSlots; u += 1024) {
+    for (int u = tid; u < dm.V * kViewSlots; u += kFT) {
         const unsigned long long c = view_total[u];
         all += c;
         if (u < v * kViewSlots) before += c;
     }
-    for (int t = tid; t < T; t += 1024) cnt[t] = 0;
+    for (int t = tid; t < T; t += kFT) cnt[t] = 0;
     // exclusive scan of my view's counters: thread-local, wave (shuffles), 16 wave totals
     uint32_t loc = 0;
 #pragma unroll
-    for (int j = 0; j < kLdsTiles / 1024; ++j) loc += tc[j];
+    for (int j = 0; j < kLdsTiles / kFT; ++j) loc += tc[j];
     uint32_t x = loc;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -574,7 +578,7 @@ __global__ __launch_bounds__(1024) void surfel_fill_sched_kernel(ScanArgs sa, co
     unsigned long long vbase = 0, total = 0;
     uint32_t wbase = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
+    for (int w = 0; w < kFW; ++w) {
         vbase += wave_base[w];
         total += wave_all[w];
         wbase += w < wid ? wave_sum[w] : 0u;
@@ -584,7 +588,7 @@ __global__ __launch_bounds__(1024) void surfel_fill_sched_kernel(ScanArgs sa, co
     {
         uint32_t run = (uint32_t)vbase + wbase + x - loc;
 #pragma unroll
-        for (int j = 0; j < kLdsTiles / 1024; ++j) {
+        for (int j = 0; j < kLdsTiles / kFT; ++j) {
             const int t = tid * per + j;
             if (j < per && t < T) basep[t] = run;
             run += tc[j];
@@ -597,7 +601,7 @@ __global__ __launch_bounds__(1024) void surfel_fill_sched_kernel(ScanArgs sa, co
             for (int tx = rcs[k].x; tx < rcs[k].z; ++tx) atomicAdd(cnt + ty * dm.gx + tx, 1u);
     __syncthreads();
     // b) reserve [base, base + count) in each touched tile's list: ONE returning atomic on the tile's relative cursor
-    for (int t = tid; t < T; t += 1024) {
+    for (int t = tid; t < T; t += kFT) {
         const uint32_t c = cnt[t];
         if (c) { basep[t] += atomicAdd(cur + t, c); cnt[t] = 0; }
     }
@@ -607,7 +611,7 @@ __global__ __launch_bounds__(1024) void surfel_fill_sched_kernel(ScanArgs sa, co
     for (int k = 0; k < kFillSplats; ++k) {
         const ushort4 rc = rcs[k];
         if (rc.z <= rc.x || rc.w <= rc.y) continue;
-        const int i = (blockIdx.x * kFillSplats + k) * 1024 + tid;
+        const int i = (blockIdx.x * kFillSplats + k) * kFT + tid;
         const uint64_t key = ((uint64_t)__float_as_uint(depth[(size_t)v * dm.N + i]) << 32) | (uint32_t)i;
         for (int ty = rc.y; ty < rc.w; ++ty)
             for (int tx = rc.x; tx < rc.z; ++tx) {
@@ -1063,11 +1067,11 @@ void launch_binning(const GaSurfelForwardArgs &a, const Dims &d, const Workspace
     const int nt = d.V * d.tiles;
     const ScanArgs sa{ws.tile_count, ws.seg_sync, (uint32_t)(8 * ((size_t)a.capacity / 1024 + 1)), ws.tile_start, ws.tile_cursor,
                       ws.tile_order, ws.run_table, nt, a.capacity, seg_items(a.capacity, a.seg_capacity), ws.seg_table, ws.status};
-    const unsigned nbx = (unsigned)std::max(1, (d.N + 1024 * kFillSplats - 1) / (1024 * kFillSplats));
-    const int nsched = (int)std::min<unsigned>(nbx, (unsigned)((nt + 1023) / 1024));   // ~1024 schedule slots per workgroup of row 0
+    const unsigned nbx = (unsigned)std::max(1, (d.N + kFT * kFillSplats - 1) / (kFT * kFillSplats));
+    const int nsched = (int)std::min<unsigned>(nbx, (unsigned)((nt + kFT - 1) / kFT));   // one schedule slot per thread of a row-0 workgroup
     // (16-bit halves in the schedule's class bins; the schedule workgroups' notes of the long lists fit point_list)
     if (d.tiles <= kLdsTiles && nt <= 0xFFFF && (int64_t)nsched * 2 * (a.capacity / kSortCap + 1) <= a.capacity) {
-        hipLaunchKernelGGL(surfel_fill_sched_kernel, dim3(nbx, (unsigned)d.V + 1u), dim3(1024), 2 * d.tiles * sizeof(uint32_t), s, sa,
+        hipLaunchKernelGGL(surfel_fill_sched_kernel, dim3(nbx, (unsigned)d.V + 1u), dim3(kFT), 2 * d.tiles * sizeof(uint32_t), s, sa,
                            ws.rect, ws.depth, d, ws.view_total, ws.keys, nsched, ws.point_list, ws.seg_scratch);
         return;
     }
