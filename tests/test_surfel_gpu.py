@@ -147,6 +147,21 @@ def test_more_than_8192_tiles_take_the_chunked_scan(gpu_device):
     _run_case(g, cams, [1, 4, 6], 1024, 1024, gpu_device)
 
 
+def test_sizes_beyond_the_fused_binning_launch_take_the_scan_in_front_of_the_fill(gpu_device):
+    """The fill launch that carries the schedule (round 4) covers views of at most 8192 tiles and fewer than 65536 (view, tile)
+    counters; beyond either the single-workgroup scan runs in front of the fill: (i) one view of 1552 x 1552 = 9409 tiles (global
+    cursors, no LDS histogram), (ii) 264 views of 256 x 256 = 67 584 counters (LDS histograms, absolute cursors).  Same bins, same
+    pixels as the oracle, and the workspace is left clean for the next forward either way (second forward on the same workspace)."""
+    cams = synthetic.eval_cameras(8)
+    g = synthetic.random_surfels(1200, seed=33)[0]
+    _run_case(g, cams, [2], 1552, 1552, gpu_device)
+    _run_case(g, cams, [2], 1552, 1552, gpu_device)
+    g2 = synthetic.random_surfels(400, seed=34)[0]
+    views = [v % 8 for v in range(264)]
+    _run_case(g2, cams, views, 256, 256, gpu_device)
+    _run_case(g2, cams, views, 256, 256, gpu_device)
+
+
 def test_multi_view_batch_equals_oracle_per_view(gpu_device):
     cams = synthetic.eval_cameras(8)
     g = synthetic.random_surfels(20000, seed=5)[0]
