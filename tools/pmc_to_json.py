@@ -48,7 +48,8 @@ def main():
         "valu_issue_frac": round(b["SQ_INSTS_VALU"] * 4 / 1024 / (gui / 8), 4),
         "kernel_cycles": gui / 8,
         "source": "profiles/r4_blend_pmc.txt",
-        "source_sha256": {"gaussiananything_amd/csrc/surfel_blend.hip": sha("gaussiananything_amd/csrc/surfel_blend.hip")},
+        "source_sha256": {rel: sha(rel) for rel in ("gaussiananything_amd/csrc/surfel_blend.hip", "gaussiananything_amd/csrc/surfel_common.h",
+                                                    "gaussiananything_amd/csrc/Makefile")},   # (the build flags count: see the Makefile)
     }
     json.dump(blend, open(os.path.join(ROOT, "profiles", "r4_blend_pmc.json"), "w"), indent=1)
     att = {}
@@ -59,7 +60,7 @@ def main():
     json.dump({"_comment": "MFMA busy = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs) of the two attention launches of "
                            "bench.py's `attention` section (tools/dit_kernels_two.py attn; profiles/r4_attention_pmc.txt)",
                "kernels": att, "source": "profiles/r4_attention_pmc.txt",
-               "source_sha256": {"gaussiananything_amd/csrc/dit_attention.hip": sha("gaussiananything_amd/csrc/dit_attention.hip")}},
+               "source_sha256": {rel: sha(rel) for rel in ("gaussiananything_amd/csrc/dit_attention.hip", "gaussiananything_amd/csrc/Makefile")}},
               open(os.path.join(ROOT, "profiles", "r4_attention_pmc.json"), "w"), indent=1)
     print(json.dumps(blend, indent=1)[:600])
     print(json.dumps(att, indent=1))
