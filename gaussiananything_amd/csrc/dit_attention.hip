@@ -81,8 +81,15 @@ __device__ __forceinline__ float group_max(float t)
 // the 64-key tiles ks, ks + KS, ks + 2 KS, ...; every key group stages its own K / V^T tiles (KS rings in LDS) and the
 // groups' partial (max, sum, O) are merged through LDS at the end.  KS > 1 only pays when 128-query workgroups would
 // leave most CUs empty (see the launcher).  KNORM: K is RMS-normalised while it is staged (through registers).
+// (tail: workgroups behind the attention grid -- y slices >= tail.y0, head-major; z slices >= tail.y0 otherwise -- compute a
+//  ShiftBiasJob, dit_common.h; job.W[0] == nullptr: none)
+struct AttnTail {
+    ShiftBiasJob job;
+    int y0;
+};
+
 template <int NW, int KS, bool KNORM>
-__global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttentionArgs a)
+__global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttentionArgs a, AttnTail tail)
 {
     constexpr int QB = NW * 16, GT = NW * 64, CPT = (512 + GT - 1) / GT;  // 16-byte chunks per thread per staged tile
     constexpr int DPW = 16 / NW;                                          // DMA instructions per wave per tile (K + V^T)
@@ -91,6 +98,18 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
     constexpr int TPS = (!KNORM && KS == 1) ? 2 : 1;
     static_assert(16 % NW == 0, "a tile is 16 one-KiB DMA pieces");
     __shared__ __attribute__((aligned(16))) uint16_t smem[KS * 6 * TPS * TILE];  // per key group: K[3][TPS][key][d], V^T[3][TPS][d][key]
+    static_assert(sizeof(smem) >= kSbLdsFloats * sizeof(float), "the tail's partial sums");
+    if (tail.job.W[0] != nullptr) {   // kernel-uniform
+#if GA_ATTN_HEAD_MAJOR
+        const int slice = (int)blockIdx.y - tail.y0, in_slice = blockIdx.x, per_slice = gridDim.x;
+#else
+        const int slice = (int)blockIdx.z - tail.y0, in_slice = blockIdx.y * gridDim.x + blockIdx.x, per_slice = gridDim.x * gridDim.y;
+#endif
+        if (slice >= 0) {             // workgroup-uniform
+            shift_bias_block(tail.job, slice * per_slice + in_slice, reinterpret_cast<float *>(smem));
+            return;
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: uniform branches
     const int ks = wave / NW, wq = wave - ks * NW, tg = tid - ks * GT;
     const int g = lane >> 4, c16 = lane & 15;
@@ -400,7 +419,7 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
 }
 
 template <int NW, int KS>
-static void launch_attention(const GaAttentionArgs &a, hipStream_t s)
+static void launch_attention(const GaAttentionArgs &a, hipStream_t s, const ShiftBiasJob *job)
 {
     // K normalised while it is staged (not on the DiT path, which normalises K once per conditioning tensor): ONE instantiation, eight
     // query waves and a single key group -- <8,2,true> / <4,3,true> spilt registers and <4,1,true> carried a private segment (round-3 review)
@@ -408,12 +427,24 @@ static void launch_attention(const GaAttentionArgs &a, hipStream_t s)
     const bool knorm = a.k_norm_weight != nullptr;
     const int rows = (knorm ? QW : NW) * 16;
 #if GA_ATTN_HEAD_MAJOR
-    const dim3 grid(a.heads * a.batch, (a.Lq + rows - 1) / rows, 1);
+    dim3 grid(a.heads * a.batch, (a.Lq + rows - 1) / rows, 1);
 #else
-    const dim3 grid((a.Lq + rows - 1) / rows, a.heads, a.batch);
+    dim3 grid((a.Lq + rows - 1) / rows, a.heads, a.batch);
 #endif
-    if (knorm) hipLaunchKernelGGL((attention_fwd_kernel<QW, 1, true>), grid, dim3(QW * 64), 0, s, a);
-    else hipLaunchKernelGGL((attention_fwd_kernel<NW, KS, false>), grid, dim3(NW * KS * 64), 0, s, a);
+    AttnTail tail{};
+    if (job) {
+        tail.job = *job;
+        const int needed = shift_bias_wgs(job->N0, job->N1);
+#if GA_ATTN_HEAD_MAJOR
+        const int per_slice = (int)grid.x;
+        tail.y0 = grid.y; grid.y += (needed + per_slice - 1) / per_slice;
+#else
+        const int per_slice = (int)(grid.x * grid.y);
+        tail.y0 = grid.z; grid.z += (needed + per_slice - 1) / per_slice;
+#endif
+    }
+    if (knorm) hipLaunchKernelGGL((attention_fwd_kernel<QW, 1, true>), grid, dim3(QW * 64), 0, s, a, tail);
+    else hipLaunchKernelGGL((attention_fwd_kernel<NW, KS, false>), grid, dim3(NW * KS * 64), 0, s, a, tail);
 }
 
 }  // namespace gadit
@@ -425,7 +456,19 @@ extern "C" int ga_attn_debug_stamps(unsigned long long *out)
 }
 #endif
 
-extern "C" int ga_attention_bf16(const GaAttentionArgs *a, void *stream)
+namespace gadit {
+static int dispatch_attention(const GaAttentionArgs *a, const ShiftBiasJob *job, void *stream);
+int attention_with_tail(const GaAttentionArgs *a, const ShiftBiasJob *job, void *stream)
+{
+    if (!job || !job->W[0] || !job->W[1] || !job->shift || !job->out) return GA_DIT_ERR_NULL_ARG;
+    if (job->N0 % 8 != 0 || job->N1 % 8 != 0 || job->K % 64 != 0 || job->K > 2048 || job->B <= 0) return GA_DIT_ERR_BAD_SHAPE;   // (K / 64 <= 4 x 8 waves)
+    return dispatch_attention(a, job, stream);
+}
+}  // namespace gadit
+
+extern "C" int ga_attention_bf16(const GaAttentionArgs *a, void *stream) { return gadit::dispatch_attention(a, nullptr, stream); }
+
+static int gadit::dispatch_attention(const GaAttentionArgs *a, const ShiftBiasJob *job, void *stream)
 {
     using namespace gadit;
     if (!a || !a->q || !a->k || !a->vt || !a->out) return GA_DIT_ERR_NULL_ARG;
@@ -445,20 +488,20 @@ extern "C" int ga_attention_bf16(const GaAttentionArgs *a, void *stream)
 #endif
     const int64_t wgs128 = (int64_t)((a->Lq + 127) / 128) * a->heads * a->batch;
 #ifdef GA_TUNING
-    if (cfg == 23) { launch_attention<2, 3>(*a, s); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
-    if (cfg == 43) { launch_attention<4, 3>(*a, s); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
-    if (cfg == 22) { launch_attention<2, 2>(*a, s); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
-    if (cfg == 41) { launch_attention<4, 1>(*a, s); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
-    if (cfg == 82) { launch_attention<8, 2>(*a, s); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
-    if (cfg == 21) { launch_attention<2, 1>(*a, s); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
+    if (cfg == 23) { launch_attention<2, 3>(*a, s, job); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
+    if (cfg == 43) { launch_attention<4, 3>(*a, s, job); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
+    if (cfg == 22) { launch_attention<2, 2>(*a, s, job); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
+    if (cfg == 41) { launch_attention<4, 1>(*a, s, job); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
+    if (cfg == 82) { launch_attention<8, 2>(*a, s, job); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
+    if (cfg == 21) { launch_attention<2, 1>(*a, s, job); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
 #endif
     // Round 3 (tools/attn_cfg_sweep.py): three key groups on the small grids (1 x 16 x 768 x 1369: 15.9 -> 14.2 us, x 768 keys
     // 10.1 -> 9.6 us), and two key groups beside eight query waves while 128-query workgroups are fewer than two per CU
     // (2 x 16 x 768 x 768: 13.7 -> 12.8 us; 4 x 16 x 768 x 1369: 39.5 -> 37.1 us); one group on the grids beyond that.
-    if (cfg == 42) launch_attention<4, 2>(*a, s);
-    else if (cfg == 81) launch_attention<8, 1>(*a, s);
-    else if (wgs128 <= 128) launch_attention<4, 3>(*a, s);
-    else if (wgs128 <= 512) launch_attention<8, 2>(*a, s);
-    else launch_attention<8, 1>(*a, s);
+    if (cfg == 42) launch_attention<4, 2>(*a, s, job);
+    else if (cfg == 81) launch_attention<8, 1>(*a, s, job);
+    else if (wgs128 <= 128) launch_attention<4, 3>(*a, s, job);
+    else if (wgs128 <= 512) launch_attention<8, 2>(*a, s, job);
+    else launch_attention<8, 1>(*a, s, job);
     return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
 }

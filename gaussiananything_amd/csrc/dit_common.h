@@ -31,4 +31,99 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// out[b][n] = bias[n] + sum_k shift_b[k] W[n][k] for the two projections behind a block's folded modulated pre-norms (which = 0:
+// qkv, N0 rows, shift row 0 of the block's modulation; which = 1: fc1, N1 rows, shift row `shift_which_off` further): the bias rows
+// GaGemmArgs.bias_stride reads (include/ga_dit.h).
+// Mapping: shift-stationary, weight-streaming.  A workgroup owns kSbRows groups of 8 weight rows of one projection; wave w owns the
+// K-tiles w, w + waves, ... and keeps its 8 shift values per tile and batch item in registers (lane l: row l >> 3, 16-byte chunk l & 7
+// of the 8 x 64 tile -- one 1-KiB piece of the tiled weight image per wave load).  All kSbRows tile loads of a wave are in flight
+// together; the 8 lanes of a row add up by DPP, the waves' partial sums meet in LDS (fixed order: deterministic).
+struct ShiftBiasJob {
+    const uint16_t *W[2];
+    const float *bias[2];
+    const float *shift;      // [B] rows, shift_batch_stride apart
+    float *out;              // [B x N0 | B x N1]
+    long long shift_batch_stride, shift_which_off;
+    int N0, N1, K, B, tiled;
+};
+constexpr int kSbRows = 16;          // 8-row groups per workgroup
+constexpr int kSbTilesPerWave = 4;   // K / 64 <= kSbTilesPerWave * waves of the workgroup (host-checked)
+constexpr int kSbLdsFloats = kSbRows * 16 * 8 * 2;   // partial sums of up to 16 waves
+
+__host__ __device__ __forceinline__ int shift_bias_wgs(int N0, int N1)
+{
+    return (N0 / 8 + kSbRows - 1) / kSbRows + (N1 / 8 + kSbRows - 1) / kSbRows;
+}
+
+__device__ __forceinline__ void shift_bias_block(const ShiftBiasJob &j, int wg, float *lds)
+{
+    const int nw = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wgs0 = (j.N0 / 8 + kSbRows - 1) / kSbRows;
+    const int which = wg >= wgs0;
+    const int N = which ? j.N1 : j.N0, rg0 = (which ? wg - wgs0 : wg) * kSbRows;
+    if (rg0 >= (N >> 3)) return;                                       // workgroup-uniform
+    const int nr = min(kSbRows, (N >> 3) - rg0), K = j.K, nk = K >> 6;
+    const int row = lane >> 3, ch = lane & 7;
+    const uint16_t *W = j.W[which];
+    const float *bias = j.bias[which];
+    float *out = j.out + (which ? (size_t)j.B * j.N0 : 0);
+    for (int b0 = 0; b0 < j.B; b0 += 2) {
+        const bool two = b0 + 1 < j.B;
+        const float *s0 = j.shift + (size_t)b0 * j.shift_batch_stride + (which ? j.shift_which_off : 0) + ch * 8;
+        const float *s1 = two ? s0 + j.shift_batch_stride : s0;
+        // byte offsets from the (scalar) weight base fit 32 bits: scalar base + per-lane offset addressing, no 64-bit address per load
+        const uint32_t lane_off = j.tiled ? (uint32_t)lane * 16u : ((uint32_t)row * K + ch * 8) * 2u;
+        const uint32_t rg_step = j.tiled ? (uint32_t)nk * 1024u : (uint32_t)K * 16u, kt_step = j.tiled ? 1024u : 128u;
+        const char *wb = reinterpret_cast<const char *>(W);
+        __syncthreads();                                               // (the previous pair's sums have been read)
+#pragma unroll 1
+        for (int i = 0; i < kSbTilesPerWave; ++i) {
+            const int kt = w + i * nw;
+            if (kt >= nk) break;                                       // wave-uniform
+            const float4 a0 = *reinterpret_cast<const float4 *>(s0 + kt * 64), a1 = *reinterpret_cast<const float4 *>(s0 + kt * 64 + 4);
+            const float4 c0 = *reinterpret_cast<const float4 *>(s1 + kt * 64), c1 = *reinterpret_cast<const float4 *>(s1 + kt * 64 + 4);
+#pragma unroll 1
+            for (int h = 0; h < kSbRows; h += 8) {                     // 8 tile loads in flight per lane (the register budget of the hosts)
+                uint4 wv[8];
+                const uint32_t off0 = (uint32_t)rg0 * rg_step + (uint32_t)kt * kt_step + lane_off;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) wv[r] = *reinterpret_cast<const uint4 *>(wb + (off0 + (uint32_t)min(h + r, nr - 1) * rg_step));
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const uint4 x = wv[r];
+                    const float w0 = __uint_as_float(x.x << 16), w1 = __uint_as_float(x.x & 0xFFFF0000u), w2 = __uint_as_float(x.y << 16),
+                                w3 = __uint_as_float(x.y & 0xFFFF0000u), w4 = __uint_as_float(x.z << 16), w5 = __uint_as_float(x.z & 0xFFFF0000u),
+                                w6 = __uint_as_float(x.w << 16), w7 = __uint_as_float(x.w & 0xFFFF0000u);
+                    float v0 = (w0 * a0.x + w1 * a0.y) + (w2 * a0.z + w3 * a0.w) + (w4 * a1.x + w5 * a1.y) + (w6 * a1.z + w7 * a1.w);
+                    float v1 = (w0 * c0.x + w1 * c0.y) + (w2 * c0.z + w3 * c0.w) + (w4 * c1.x + w5 * c1.y) + (w6 * c1.z + w7 * c1.w);
+                    v0 += __shfl_xor(v0, 1, 64); v0 += __shfl_xor(v0, 2, 64); v0 += __shfl_xor(v0, 4, 64);
+                    v1 += __shfl_xor(v1, 1, 64); v1 += __shfl_xor(v1, 2, 64); v1 += __shfl_xor(v1, 4, 64);
+                    if (ch == 0) {                                     // this wave's own slot: its K-tiles add up here
+                        float2 *slot = reinterpret_cast<float2 *>(lds + (((size_t)(h + r) * nw + w) * 8 + row) * 2);
+                        const float2 prev = i ? *slot : make_float2(0.f, 0.f);
+                        *slot = make_float2(prev.x + v0, prev.y + v1);
+                    }
+                }
+            }
+        }
+        if (w >= nk && lane < 16) {                                    // a wave without a K-tile: zero partial sums
+            for (int r = 0; r < kSbRows; ++r) lds[((size_t)r * nw + w) * 16 + lane] = 0.f;
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < nr * 16; o += blockDim.x) {
+            const int r = o >> 4, rw = (o >> 1) & 7, bb = o & 1;
+            if (bb && !two) continue;
+            float sum = 0.f;
+            for (int ww = 0; ww < nw; ++ww) sum += lds[(((size_t)r * nw + ww) * 8 + rw) * 2 + bb];
+            const int n = (rg0 + r) * 8 + rw;
+            out[(size_t)(b0 + bb) * N + n] = (bias ? bias[n] : 0.f) + sum;
+        }
+    }
+}
+
+// dit_attention.hip: the attention launch with `tail` workgroups behind its grid that compute one ShiftBiasJob (the self-attention of a
+// CFG pair fills 192 of the 256 CUs with one 96-KiB-LDS workgroup each: the job's weight stream runs on the idle ones)
+int attention_with_tail(const GaAttentionArgs *a, const ShiftBiasJob *job, void *stream);
+
 }  // namespace gadit

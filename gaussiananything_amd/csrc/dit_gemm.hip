@@ -53,6 +53,10 @@ struct GemmP {  // by-value kernel parameters (kept flat: no pointer into the ar
     int row_ss_tiles;
     float row_ss_inv_dim, row_ss_eps;
     int w_tiled;       // W is the tiled image [N/8][K/64][8][64] (include/ga_dit.h)
+    // folded MODULATED RMSNorm (include/ga_dit.h): emit multiplier w[n] (1 + scale_b[n]); one bias row per batch item; rows of A in the product
+    const float *emit_w, *emit_scale;
+    long long emit_scale_stride, bias_stride;
+    int k_rows;
 };
 
 // Element offset of chunk c (8 bf16) of weight row n at K-tile 0, and the stride from one K-tile to the next: row-major
@@ -180,8 +184,11 @@ template <int EPI, int MT, int FN, bool PRE, bool RSSPRE>
 __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[FN][MT], const ResidualPrefetch<MT> *pre,
                                               const RowSsPrefetch<MT> *rss, int mrow0, int ncol0, int lane, float *emit_part = nullptr,
                                               const f32x4 *bias_pre = nullptr, const f32x4 *qkw_pre = nullptr,
-                                              float *qk_mine = nullptr, const float *qk_other = nullptr)
+                                              float *qk_mine = nullptr, const float *qk_other = nullptr, bool bias_pre_ok = true,
+                                              const f32x4 (*emul_pre)[2] = nullptr, bool emul_pre_ok = false)
 {
+    // (bias_pre_ok false: the wave's rows straddle two batch items of a per-batch bias -- fetched per row below.  A flag, not a null
+    //  pointer: selecting between the caller's register array and nullptr sends the array to scratch)
     static_assert(FN == 4 || FN == 2, "a wave owns 64 or 32 columns");
     const int M = p.M, N = p.N;
     // epilogue: lane holds acc[i][j][r] = C[m = mrow0 + j*16 + (lane&15)][n = ncol0 + i*16 + (lane>>4)*4 + r];
@@ -201,17 +208,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[FN][M
     auto prepare = [&](int j, f32x4 (&v)[FN]) __attribute__((always_inline)) {
         const int m = mrow0 + j * 16 + (lane & 15);
 #pragma unroll
-        for (int i = 0; i < FN; ++i) {
-            const int n = nhead + i * 16 + g * 4;
-            v[i] = acc[i][j];
-            if (bias_pre) {                       // requested before the K loop (zero without a bias)
-                v[i][0] += bias_pre[i][0]; v[i][1] += bias_pre[i][1]; v[i][2] += bias_pre[i][2]; v[i][3] += bias_pre[i][3];
-            } else if (p.bias && n < N) {
-                const float4 b = *reinterpret_cast<const float4 *>(p.bias + n);
-                v[i][0] += b.x; v[i][1] += b.y; v[i][2] += b.z; v[i][3] += b.w;
-            }
+        for (int i = 0; i < FN; ++i) v[i] = acc[i][j];
+        if (EPI == GA_GEMM_EPI_RESIDUAL && p.k_rows && m >= p.k_rows) {   // rows behind the product: bias (and emit) only
+#pragma unroll
+            for (int i = 0; i < FN; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (EPI == GA_GEMM_EPI_STORE_BF16 && p.row_ss) {  // kernel-uniform: the RMSNorm row scale folded out of the A operand
+        if ((EPI == GA_GEMM_EPI_STORE_BF16 || EPI == GA_GEMM_EPI_GELU_BF16) && p.row_ss) {  // kernel-uniform: the RMSNorm row scale folded out of the A operand
             float tot = 0.f;
             if (RSSPRE) {
 #pragma unroll
@@ -226,6 +228,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[FN][M
             const float rs = rsqrtf(tot * p.row_ss_inv_dim + p.row_ss_eps);
 #pragma unroll
             for (int i = 0; i < FN; ++i) { v[i][0] *= rs; v[i][1] *= rs; v[i][2] *= rs; v[i][3] *= rs; }
+        }
+        // (the bias after the row scale: with a folded modulated norm it carries shift_b W^T, which is not scaled)
+        const float *brow = p.bias;
+        if (!(bias_pre && bias_pre_ok) && p.bias && p.bias_stride) brow += (size_t)(min(m, M - 1) / p.rows_per_batch) * p.bias_stride;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const int n = nhead + i * 16 + g * 4;
+            if (bias_pre && bias_pre_ok) {        // requested before the K loop (zero without a bias)
+                v[i][0] += bias_pre[i][0]; v[i][1] += bias_pre[i][1]; v[i][2] += bias_pre[i][2]; v[i][3] += bias_pre[i][3];
+            } else if (p.bias && n < N) {
+                const float4 b = *reinterpret_cast<const float4 *>(brow + n);
+                v[i][0] += b.x; v[i][1] += b.y; v[i][2] += b.z; v[i][3] += b.w;
+            }
         }
     };
     const bool halves = EPI == GA_GEMM_EPI_STORE_BF16 && FN == 2 && qk_mine != nullptr;   // workgroup-uniform
@@ -342,11 +357,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[FN][M
                     dst[0] = make_float4(xn[0], xn[1], xn[2], xn[3]);
                     if (hi) dst[1] = make_float4(xn[4], xn[5], xn[6], xn[7]);
                     if (p.emit_x) {  // kernel-uniform; N % 64 == 0, so `hi` holds
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) emit_acc += xn[e] * xn[e];
+                        if (p.emit_w && emul_pre && emul_pre_ok) {   // (requested before the K loop: one batch item per wave)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                xn[e] *= emul_pre[q][0][e] * (1.f + emul_pre[FN / 2 + q][0][e]);
+                                xn[4 + e] *= emul_pre[q][1][e] * (1.f + emul_pre[FN / 2 + q][1][e]);
+                            }
+                        } else if (p.emit_w) {   // kernel-uniform: the modulated pre-norm's w (1 + scale_b), applied before the bf16 rounding
+                            const float *sc = p.emit_scale + (size_t)(m / p.rows_per_batch) * p.emit_scale_stride + n;
+                            const float4 w0 = *reinterpret_cast<const float4 *>(p.emit_w + n), w1 = *reinterpret_cast<const float4 *>(p.emit_w + n + 4);
+                            const float4 s0 = *reinterpret_cast<const float4 *>(sc), s1 = *reinterpret_cast<const float4 *>(sc + 4);
+                            xn[0] *= w0.x * (1.f + s0.x); xn[1] *= w0.y * (1.f + s0.y); xn[2] *= w0.z * (1.f + s0.z); xn[3] *= w0.w * (1.f + s0.w);
+                            xn[4] *= w1.x * (1.f + s1.x); xn[5] *= w1.y * (1.f + s1.y); xn[6] *= w1.z * (1.f + s1.z); xn[7] *= w1.w * (1.f + s1.w);
+                        }
                         *reinterpret_cast<uint4 *>(p.emit_x + (size_t)m * p.emit_ld + n) =
                             make_uint4(pack_bf16x2(xn[0], xn[1]), pack_bf16x2(xn[2], xn[3]), pack_bf16x2(xn[4], xn[5]),
                                        pack_bf16x2(xn[6], xn[7]));
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) emit_acc += xn[e] * xn[e];
                     }
                 } else {
                     dst[0] = make_float4(w[0], w[1], w[2], w[3]);
@@ -391,7 +419,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p)
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int row = (wave * MT + i) * 8 + (lane >> 3);
-        srcA[i] = p.A + (size_t)min(m0 + row, M - 1) * p.lda + ((lane & 7) ^ (row & 7)) * 8;
+        srcA[i] = p.A + (size_t)min(m0 + row, ((EPI == GA_GEMM_EPI_RESIDUAL && p.k_rows) ? p.k_rows : M) - 1) * p.lda + ((lane & 7) ^ (row & 7)) * 8;
     }
     f32x4 acc[4][MT];
 #pragma unroll
@@ -552,12 +580,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
     // slot (row, s) of the 128-byte row receives global chunk s ^ (row & 7)
     const uint16_t *src[DPT];
     static_assert(BNT % (8 * NW) == 0, "instruction i of every wave is on the same side of the W | A boundary");
+    const int arows = (EPI == GA_GEMM_EPI_RESIDUAL && p.k_rows) ? p.k_rows : M;   // rows of A that exist / take part
+    const bool product = m0 < arows;                                              // workgroup-uniform: a tile behind them skips the K loop
     const int wks = w_kstep(p);
 #pragma unroll
     for (int i = 0; i < DPT; ++i) {
         const int row = (i * NW + wave) * 8 + (lane >> 3);
         if (i * NW * 8 < BNT) src[i] = p.W + w_offset(p, min(n0 + row, N - 1), (lane & 7) ^ (row & 7));
-        else src[i] = p.A + (size_t)min(m0 + row - BNT, M - 1) * p.lda + ((lane & 7) ^ ((row - BNT) & 7)) * 8;
+        else src[i] = p.A + (size_t)min(m0 + row - BNT, arows - 1) * p.lda + ((lane & 7) ^ ((row - BNT) & 7)) * 8;
     }
     f32x4 acc[FN][FM];
 #pragma unroll
@@ -586,11 +616,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
     // they say): bias, per-head norm weights, the consumer's row sums, and -- where the registers are there (the 4-wave tiles) --
     // the residual rows and gates.  Without this the epilogue starts with a dependent L2 / HBM round trip per operand.
     f32x4 bias_pre[FN], qkw_pre[FN];
+    const float *bias_row = p.bias;
+    bool bias_one_row = true;     // wave-uniform: all rows of this wave take the same bias row (else the epilogue fetches per row)
+    if (p.bias && p.bias_stride) {
+        const int b0 = min(mrow0, M - 1) / p.rows_per_batch, b1 = min(mrow0 + FM * 16 - 1, M - 1) / p.rows_per_batch;
+        bias_one_row = b0 == b1;
+        bias_row += (size_t)b0 * p.bias_stride;
+    }
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
         bias_pre[i] = qkw_pre[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (p.bias) {
-            const float4 b = *reinterpret_cast<const float4 *>(p.bias + min(ncol0 + i * 16 + lg * 4, N - 4));
+            const float4 b = *reinterpret_cast<const float4 *>(bias_row + min(ncol0 + i * 16 + lg * 4, N - 4));
             bias_pre[i] = f32x4{b.x, b.y, b.z, b.w};
         }
     }
@@ -604,15 +641,37 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
             }
         }
     }
+    // the emit multipliers w (1 + scale_b) of a folded modulated pre-norm, in the exchanged 8-column layout of the epilogue
+    constexpr int EQ = EPI == GA_GEMM_EPI_RESIDUAL ? FN / 2 : 1;
+    f32x4 emul[2 * EQ][2];     // [q]: norm weight, [EQ + q]: scale -- combined in the epilogue (no wait on these loads before the K loop)
+    bool emul_ok = false;
+#pragma unroll
+    for (int q = 0; q < 2 * EQ; ++q) emul[q][0] = emul[q][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (EPI == GA_GEMM_EPI_RESIDUAL && p.emit_w) {
+        const int b0 = min(mrow0, M - 1) / p.rows_per_batch, b1 = min(mrow0 + FM * 16 - 1, M - 1) / p.rows_per_batch;
+        emul_ok = b0 == b1;
+        const float *sc = p.emit_scale + (size_t)b0 * p.emit_scale_stride;
+#pragma unroll
+        for (int q = 0; q < EQ; ++q) {
+            const int n = min(ncol0 + q * 32 + (lg & 1) * 16 + (lg >> 1) * 8, N - 8);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const float4 w4 = *reinterpret_cast<const float4 *>(p.emit_w + n + 4 * hh), s4 = *reinterpret_cast<const float4 *>(sc + n + 4 * hh);
+                emul[q][hh] = f32x4{w4.x, w4.y, w4.z, w4.w};
+                emul[EQ + q][hh] = f32x4{s4.x, s4.y, s4.z, s4.w};
+            }
+        }
+    }
     constexpr bool PRE = EPI == GA_GEMM_EPI_RESIDUAL && NW == 4;      // 8-wave tile: 256-register budget, no room
     ResidualPrefetch<PRE ? FM : 1> pre;
     if (PRE) residual_prefetch<FM, FN / 2>(p, reinterpret_cast<ResidualPrefetch<FM> &>(pre), mrow0, ncol0, lane);
-    constexpr bool RSS = EPI == GA_GEMM_EPI_STORE_BF16;
+    constexpr bool RSS = EPI == GA_GEMM_EPI_STORE_BF16 || EPI == GA_GEMM_EPI_GELU_BF16;
     RowSsPrefetch<RSS ? FM : 1> rss;
     if (RSS && p.row_ss) rowss_prefetch<FM>(p, reinterpret_cast<RowSsPrefetch<FM> &>(rss), mrow0, lane);
 
     // nk = n_main * NST + NST: the last NST tiles are peeled (compile-time slot, wait count, request-or-not)
     const int n_main = nk / NST - 1;
+    if (product) {
     static_for<0, NST - 1>([&](auto bc) __attribute__((always_inline)) { stage(bc, decltype(bc)::value); });
 
     if constexpr (PIPE == 0) {
@@ -717,10 +776,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
             tile(ic, kt + i, std::integral_constant<int, HO>{}, std::integral_constant<int, fly>{});
         });
     }
+    }   // product
 
     if constexpr (FN == 4) {
         gemm_epilogue<EPI, FM, 4, PRE, RSS>(p, acc, reinterpret_cast<const ResidualPrefetch<FM> *>(&pre),
-                                            reinterpret_cast<const RowSsPrefetch<FM> *>(&rss), mrow0, ncol0, lane, nullptr, bias_pre, qkw_pre);
+                                            reinterpret_cast<const RowSsPrefetch<FM> *>(&rss), mrow0, ncol0, lane, nullptr, bias_pre, qkw_pre, nullptr, nullptr, bias_one_row, emul, emul_ok);
     } else {
         // 32-column waves: the two waves of a 64-column group add their row sums of squares through LDS (the ring is idle now)
         static_assert(WN == 2, "a 64-column tile is two 32-column waves");
@@ -732,7 +792,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
         gemm_epilogue<EPI, FM, 2, PRE, RSS>(p, acc, reinterpret_cast<const ResidualPrefetch<FM> *>(&pre),
                                             reinterpret_cast<const RowSsPrefetch<FM> *>(&rss), mrow0, ncol0, lane, part, bias_pre, qkw_pre,
                                             qk2 ? part : nullptr,
-                                            reinterpret_cast<const float *>(smem) + ((wn ^ 1) * WM + wm) * FM * 16);
+                                            reinterpret_cast<const float *>(smem) + ((wn ^ 1) * WM + wm) * FM * 16, bias_one_row, emul, emul_ok);
         if (emit) {
             __syncthreads();
             const float *all = reinterpret_cast<const float *>(smem);
@@ -769,13 +829,18 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
                                       a->emit_ld % 8 != 0 || a->emit_ld < a->N))
         return GA_DIT_ERR_BAD_SHAPE;
     if (a->w_tiled && a->N % 8 != 0) return GA_DIT_ERR_BAD_SHAPE;
-    if (a->row_ss && (a->epilogue != GA_GEMM_EPI_STORE_BF16 || a->bias || a->row_ss_tiles <= 0 || a->row_ss_tiles > 16 ||
-                      a->row_ss_tiles % 4 != 0 || a->row_ss_dim <= 0))
+    if (a->row_ss && ((a->epilogue != GA_GEMM_EPI_STORE_BF16 && a->epilogue != GA_GEMM_EPI_GELU_BF16) || a->row_ss_tiles <= 0 ||
+                      a->row_ss_tiles > 16 || a->row_ss_tiles % 4 != 0 || a->row_ss_dim <= 0))
         return GA_DIT_ERR_BAD_SHAPE;
+    if ((a->emit_w || a->emit_scale) && (!a->emit_x || !a->emit_w || !a->emit_scale || a->rows_per_batch <= 0 || a->emit_scale_stride % 4 != 0))
+        return GA_DIT_ERR_BAD_SHAPE;
+    if (a->bias_stride && (!a->bias || a->rows_per_batch <= 0 || a->bias_stride % 4 != 0 || a->bias_stride < a->N)) return GA_DIT_ERR_BAD_SHAPE;
+    if (a->k_rows && (a->epilogue != GA_GEMM_EPI_RESIDUAL || a->k_rows < 0 || a->k_rows > a->M)) return GA_DIT_ERR_BAD_SHAPE;
     const GemmP p{a->M, a->N, a->K, a->rows_per_batch, a->A, a->W, a->bias, a->gate, a->out, a->lda, a->ldo, a->gate_stride,
                   a->vt, a->vt_col0, a->vt ? (a->N - a->vt_col0) / 64 : 0, a->vt_ld, a->qk_w0, a->qk_w1, a->qk_cols0,
                   a->qk_cols1, a->emit_x, a->emit_ss, a->emit_ld, a->row_ss, a->row_ss_tiles,
-                  a->row_ss_dim > 0 ? 1.0f / (float)a->row_ss_dim : 0.f, a->row_ss_eps, a->w_tiled ? 1 : 0};
+                  a->row_ss_dim > 0 ? 1.0f / (float)a->row_ss_dim : 0.f, a->row_ss_eps, a->w_tiled ? 1 : 0,
+                  a->emit_w, a->emit_scale, a->emit_scale_stride, a->bias_stride, a->k_rows == a->M ? 0 : a->k_rows};
     // Tile / ring choice (256 CUs).  A workgroup tile is 128 weight rows x 32 MT activation rows (MT = 4, 3, 2, 1); its work is
     // proportional to MT plus a tile-independent share (prologue, weight tile, epilogue: about one MT unit, tools/gemm_sweep.py) and
     // the launch ends with the busiest CU, so the cost of a choice is ceil(workgroups / 256) * (MT + 1)

@@ -163,6 +163,34 @@ __global__ void mod_table_kernel(ModTableArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The shift of a folded modulated pre-norm, carried through the projection (include/ga_dit.h, GaGemmArgs.bias_stride):
+//   out[job][b][n] = bias[n] + sum_k shift_b[k] W[n][k]      for the qkv (which = 0) and fc1 (which = 1) weights of every block
+// in ONE launch per evaluation (the modulation of all blocks is known once t is embedded).  A wave owns 8 weight rows -- one 1-KiB
+// tile column of the tiled image, K/64 tiles contiguous -- lane l reads the 16 bytes (row l >> 3, chunk l & 7) of every tile,
+// so the weights stream through once per batch pair at full request width; 350 MB for DiT-L.
+struct ShiftBiasArgs {
+    const uint16_t *W[128];     // [block][which]
+    const float *bias[128];
+    const float *shift;         // mod table [block][B][6][D]; which = 0: row 0 (shift_msa), which = 1: row 3 (shift_mlp)
+    float *out;                 // [block][ B x N0 | B x N1 ]
+    long long shift_block_stride, shift_batch_stride, shift_which_off, out_block_stride;
+    int N0, N1, K, B, jobs, tiled;
+};
+
+__global__ __launch_bounds__(1024) void shift_bias_kernel(ShiftBiasArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float sh[kSbLdsFloats];
+    ShiftBiasJob j;
+    j.N0 = a.N0; j.N1 = a.N1; j.K = a.K; j.B = a.B; j.tiled = a.tiled;
+    const int wgs = shift_bias_wgs(a.N0, a.N1);                        // workgroups per block of the model (grid = jobs * wgs)
+    const int blk = blockIdx.x / wgs;
+    j.W[0] = a.W[2 * blk]; j.W[1] = a.W[2 * blk + 1]; j.bias[0] = a.bias[2 * blk]; j.bias[1] = a.bias[2 * blk + 1];
+    j.shift = a.shift + (size_t)blk * a.shift_block_stride; j.out = a.out + (size_t)blk * a.out_block_stride;
+    j.shift_batch_stride = a.shift_batch_stride; j.shift_which_off = a.shift_which_off;
+    shift_bias_block(j, blockIdx.x - blk * wgs, sh);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // h[m][n] = gelu_tanh(sum_c x[m][c] W1[n][c] + b1[n]) as bf16 (A operand of the x_embedder.fc2 GEMM) and, for stage 2,
 // xres[m][n] = sum_j PE(xyz[m])[j] Wx[n][j] + bx[n]  (fp32 residual stream start; fc2 is accumulated on top).
 struct EmbedArgs {
@@ -368,13 +396,26 @@ extern "C" int ga_small_linear(const GaSmallLinearArgs *a, void *stream)
     return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
 }
 
+extern "C" int ga_dit_shift_bias(const ga_bf16 *W, int32_t w_tiled, const float *bias, int32_t N, int32_t K, const float *shift,
+                                 int64_t shift_stride, int32_t batch, float *out, void *stream)
+{
+    using namespace gadit;
+    if (!W || !shift || !out) return GA_DIT_ERR_NULL_ARG;
+    if (N <= 0 || N % 8 != 0 || K <= 0 || K % 64 != 0 || K > 4096 || batch <= 0 || shift_stride % 4 != 0) return GA_DIT_ERR_BAD_SHAPE;
+    ShiftBiasArgs sb{};
+    sb.W[0] = W; sb.bias[0] = bias; sb.shift = shift; sb.out = out; sb.shift_batch_stride = shift_stride;
+    sb.N0 = N; sb.N1 = 0; sb.K = K; sb.B = batch; sb.jobs = 1; sb.tiled = w_tiled ? 1 : 0;
+    hipLaunchKernelGGL(shift_bias_kernel, dim3((unsigned)shift_bias_wgs(N, 0)), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), sb);
+    return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
+}
+
 // =================================================================================================================
 // Whole forward: launch sequence of one function evaluation (see include/ga_dit.h).  ~11 launches per block; nothing
 // synchronises, so the caller can capture it in a HIP graph.
 namespace gadit {
 
 struct Ws {
-    float *xres, *tfreq, *t1, *pln, *pvec, *tvec, *t0, *mod, *rowss;
+    float *xres, *tfreq, *t1, *pln, *pvec, *tvec, *t0, *mod, *rowss, *sbias;
     uint16_t *xn, *qkv, *att, *hmid, *vt;
     size_t vt_bytes;
     size_t total;
@@ -397,6 +438,7 @@ static Ws carve(const GaDitModel *m, int B, int L, void *base)
     const size_t o_tvec = take((size_t)B * D * 4), o_t0 = take((size_t)B * 6 * D * 4);
     const size_t o_mod = take((size_t)m->depth * B * 6 * D * 4);
     const size_t o_rowss = take(M * (D / 64) * 4);   // per-row partial sums of squares of the residual stream (folded pre-norm)
+    const size_t o_sbias = take((size_t)m->depth * B * 7 * D * 4);   // shift_b W^T + bias of the qkv and fc1 projections (folded modulated pre-norms)
     w.total = off;
     w.xres = reinterpret_cast<float *>(p + o_xres); w.xn = reinterpret_cast<uint16_t *>(p + o_xn);
     w.qkv = reinterpret_cast<uint16_t *>(p + o_qkv); w.att = reinterpret_cast<uint16_t *>(p + o_att);
@@ -405,7 +447,7 @@ static Ws carve(const GaDitModel *m, int B, int L, void *base)
     w.t1 = reinterpret_cast<float *>(p + o_t1); w.pln = reinterpret_cast<float *>(p + o_pln);
     w.pvec = reinterpret_cast<float *>(p + o_pvec); w.tvec = reinterpret_cast<float *>(p + o_tvec);
     w.t0 = reinterpret_cast<float *>(p + o_t0); w.mod = reinterpret_cast<float *>(p + o_mod);
-    w.rowss = reinterpret_cast<float *>(p + o_rowss);
+    w.rowss = reinterpret_cast<float *>(p + o_rowss); w.sbias = reinterpret_cast<float *>(p + o_sbias);
     return w;
 }
 
@@ -494,6 +536,22 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         const int64_t tot = (int64_t)m->depth * B * 6 * D;
         hipLaunchKernelGGL(mod_table_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, mt);
     }
+    // the modulated pre-norms of the self-attention and the MLP fold into the neighbouring GEMMs like the cross-attention's (below):
+    // their shifts go through the qkv / fc1 weights once per evaluation, for all blocks in one launch
+    const bool fold_mod = can_fold(m, 0) && m->depth <= 64;
+    static const bool sb_tail = [] { const char *e = getenv("GA_DIT_SBTAIL"); return !e || atoi(e) != 0; }();
+    if (fold_mod) {
+        ShiftBiasArgs sb{};
+        for (int i = 0; i < m->depth; ++i) {
+            sb.W[2 * i] = m->blocks[i].qkv_w; sb.bias[2 * i] = m->blocks[i].qkv_b;
+            sb.W[2 * i + 1] = m->blocks[i].fc1_w; sb.bias[2 * i + 1] = m->blocks[i].fc1_b;
+        }
+        sb.shift = w.mod; sb.out = w.sbias; sb.shift_block_stride = (long long)B * 6 * D; sb.shift_batch_stride = 6 * (long long)D;
+        sb.shift_which_off = 3 * (long long)D; sb.out_block_stride = (long long)B * 7 * D;
+        // (GA_DIT_SBTAIL=0: all blocks here, A/B aid; default: block 0 here, block i + 1 behind the self-attention grid of block i)
+        sb.N0 = 3 * D; sb.N1 = 4 * D; sb.K = D; sb.B = B; sb.jobs = sb_tail ? 1 : m->depth; sb.tiled = m->gemm_weights_tiled;
+        hipLaunchKernelGGL(shift_bias_kernel, dim3((unsigned)(sb.jobs * shift_bias_wgs(sb.N0, sb.N1))), dim3(1024), 0, s, sb);
+    }
     // ---- token embedding: x = fc2(gelu_tanh(fc1(x))) (+ xyz positional embedding)
     {
         EmbedArgs e{Mrows, D, m->in_channels, m->stage2, a->x, m->xe_fc1_w, m->xe_fc1_b, a->fps_xyz, m->xyz_w, m->xyz_b,
@@ -533,31 +591,57 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         GaGemmArgs go{};
         go.M = Mca; go.N = D; go.K = D; go.epilogue = GA_GEMM_EPI_RESIDUAL; go.A = w.att; go.lda = D; go.W = bw.ca_out_w; go.w_tiled = m->gemm_weights_tiled;
         go.bias = bw.ca_out_b; go.out = w.xres; go.ldo = D; go.gate = nullptr; go.rows_per_batch = L;
+        const float *sbias = w.sbias + (size_t)i * B * 7 * D;   // [B][3D] qkv | [B][4D] fc1
+        if (fold_mod) {
+            // norm1 folded: this GEMM runs over ALL rows -- the rows of the items that skipped the cross-attention take its output bias
+            // with a zero product (k_rows) -- and leaves bf16(x norm1.weight (1 + scale_msa)) in xn, the rows' sums of squares in rowss
+            go.M = Mrows; go.k_rows = Mca;
+            go.emit_x = w.xn; go.emit_ld = D; go.emit_ss = w.rowss; go.emit_w = bw.norm1_w; go.emit_scale = mod + 1 * D;
+            go.emit_scale_stride = 6 * (int64_t)D;
+        }
         GA_UNLESS(32, ga_gemm_bf16(&go, stream));
         // self-attention
         // (rows of the items that skipped the cross-attention pick up its output bias here)
         GaRmsNormArgs n1{Mrows, D, L, w.xres, bw.norm1_w, mod + 1 * D, mod + 0 * D, 6 * (int64_t)D, w.xn,
                          Mca < Mrows ? bw.ca_out_b : nullptr, Mca};
-        GA_UNLESS(4, ga_rmsnorm_modulate(&n1, stream));
+        if (!fold_mod) GA_UNLESS(4, ga_rmsnorm_modulate(&n1, stream));
         GaGemmArgs gqkv{};
         gqkv.M = Mrows; gqkv.N = 3 * D; gqkv.K = D; gqkv.epilogue = GA_GEMM_EPI_STORE_BF16; gqkv.A = w.xn; gqkv.lda = D;
         gqkv.W = bw.qkv_w; gqkv.w_tiled = m->gemm_weights_tiled; gqkv.bias = bw.qkv_b; gqkv.out = w.qkv; gqkv.ldo = 2 * D;   // q | k row-major ...
         gqkv.vt = w.vt; gqkv.vt_col0 = 2 * D; gqkv.vt_ld = Lp; gqkv.rows_per_batch = L;  // ... v transposed
         gqkv.qk_w0 = bw.q_norm_w; gqkv.qk_cols0 = D; gqkv.qk_w1 = bw.k_norm_w; gqkv.qk_cols1 = 2 * D;  // per-head q/k RMSNorm
+        if (fold_mod) {
+            gqkv.row_ss = w.rowss; gqkv.row_ss_tiles = D / 64; gqkv.row_ss_dim = D; gqkv.row_ss_eps = 1e-5f;
+            gqkv.bias = sbias; gqkv.bias_stride = 3 * (int64_t)D;
+        }
         GA_UNLESS(16, ga_gemm_bf16(&gqkv, stream));
         GaAttentionArgs sa{B, m->heads, L, L, w.qkv, w.qkv + D, w.vt, 2 * D, 2 * D, Lp, nullptr, nullptr, w.att, D};
-        GA_UNLESS(1, ga_attention_bf16(&sa, stream));
+        if (fold_mod && sb_tail && i + 1 < m->depth) {
+            const GaDitBlockWeights &nb = m->blocks[i + 1];
+            ShiftBiasJob job{{nb.qkv_w, nb.fc1_w}, {nb.qkv_b, nb.fc1_b}, w.mod + (size_t)(i + 1) * B * 6 * D, w.sbias + (size_t)(i + 1) * B * 7 * D,
+                             6 * (long long)D, 3 * (long long)D, 3 * D, 4 * D, D, B, m->gemm_weights_tiled};
+            GA_UNLESS(1, attention_with_tail(&sa, &job, stream));
+        } else
+            GA_UNLESS(1, ga_attention_bf16(&sa, stream));
         GaGemmArgs gp{};
         gp.M = Mrows; gp.N = D; gp.K = D; gp.epilogue = GA_GEMM_EPI_RESIDUAL; gp.A = w.att; gp.lda = D; gp.W = bw.proj_w; gp.w_tiled = m->gemm_weights_tiled;
         gp.bias = bw.proj_b; gp.out = w.xres; gp.ldo = D; gp.gate = mod + 2 * D; gp.gate_stride = 6 * (int64_t)D;
         gp.rows_per_batch = L;
+        if (fold_mod) {   // norm2 folded the same way: proj emits, fc1 consumes
+            gp.emit_x = w.xn; gp.emit_ld = D; gp.emit_ss = w.rowss; gp.emit_w = bw.norm2_w; gp.emit_scale = mod + 4 * D;
+            gp.emit_scale_stride = 6 * (int64_t)D;
+        }
         GA_UNLESS(16, ga_gemm_bf16(&gp, stream));
         // FusedMLP
         GaRmsNormArgs n2{Mrows, D, L, w.xres, bw.norm2_w, mod + 4 * D, mod + 3 * D, 6 * (int64_t)D, w.xn, nullptr, 0};
-        GA_UNLESS(4, ga_rmsnorm_modulate(&n2, stream));
+        if (!fold_mod) GA_UNLESS(4, ga_rmsnorm_modulate(&n2, stream));
         GaGemmArgs g1{};
         g1.M = Mrows; g1.N = 4 * D; g1.K = D; g1.epilogue = GA_GEMM_EPI_GELU_BF16; g1.A = w.xn; g1.lda = D; g1.W = bw.fc1_w; g1.w_tiled = m->gemm_weights_tiled;
         g1.bias = bw.fc1_b; g1.out = w.hmid; g1.ldo = 4 * D;
+        if (fold_mod) {
+            g1.row_ss = w.rowss; g1.row_ss_tiles = D / 64; g1.row_ss_dim = D; g1.row_ss_eps = 1e-5f;
+            g1.bias = sbias + (size_t)B * 3 * D; g1.bias_stride = 4 * (int64_t)D; g1.rows_per_batch = L;
+        }
         GA_UNLESS(8, ga_gemm_bf16(&g1, stream));
         GaGemmArgs g2{};
         g2.M = Mrows; g2.N = D; g2.K = 4 * D; g2.epilogue = GA_GEMM_EPI_RESIDUAL; g2.A = w.hmid; g2.lda = 4 * D;

@@ -19,7 +19,8 @@ class GaGemmArgs(ctypes.Structure):
                 ("bias", c_p), ("out", c_p), ("ldo", i64), ("gate", c_p), ("gate_stride", i64), ("rows_per_batch", i32),
                 ("vt", c_p), ("vt_col0", i32), ("vt_ld", i64), ("qk_w0", c_p), ("qk_w1", c_p), ("qk_cols0", i32),
                 ("qk_cols1", i32), ("emit_x", c_p), ("emit_ss", c_p), ("emit_ld", i64), ("row_ss", c_p),
-                ("row_ss_tiles", i32), ("row_ss_dim", i32), ("row_ss_eps", ctypes.c_float), ("w_tiled", i32)]
+                ("row_ss_tiles", i32), ("row_ss_dim", i32), ("row_ss_eps", ctypes.c_float), ("w_tiled", i32),
+                ("emit_w", c_p), ("emit_scale", c_p), ("emit_scale_stride", i64), ("bias_stride", i64), ("k_rows", i32)]
 
 
 class GaAttentionArgs(ctypes.Structure):
@@ -79,7 +80,7 @@ class GaDitForwardArgs(ctypes.Structure):
 
 
 DIT_EXPORTS = ("ga_gemm_bf16", "ga_attention_bf16", "ga_rmsnorm_modulate", "ga_small_linear", "ga_dit_workspace_bytes",
-               "ga_dit_cache_context", "ga_dit_forward", "ga_dit_sampler_advance", "ga_ode_dopri5_stage", "ga_ode_dopri5_finish",
+               "ga_dit_cache_context", "ga_dit_forward", "ga_dit_shift_bias", "ga_dit_sampler_advance", "ga_ode_dopri5_stage", "ga_ode_dopri5_finish",
                "ga_dit_version")
 _ERR = {-1: "GA_DIT_ERR_NULL_ARG", -2: "GA_DIT_ERR_BAD_SHAPE", -4: "GA_DIT_ERR_LAUNCH"}
 _bound = False
@@ -103,6 +104,8 @@ def lib():
         L.ga_dit_forward.argtypes = [ctypes.POINTER(GaDitModel), ctypes.POINTER(GaDitForwardArgs), c_p]
         L.ga_dit_sampler_advance.restype = ctypes.c_int
         L.ga_dit_sampler_advance.argtypes = [c_p, c_p, c_p, i32, c_p, i32, c_p, c_p]
+        L.ga_dit_shift_bias.restype = ctypes.c_int
+        L.ga_dit_shift_bias.argtypes = [c_p, i32, c_p, i32, i32, c_p, i64, i32, c_p, c_p]
         L.ga_ode_dopri5_stage.restype = ctypes.c_int
         L.ga_ode_dopri5_stage.argtypes = [ctypes.POINTER(GaOdeDopri5), i32, c_p]
         L.ga_ode_dopri5_finish.restype = ctypes.c_int
@@ -132,11 +135,13 @@ def _need_cuda(*ts):
 
 def gemm(A, W, bias=None, epilogue=EPI_STORE_BF16, out=None, gate=None, rows_per_batch=1, vt=None, vt_col0=0,
          qk_w0=None, qk_cols0=0, qk_w1=None, qk_cols1=0, emit_x=None, emit_ss=None, row_ss=None, row_ss_dim=0,
-         row_ss_eps=1e-5, w_tiled=False, N=None):
+         row_ss_eps=1e-5, w_tiled=False, N=None, emit_w=None, emit_scale=None, k_rows=0):
     """A [M,K] bf16, W [N,K] bf16 -> see ga_dit.h.  EPI_RESIDUAL accumulates into ``out`` (fp32 [M,N]).
     ``vt`` [B*heads*64, Lpad] bf16 (zero-initialised): columns >= vt_col0 are stored transposed there (V projection).
     ``qk_w0/qk_w1``: per-head RMSNorm weights for the column groups [0, qk_cols0) / [qk_cols0, qk_cols1).
-    ``emit_*`` (EPI_RESIDUAL) / ``row_ss`` (EPI_STORE_BF16): the folded un-modulated RMSNorm of ga_dit.h."""
+    ``emit_*`` (EPI_RESIDUAL) / ``row_ss`` (EPI_STORE_BF16, EPI_GELU_BF16): the folded RMSNorm of ga_dit.h; ``emit_w`` [N] and
+    ``emit_scale`` [B, N] fp32 make it the modulated one; a 2-d ``bias`` [B, N] is one bias row per batch item (``rows_per_batch``).
+    ``k_rows``: EPI_RESIDUAL rows >= k_rows get the epilogue with a zero product."""
     _need_cuda(A, W, bias, out, gate, vt)
     assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and A.stride(-1) == 1 and W.is_contiguous()
     M, K = A.shape
@@ -144,11 +149,14 @@ def gemm(A, W, bias=None, epilogue=EPI_STORE_BF16, out=None, gate=None, rows_per
     if out is None:
         out = torch.empty((M, N if vt is None else vt_col0), device=A.device,
                           dtype=torch.bfloat16 if epilogue in (EPI_STORE_BF16, EPI_GELU_BF16) else torch.float32)
+    M = out.shape[0] if k_rows else M       # (A may hold only the first k_rows rows)
     a = GaGemmArgs(M, N, K, epilogue, A.data_ptr(), A.stride(0), W.data_ptr(), _ptr(bias), out.data_ptr(), out.stride(0),
                    _ptr(gate), gate.stride(0) if gate is not None else 0, rows_per_batch, _ptr(vt), vt_col0,
                    vt.stride(0) if vt is not None else 0, _ptr(qk_w0), _ptr(qk_w1), qk_cols0, max(qk_cols1, qk_cols0),
                    _ptr(emit_x), _ptr(emit_ss), emit_x.stride(0) if emit_x is not None else 0,
-                   _ptr(row_ss), row_ss.shape[1] if row_ss is not None else 0, row_ss_dim, row_ss_eps, 1 if w_tiled else 0)
+                   _ptr(row_ss), row_ss.shape[1] if row_ss is not None else 0, row_ss_dim, row_ss_eps, 1 if w_tiled else 0,
+                   _ptr(emit_w), _ptr(emit_scale), emit_scale.stride(0) if emit_scale is not None else 0,
+                   bias.stride(0) if (bias is not None and bias.dim() == 2) else 0, k_rows)
     check(lib().ga_gemm_bf16(ctypes.byref(a), _stream(A)), "ga_gemm_bf16")
     return out
 
@@ -195,6 +203,19 @@ def rmsnorm_modulate(x, weight, scale=None, shift=None, rows_per_batch=1):
     a = GaRmsNormArgs(M, D, rows_per_batch, x.data_ptr(), weight.data_ptr(), _ptr(scale), _ptr(shift),
                       scale.stride(0) if scale is not None else 0, out.data_ptr(), None, 0)
     check(lib().ga_rmsnorm_modulate(ctypes.byref(a), _stream(x)), "ga_rmsnorm_modulate")
+    return out
+
+
+def shift_bias(W, shift, bias=None, w_tiled=False, N=None):
+    """W [N, K] bf16 (or its tiled image with ``N``), shift [B, K] fp32 rows -> bias[n] + shift_b . W[n] as fp32 [B, N]: the bias
+    rows of a GEMM behind a folded modulated RMSNorm (ga_dit.h)."""
+    _need_cuda(W, shift, bias)
+    B, K = shift.shape
+    N = W.shape[0] if N is None else N
+    assert shift.dtype == torch.float32 and shift.stride(1) == 1 and W.dtype == torch.bfloat16
+    out = torch.empty((B, N), device=W.device, dtype=torch.float32)
+    check(lib().ga_dit_shift_bias(W.data_ptr(), 1 if w_tiled else 0, _ptr(bias), N, K, shift.data_ptr(), shift.stride(0), B,
+                                  out.data_ptr(), _stream(W)), "ga_dit_shift_bias")
     return out
 
 

@@ -84,9 +84,29 @@ typedef struct GaGemmArgs {
      * contiguous in memory (N % 8 == 0).  Weights are packed once at load time; on weights that stream from HBM (a DiT evaluation
      * reads 600 MB of them) whole-KiB requests measured 3-6 % faster than eight 128-byte row pieces (tools/gemm_lab.hip). */
     int32_t w_tiled;
+    /* Round 4: folding a MODULATED RMSNorm, y = x * rsqrt(mean(x^2) + eps) * weight * (1 + scale_b) + shift_b (the adaLN pre-norms of
+     * the self-attention and the MLP: dit/dit_models_xformers.py:775-785), between a residual GEMM and the next projection:
+     *     y W^T = rsqrt(.) * ((x * weight * (1 + scale_b)) W^T) + shift_b W^T
+     *   producer (EPI 2 with emit_x / emit_ss), optional: emit_x[m][n] = bf16(x_new[m][n] * emit_w[n] * (1 + emit_scale[b][n])),
+     *     b = m / rows_per_batch, emit_scale rows emit_scale_stride elements apart; emit_ss stays the sum of the RAW x_new^2;
+     *   consumer (EPI 0 or 1): row_ss as above, applied to the accumulator BEFORE the bias, and the bias may be one row per batch
+     *     item -- bias[b * bias_stride + n], bias_stride != 0 -- holding bias[n] + sum_k shift_b[k] W[n][k] (ga_dit_shift_bias).
+     * k_rows (EPI 2, 0 = M): only the first k_rows rows of A take part in the product; the rows behind them get the epilogue with
+     *   a zero accumulator (x += gate * bias, and the emit) -- the batch items whose cross-attention is skipped (ca_batch) still
+     *   receive the output bias and the folded pre-norm of the next projection in the same launch.  A is not read past row k_rows. */
+    const float *emit_w, *emit_scale;
+    int64_t emit_scale_stride;
+    int64_t bias_stride;
+    int32_t k_rows;
 } GaGemmArgs;
 
 int ga_gemm_bf16(const GaGemmArgs *args, void *stream);
+
+/* out[b][n] = bias[n] + sum_k shift[b * shift_stride + k] * W[n][k]  (fp32; W [N, K] bf16, row-major or the tiled image; N % 8 == 0,
+ * K % 64 == 0; bias may be NULL): the per-batch bias row of a consumer GEMM behind a folded modulated RMSNorm (GaGemmArgs.bias_stride).
+ * ga_dit_forward computes these rows for every block's qkv and fc1 projection in one launch per evaluation. */
+int ga_dit_shift_bias(const ga_bf16 *W, int32_t w_tiled, const float *bias, int32_t N, int32_t K, const float *shift,
+                      int64_t shift_stride, int32_t batch, float *out, void *stream);
 
 /* softmax(q k^T / sqrt(64)) v with per-head RMSNorm of q and k fused on load (weights qn/kn, eps 1e-5; NULL = none):
  * what MemEffAttention / MemoryEfficientCrossAttention compute between their projections.  head_dim must be 64.

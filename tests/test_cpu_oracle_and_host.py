@@ -542,7 +542,8 @@ def test_committed_bench_line_follows_the_contract():
     cfg = d["config"]
     assert abs(d["value"] - cfg["points"] * cfg["views"] * d["n_gpus"] / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    # ("valu": round 3's review asked for the roof that binds; achieved / peak / frac stay the contract's HBM pair, valu_issue_frac beside)
+    assert r["bound"] in ("hbm", "mfma", "valu") and "valu_issue_frac" in r and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"] * 0.5
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
     c = d["cpu_baseline"]

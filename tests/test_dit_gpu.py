@@ -249,6 +249,71 @@ def test_folded_prenorm_pair_matches_the_unfused_sequence(gpu_device):
             assert rel_l2(y.float(), y_ref.float()) < 8e-3, (M, qk)
 
 
+def test_folded_modulated_prenorm_pair_matches_the_unfused_sequence(gpu_device):
+    """ga_dit.h 'folding a MODULATED RMSNorm': residual GEMM emitting bf16(x w (1 + scale_b)) and the raw sums of squares, then the
+    projection with row_ss and the per-batch bias rows bias + shift_b W^T (ga_dit_shift_bias), must equal residual GEMM ->
+    rmsnorm_modulate -> projection, for the plain and the GELU epilogue, with the q/k head norm + V^T store of the qkv projection,
+    and with rows behind k_rows taking only the bias (the skipped cross-attention).  Tiles whose rows straddle two batch items
+    (rows_per_batch not a multiple of the tile) take the per-row bias path."""
+    from gaussiananything_amd import dit_ops as ops
+    g = torch.Generator(device="cpu").manual_seed(33)
+    for (M, D, K, N2, nb) in ((200, 256, 128, 512, 3), (1536, 1024, 1024, 4096, 2), (1000, 768, 256, 768, 1), (1536, 1024, 1024, 3072, 2)):
+        rpb = (M + nb - 1) // nb
+        A = torch.randn(M, K, generator=g).to(gpu_device).bfloat16()
+        W1 = (torch.randn(D, K, generator=g) / K ** 0.5).to(gpu_device).bfloat16()
+        b1 = torch.randn(D, generator=g).to(gpu_device)
+        gate = torch.randn(nb, D, generator=g).to(gpu_device)
+        x0 = torch.randn(M, D, generator=g).to(gpu_device)
+        nw = (1 + 0.2 * torch.randn(D, generator=g)).to(gpu_device)
+        mod = (0.3 * torch.randn(nb, 6, D, generator=g)).to(gpu_device)
+        scale, shift = mod[:, 1], mod[:, 0]
+        W2 = (torch.randn(N2, D, generator=g) / D ** 0.5).to(gpu_device).bfloat16()
+        b2 = torch.randn(N2, generator=g).to(gpu_device)
+        for k_rows in (0, rpb if nb > 1 else 0):
+            if k_rows == 0 and M == 1536 and N2 == 3072:
+                continue
+            # --- unfused
+            x_ref = x0.clone()
+            if k_rows:
+                ops.gemm(A[:k_rows], W1, b1, ops.EPI_RESIDUAL, out=x_ref[:k_rows], rows_per_batch=rpb)
+                x_ref[k_rows:] += b1
+            else:
+                ops.gemm(A, W1, b1, ops.EPI_RESIDUAL, out=x_ref, gate=gate, rows_per_batch=rpb)
+            h = ops.rmsnorm_modulate(x_ref, nw, scale, shift, rows_per_batch=rpb)
+            # --- folded
+            x = x0.clone()
+            xb = torch.empty(M, D, device=gpu_device, dtype=torch.bfloat16)
+            ss = torch.full((M, D // 64), float("nan"), device=gpu_device)
+            ops.gemm(A[:k_rows] if k_rows else A, W1, b1, ops.EPI_RESIDUAL, out=x, gate=None if k_rows else gate, rows_per_batch=rpb,
+                     emit_x=xb, emit_ss=ss, emit_w=nw, emit_scale=scale, k_rows=k_rows)
+            assert torch.equal(x, x_ref), (M, k_rows)
+            mult = (nw[None] * (1 + scale)).repeat_interleave(rpb, 0)[:M]
+            assert torch.equal(xb, (x * mult).bfloat16())
+            assert torch.allclose(ss.sum(1), x.pow(2).sum(1), rtol=1e-5)
+            bias2 = ops.shift_bias(W2, shift, b2)
+            ref_b2 = b2[None] + shift @ W2.float().T
+            assert torch.allclose(bias2, ref_b2, rtol=1e-4, atol=1e-4)
+            bias2_t = ops.shift_bias(ops.tile_weight(W2), shift, b2, w_tiled=True, N=N2)
+            assert torch.equal(bias2, bias2_t)
+            if D % 256 or D > 1024:
+                continue            # (the consumer takes at most 16 partial sums per row, in groups of 4)
+            for epi in (ops.EPI_STORE_BF16, ops.EPI_GELU_BF16):
+                y_ref = ops.gemm(h, W2, b2, epi)
+                y = ops.gemm(xb, W2, bias2, epi, row_ss=ss, row_ss_dim=D, rows_per_batch=rpb)
+                assert rel_l2(y.float(), y_ref.float()) < 8e-3, (M, epi, k_rows)
+            if N2 == 3 * D:    # the qkv projection: per-head q / k norm and the transposed V store on top
+                qw = (1 + 0.2 * torch.randn(64, generator=g)).to(gpu_device)
+                kw_ = (1 + 0.2 * torch.randn(64, generator=g)).to(gpu_device)
+                Lp = (rpb + 63) // 64 * 64
+                outs = []
+                for (a_, bias_, extra) in ((h, b2, {}), (xb, bias2, dict(row_ss=ss, row_ss_dim=D))):
+                    vt = torch.zeros(nb * D, Lp, device=gpu_device, dtype=torch.bfloat16)
+                    qk = ops.gemm(a_, W2, bias_, ops.EPI_STORE_BF16, rows_per_batch=rpb, vt=vt, vt_col0=2 * D, qk_w0=qw, qk_cols0=D,
+                                  qk_w1=kw_, qk_cols1=2 * D, **extra)
+                    outs.append((qk.float(), vt.float()))
+                assert rel_l2(outs[1][0], outs[0][0]) < 8e-3 and rel_l2(outs[1][1], outs[0][1]) < 8e-3
+
+
 def test_small_linear(gpu_device):
     from gaussiananything_amd import dit_ops as ops
     g = torch.Generator(device="cpu").manual_seed(3)
