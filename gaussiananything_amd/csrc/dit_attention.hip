@@ -98,7 +98,8 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
     constexpr int TPS = (!KNORM && KS == 1) ? 2 : 1;
     static_assert(16 % NW == 0, "a tile is 16 one-KiB DMA pieces");
     __shared__ __attribute__((aligned(16))) uint16_t smem[KS * 6 * TPS * TILE];  // per key group: K[3][TPS][key][d], V^T[3][TPS][d][key]
-    static_assert(sizeof(smem) >= kSbLdsFloats * sizeof(float), "the tail's partial sums");
+    constexpr int kTailPairs = sizeof(smem) / (kSbLdsFloats * sizeof(float)) >= 4 ? 4 : (int)(sizeof(smem) / (kSbLdsFloats * sizeof(float)));
+    static_assert(kTailPairs >= 1, "the tail's partial sums");
     if (tail.job.W[0] != nullptr) {   // kernel-uniform
 #if GA_ATTN_HEAD_MAJOR
         const int slice = (int)blockIdx.y - tail.y0, in_slice = blockIdx.x, per_slice = gridDim.x;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
         const int slice = (int)blockIdx.z - tail.y0, in_slice = blockIdx.y * gridDim.x + blockIdx.x, per_slice = gridDim.x * gridDim.y;
 #endif
         if (slice >= 0) {             // workgroup-uniform
-            shift_bias_block(tail.job, slice * per_slice + in_slice, reinterpret_cast<float *>(smem));
+            shift_bias_block<kTailPairs>(tail.job, slice * per_slice + in_slice, reinterpret_cast<float *>(smem));
             return;
         }
     }
@@ -458,6 +459,12 @@ extern "C" int ga_attn_debug_stamps(unsigned long long *out)
 
 namespace gadit {
 static int dispatch_attention(const GaAttentionArgs *a, const ShiftBiasJob *job, void *stream);
+// workgroups of the launch dispatch_attention picks for this shape (no k-norm): a tail only pays while they leave CUs idle
+int attention_workgroups(const GaAttentionArgs *a)
+{
+    const int64_t wgs128 = (int64_t)((a->Lq + 127) / 128) * a->heads * a->batch;
+    return (int)(wgs128 <= 128 ? (int64_t)((a->Lq + 63) / 64) * a->heads * a->batch : wgs128);
+}
 int attention_with_tail(const GaAttentionArgs *a, const ShiftBiasJob *job, void *stream)
 {
     if (!job || !job->W[0] || !job->W[1] || !job->shift || !job->out) return GA_DIT_ERR_NULL_ARG;

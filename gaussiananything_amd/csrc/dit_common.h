@@ -56,6 +56,8 @@ __host__ __device__ __forceinline__ int shift_bias_wgs(int N0, int N1)
     return (N0 / 8 + kSbRows - 1) / kSbRows + (N1 / 8 + kSbRows - 1) / kSbRows;
 }
 
+// PAIRS: batch pairs served by one pass over the weights (LDS: PAIRS * kSbLdsFloats floats); larger batches take further passes
+template <int PAIRS>
 __device__ __forceinline__ void shift_bias_block(const ShiftBiasJob &j, int wg, float *lds)
 {
     const int nw = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -65,59 +67,67 @@ __device__ __forceinline__ void shift_bias_block(const ShiftBiasJob &j, int wg, 
     if (rg0 >= (N >> 3)) return;                                       // workgroup-uniform
     const int nr = min(kSbRows, (N >> 3) - rg0), K = j.K, nk = K >> 6;
     const int row = lane >> 3, ch = lane & 7;
-    const uint16_t *W = j.W[which];
     const float *bias = j.bias[which];
     float *out = j.out + (which ? (size_t)j.B * j.N0 : 0);
-    for (int b0 = 0; b0 < j.B; b0 += 2) {
-        const bool two = b0 + 1 < j.B;
-        const float *s0 = j.shift + (size_t)b0 * j.shift_batch_stride + (which ? j.shift_which_off : 0) + ch * 8;
-        const float *s1 = two ? s0 + j.shift_batch_stride : s0;
-        // byte offsets from the (scalar) weight base fit 32 bits: scalar base + per-lane offset addressing, no 64-bit address per load
-        const uint32_t lane_off = j.tiled ? (uint32_t)lane * 16u : ((uint32_t)row * K + ch * 8) * 2u;
-        const uint32_t rg_step = j.tiled ? (uint32_t)nk * 1024u : (uint32_t)K * 16u, kt_step = j.tiled ? 1024u : 128u;
-        const char *wb = reinterpret_cast<const char *>(W);
-        __syncthreads();                                               // (the previous pair's sums have been read)
+    // byte offsets from the (scalar) weight base fit 32 bits: scalar base + per-lane offset addressing, no 64-bit address per load
+    const uint32_t lane_off = j.tiled ? (uint32_t)lane * 16u : ((uint32_t)row * K + ch * 8) * 2u;
+    const uint32_t rg_step = j.tiled ? (uint32_t)nk * 1024u : (uint32_t)K * 16u, kt_step = j.tiled ? 1024u : 128u;
+    const char *wb = reinterpret_cast<const char *>(j.W[which]);
+    const size_t pair_floats = (size_t)kSbRows * nw * 16;              // lds[pair][row group][wave][row][2]
+    for (int b0 = 0; b0 < j.B; b0 += 2 * PAIRS) {
+        const int npairs = min(PAIRS, (j.B - b0 + 1) >> 1);
+        const float *sh = j.shift + (size_t)b0 * j.shift_batch_stride + (which ? j.shift_which_off : 0) + ch * 8;
+        __syncthreads();                                               // (the previous pass's sums have been read)
 #pragma unroll 1
         for (int i = 0; i < kSbTilesPerWave; ++i) {
             const int kt = w + i * nw;
             if (kt >= nk) break;                                       // wave-uniform
-            const float4 a0 = *reinterpret_cast<const float4 *>(s0 + kt * 64), a1 = *reinterpret_cast<const float4 *>(s0 + kt * 64 + 4);
-            const float4 c0 = *reinterpret_cast<const float4 *>(s1 + kt * 64), c1 = *reinterpret_cast<const float4 *>(s1 + kt * 64 + 4);
 #pragma unroll 1
             for (int h = 0; h < kSbRows; h += 8) {                     // 8 tile loads in flight per lane (the register budget of the hosts)
                 uint4 wv[8];
                 const uint32_t off0 = (uint32_t)rg0 * rg_step + (uint32_t)kt * kt_step + lane_off;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) wv[r] = *reinterpret_cast<const uint4 *>(wb + (off0 + (uint32_t)min(h + r, nr - 1) * rg_step));
+#pragma unroll 1
+                for (int bp = 0; bp < npairs; ++bp) {                  // every batch pair of the pass from the same registers
+                    const float *s0 = sh + (size_t)(2 * bp) * j.shift_batch_stride + kt * 64;
+                    const float *s1 = (b0 + 2 * bp + 1 < j.B) ? s0 + j.shift_batch_stride : s0;
+                    const float4 a0 = *reinterpret_cast<const float4 *>(s0), a1 = *reinterpret_cast<const float4 *>(s0 + 4);
+                    const float4 c0 = *reinterpret_cast<const float4 *>(s1), c1 = *reinterpret_cast<const float4 *>(s1 + 4);
+                    float *pl = lds + bp * pair_floats;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const uint4 x = wv[r];
-                    const float w0 = __uint_as_float(x.x << 16), w1 = __uint_as_float(x.x & 0xFFFF0000u), w2 = __uint_as_float(x.y << 16),
-                                w3 = __uint_as_float(x.y & 0xFFFF0000u), w4 = __uint_as_float(x.z << 16), w5 = __uint_as_float(x.z & 0xFFFF0000u),
-                                w6 = __uint_as_float(x.w << 16), w7 = __uint_as_float(x.w & 0xFFFF0000u);
-                    float v0 = (w0 * a0.x + w1 * a0.y) + (w2 * a0.z + w3 * a0.w) + (w4 * a1.x + w5 * a1.y) + (w6 * a1.z + w7 * a1.w);
-                    float v1 = (w0 * c0.x + w1 * c0.y) + (w2 * c0.z + w3 * c0.w) + (w4 * c1.x + w5 * c1.y) + (w6 * c1.z + w7 * c1.w);
-                    v0 += __shfl_xor(v0, 1, 64); v0 += __shfl_xor(v0, 2, 64); v0 += __shfl_xor(v0, 4, 64);
-                    v1 += __shfl_xor(v1, 1, 64); v1 += __shfl_xor(v1, 2, 64); v1 += __shfl_xor(v1, 4, 64);
-                    if (ch == 0) {                                     // this wave's own slot: its K-tiles add up here
-                        float2 *slot = reinterpret_cast<float2 *>(lds + (((size_t)(h + r) * nw + w) * 8 + row) * 2);
-                        const float2 prev = i ? *slot : make_float2(0.f, 0.f);
-                        *slot = make_float2(prev.x + v0, prev.y + v1);
+                    for (int r = 0; r < 8; ++r) {
+                        uint4 x = wv[r];
+                        asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));   // (unpack per pair: hoisted out of the bp loop the 64 floats spill)
+                        const float w0 = __uint_as_float(x.x << 16), w1 = __uint_as_float(x.x & 0xFFFF0000u), w2 = __uint_as_float(x.y << 16),
+                                    w3 = __uint_as_float(x.y & 0xFFFF0000u), w4 = __uint_as_float(x.z << 16), w5 = __uint_as_float(x.z & 0xFFFF0000u),
+                                    w6 = __uint_as_float(x.w << 16), w7 = __uint_as_float(x.w & 0xFFFF0000u);
+                        float v0 = (w0 * a0.x + w1 * a0.y) + (w2 * a0.z + w3 * a0.w) + (w4 * a1.x + w5 * a1.y) + (w6 * a1.z + w7 * a1.w);
+                        float v1 = (w0 * c0.x + w1 * c0.y) + (w2 * c0.z + w3 * c0.w) + (w4 * c1.x + w5 * c1.y) + (w6 * c1.z + w7 * c1.w);
+                        v0 += __shfl_xor(v0, 1, 64); v0 += __shfl_xor(v0, 2, 64); v0 += __shfl_xor(v0, 4, 64);
+                        v1 += __shfl_xor(v1, 1, 64); v1 += __shfl_xor(v1, 2, 64); v1 += __shfl_xor(v1, 4, 64);
+                        if (ch == 0) {                                 // this wave's own slot: its K-tiles add up here
+                            float2 *slot = reinterpret_cast<float2 *>(pl + (((size_t)(h + r) * nw + w) * 8 + row) * 2);
+                            const float2 prev = i ? *slot : make_float2(0.f, 0.f);
+                            *slot = make_float2(prev.x + v0, prev.y + v1);
+                        }
                     }
                 }
             }
         }
         if (w >= nk && lane < 16) {                                    // a wave without a K-tile: zero partial sums
-            for (int r = 0; r < kSbRows; ++r) lds[((size_t)r * nw + w) * 16 + lane] = 0.f;
+            for (int bp = 0; bp < npairs; ++bp)
+                for (int r = 0; r < kSbRows; ++r) lds[bp * pair_floats + ((size_t)r * nw + w) * 16 + lane] = 0.f;
         }
         __syncthreads();
-        for (int o = threadIdx.x; o < nr * 16; o += blockDim.x) {
-            const int r = o >> 4, rw = (o >> 1) & 7, bb = o & 1;
-            if (bb && !two) continue;
+        for (int o = threadIdx.x; o < npairs * nr * 16; o += blockDim.x) {
+            const int bp = o / (nr * 16), q = o - bp * (nr * 16), r = q >> 4, rw = (q >> 1) & 7, bb = q & 1;
+            const int bi = b0 + 2 * bp + bb;
+            if (bi >= j.B) continue;
             float sum = 0.f;
-            for (int ww = 0; ww < nw; ++ww) sum += lds[(((size_t)r * nw + ww) * 8 + rw) * 2 + bb];
+            for (int ww = 0; ww < nw; ++ww) sum += lds[bp * pair_floats + (((size_t)r * nw + ww) * 8 + rw) * 2 + bb];
             const int n = (rg0 + r) * 8 + rw;
-            out[(size_t)(b0 + bb) * N + n] = (bias ? bias[n] : 0.f) + sum;
+            out[(size_t)bi * N + n] = (bias ? bias[n] : 0.f) + sum;
         }
     }
 }
@@ -125,5 +135,6 @@ __device__ __forceinline__ void shift_bias_block(const ShiftBiasJob &j, int wg, 
 // dit_attention.hip: the attention launch with `tail` workgroups behind its grid that compute one ShiftBiasJob (the self-attention of a
 // CFG pair fills 192 of the 256 CUs with one 96-KiB-LDS workgroup each: the job's weight stream runs on the idle ones)
 int attention_with_tail(const GaAttentionArgs *a, const ShiftBiasJob *job, void *stream);
+int attention_workgroups(const GaAttentionArgs *a);
 
 }  // namespace gadit

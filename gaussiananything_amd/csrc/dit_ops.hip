@@ -179,7 +179,8 @@ struct ShiftBiasArgs {
 
 __global__ __launch_bounds__(1024) void shift_bias_kernel(ShiftBiasArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float sh[kSbLdsFloats];
+    constexpr int kPairs = 4;                                          // 8 batch items per pass over the weights: 64 KiB of partial sums
+    __shared__ __attribute__((aligned(16))) float sh[kPairs * kSbLdsFloats];
     ShiftBiasJob j;
     j.N0 = a.N0; j.N1 = a.N1; j.K = a.K; j.B = a.B; j.tiled = a.tiled;
     const int wgs = shift_bias_wgs(a.N0, a.N1);                        // workgroups per block of the model (grid = jobs * wgs)
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(1024) void shift_bias_kernel(ShiftBiasArgs a)
     j.W[0] = a.W[2 * blk]; j.W[1] = a.W[2 * blk + 1]; j.bias[0] = a.bias[2 * blk]; j.bias[1] = a.bias[2 * blk + 1];
     j.shift = a.shift + (size_t)blk * a.shift_block_stride; j.out = a.out + (size_t)blk * a.out_block_stride;
     j.shift_batch_stride = a.shift_batch_stride; j.shift_which_off = a.shift_which_off;
-    shift_bias_block(j, blockIdx.x - blk * wgs, sh);
+    shift_bias_block<kPairs>(j, blockIdx.x - blk * wgs, sh);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -538,8 +539,18 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     }
     // the modulated pre-norms of the self-attention and the MLP fold into the neighbouring GEMMs like the cross-attention's (below):
     // their shifts go through the qkv / fc1 weights once per evaluation, for all blocks in one launch
-    const bool fold_mod = can_fold(m, 0) && m->depth <= 64;
-    static const bool sb_tail = [] { const char *e = getenv("GA_DIT_SBTAIL"); return !e || atoi(e) != 0; }();
+    // (measured, DiT-L: 1536 rows 3.42 -> 3.22 ms per evaluation, DiT-B 1.49 -> 1.40; at 6144 rows the stand-alone norm launches are
+    //  bandwidth-sized and the fold is 1 % behind -- left off there)
+    static const bool fold_mod_env = [] { const char *e = getenv("GA_DIT_FOLD_MOD"); return !e || atoi(e) != 0; }();   // A/B aid
+    const bool fold_mod = fold_mod_env && can_fold(m, 0) && m->depth <= 64 && Mrows <= 3072;
+    static const bool sb_tail_env = [] { const char *e = getenv("GA_DIT_SBTAIL"); return !e || atoi(e) != 0; }();
+    // the shift rows of block i + 1 ride behind the self-attention grid of block i while that grid leaves CUs idle (a CFG pair: 192
+    // workgroups + 56 of the tail on 256 CUs); on a full grid they would queue behind it (8 items: 9.2 -> 9.8 ms) -- one launch up front then
+    bool sb_tail = false;
+    if (fold_mod && sb_tail_env) {
+        const GaAttentionArgs probe{B, m->heads, L, L, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0};
+        sb_tail = attention_workgroups(&probe) + shift_bias_wgs(3 * D, 4 * D) <= 256;
+    }
     if (fold_mod) {
         ShiftBiasArgs sb{};
         for (int i = 0; i < m->depth; ++i) {

@@ -314,6 +314,23 @@ def test_folded_modulated_prenorm_pair_matches_the_unfused_sequence(gpu_device):
                 assert rel_l2(outs[1][0], outs[0][0]) < 8e-3 and rel_l2(outs[1][1], outs[0][1]) < 8e-3
 
 
+@pytest.mark.parametrize("B,N,K", [(1, 64, 64), (9, 3072, 1024), (4, 520, 2048), (16, 4096, 1024)])
+def test_shift_bias_rows(gpu_device, B, N, K):
+    """ga_dit_shift_bias: bias + shift_b . W rows in fp32 from the bf16 weight, every batch size (one pass over the weights serves 8
+    batch items), a ragged last row-group block, both weight layouts bit-identical."""
+    from gaussiananything_amd import dit_ops as ops
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + N)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(gpu_device).bfloat16()
+    bias = torch.randn(N, generator=g).to(gpu_device)
+    mod = torch.randn(B, 6, K, generator=g).to(gpu_device)
+    shift = mod[:, 3]                                      # a strided view, as the model's modulation table is
+    out = ops.shift_bias(W, shift, bias)
+    ref = bias[None].double() + shift.double() @ W.double().T
+    assert torch.allclose(out.double(), ref, rtol=1e-4, atol=1e-4)
+    assert torch.equal(out, ops.shift_bias(ops.tile_weight(W), shift, bias, w_tiled=True, N=N))
+    assert torch.allclose(ops.shift_bias(W, shift, None).double(), ref - bias[None].double(), rtol=1e-4, atol=1e-4)
+
+
 def test_small_linear(gpu_device):
     from gaussiananything_amd import dit_ops as ops
     g = torch.Generator(device="cpu").manual_seed(3)

@@ -60,7 +60,8 @@ def main():
     json.dump({"_comment": "MFMA busy = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs) of the two attention launches of "
                            "bench.py's `attention` section (tools/dit_kernels_two.py attn; profiles/r4_attention_pmc.txt)",
                "kernels": att, "source": "profiles/r4_attention_pmc.txt",
-               "source_sha256": {rel: sha(rel) for rel in ("gaussiananything_amd/csrc/dit_attention.hip", "gaussiananything_amd/csrc/Makefile")}},
+               "source_sha256": {rel: sha(rel) for rel in ("gaussiananything_amd/csrc/dit_attention.hip", "gaussiananything_amd/csrc/dit_common.h",
+                                                         "gaussiananything_amd/csrc/Makefile")}},
               open(os.path.join(ROOT, "profiles", "r4_attention_pmc.json"), "w"), indent=1)
     print(json.dumps(blend, indent=1)[:600])
     print(json.dumps(att, indent=1))
