@@ -31,6 +31,7 @@ namespace gadit {
 #define GA_GEMM_ABLATE 0   // tools/gemm_ablate.sh: timing-only builds with phases removed (wrong results); bit mask:
                            // 1 MFMAs, 2 DMA in the K loop, 4 barrier, 8 epilogue, 16 fragment reads; 32 = no K loop at all
 #endif
+__device__ __attribute__((aligned(16))) const float g_zero_line[4] = {0.f, 0.f, 0.f, 0.f};   // stands in for an absent epilogue operand
 constexpr int BN = 128, BK = 64;
 constexpr int TILE_ELEMS = 128 * BK;  // one operand tile: 128 rows x 64 bf16 = 16 KiB
 
@@ -180,15 +181,19 @@ __device__ __forceinline__ void rowss_prefetch(const GemmP &p, RowSsPrefetch<MT>
 // FN = 16-column fragments per wave: 4 (the wave's 64 columns are one attention head / one emit_ss group) or 2 (32 columns: no
 // per-head RMSNorm, no V^T store; the row sums of squares of a 64-column group are returned in `emit_part` for the caller to
 // combine across the two waves of the group)
-template <int EPI, int MT, int FN, bool PRE, bool RSSPRE>
+template <int EPI, int MT, int FN, bool PRE, bool RSSPRE, bool PREONLY = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[FN][MT], const ResidualPrefetch<MT> *pre,
                                               const RowSsPrefetch<MT> *rss, int mrow0, int ncol0, int lane, float *emit_part = nullptr,
                                               const f32x4 *bias_pre = nullptr, const f32x4 *qkw_pre = nullptr,
-                                              float *qk_mine = nullptr, const float *qk_other = nullptr, bool bias_pre_ok = true,
-                                              const f32x4 (*emul_pre)[2] = nullptr, bool emul_pre_ok = false)
+                                              float *qk_mine = nullptr, const float *qk_other = nullptr,
+                                              const f32x4 (*emul_pre)[2] = nullptr)
 {
-    // (bias_pre_ok false: the wave's rows straddle two batch items of a per-batch bias -- fetched per row below.  A flag, not a null
-    //  pointer: selecting between the caller's register array and nullptr sends the array to scratch)
+    // PREONLY (the ring kernels): every per-column operand -- bias row, emit multipliers -- was requested before the K loop and NO load
+    // is compiled into the row loop below.  A load that MAY have been issued makes the compiler wait for vmcnt(0) where the paths
+    // join, and on gfx950 that counter also holds the output stores of the previous row fragment: the epilogue then runs one row
+    // fragment per memory round trip (measured: every GEMM of the evaluation 0.5 ... 2 us longer).  The dispatcher sends shapes whose
+    // waves straddle two batch items of a per-batch operand to the general kernel instead.
+    // (never select between the caller's register array and nullptr at run time: that sends the array to scratch)
     static_assert(FN == 4 || FN == 2, "a wave owns 64 or 32 columns");
     const int M = p.M, N = p.N;
     // epilogue: lane holds acc[i][j][r] = C[m = mrow0 + j*16 + (lane&15)][n = ncol0 + i*16 + (lane>>4)*4 + r];
@@ -231,11 +236,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[FN][M
         }
         // (the bias after the row scale: with a folded modulated norm it carries shift_b W^T, which is not scaled)
         const float *brow = p.bias;
-        if (!(bias_pre && bias_pre_ok) && p.bias && p.bias_stride) brow += (size_t)(min(m, M - 1) / p.rows_per_batch) * p.bias_stride;
+        if (!PREONLY && !bias_pre && p.bias && p.bias_stride) brow += (size_t)(min(m, M - 1) / p.rows_per_batch) * p.bias_stride;
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
             const int n = nhead + i * 16 + g * 4;
-            if (bias_pre && bias_pre_ok) {        // requested before the K loop (zero without a bias)
+            if (PREONLY || bias_pre) {            // requested before the K loop (zero without a bias)
                 v[i][0] += bias_pre[i][0]; v[i][1] += bias_pre[i][1]; v[i][2] += bias_pre[i][2]; v[i][3] += bias_pre[i][3];
             } else if (p.bias && n < N) {
                 const float4 b = *reinterpret_cast<const float4 *>(brow + n);
@@ -359,13 +364,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[FN][M
                     if (p.emit_x) {  // kernel-uniform; N % 64 == 0, so `hi` holds
 #pragma unroll
                         for (int e = 0; e < 8; ++e) emit_acc += xn[e] * xn[e];
-                        if (p.emit_w && emul_pre && emul_pre_ok) {   // (requested before the K loop: one batch item per wave)
+                        if (p.emit_w && (PREONLY || emul_pre)) {   // (requested before the K loop: one batch item per wave)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 xn[e] *= emul_pre[q][0][e] * (1.f + emul_pre[FN / 2 + q][0][e]);
                                 xn[4 + e] *= emul_pre[q][1][e] * (1.f + emul_pre[FN / 2 + q][1][e]);
                             }
-                        } else if (p.emit_w) {   // kernel-uniform: the modulated pre-norm's w (1 + scale_b), applied before the bf16 rounding
+                        } else if (!PREONLY && p.emit_w) {   // kernel-uniform: the modulated pre-norm's w (1 + scale_b), applied before the bf16 rounding
                             const float *sc = p.emit_scale + (size_t)(m / p.rows_per_batch) * p.emit_scale_stride + n;
                             const float4 w0 = *reinterpret_cast<const float4 *>(p.emit_w + n), w1 = *reinterpret_cast<const float4 *>(p.emit_w + n + 4);
                             const float4 s0 = *reinterpret_cast<const float4 *>(sc), s1 = *reinterpret_cast<const float4 *>(sc + 4);
@@ -617,19 +622,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
     // the residual rows and gates.  Without this the epilogue starts with a dependent L2 / HBM round trip per operand.
     f32x4 bias_pre[FN], qkw_pre[FN];
     const float *bias_row = p.bias;
-    bool bias_one_row = true;     // wave-uniform: all rows of this wave take the same bias row (else the epilogue fetches per row)
-    if (p.bias && p.bias_stride) {
-        const int b0 = min(mrow0, M - 1) / p.rows_per_batch, b1 = min(mrow0 + FM * 16 - 1, M - 1) / p.rows_per_batch;
-        bias_one_row = b0 == b1;
-        bias_row += (size_t)b0 * p.bias_stride;
-    }
+    // (a per-batch bias: all rows of a wave lie in one batch item -- rows_per_batch % (FM * 16) == 0, checked by the dispatcher)
+    if (p.bias && p.bias_stride) bias_row += (size_t)(min(mrow0, M - 1) / p.rows_per_batch) * p.bias_stride;
+    // (no branch around these loads: an absent operand is read from a zero line instead.  With branches the register allocator
+    //  merged the two paths through copies of the loaded registers -- s_waitcnt vmcnt(0) in front of the first DMA request.)
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
-        bias_pre[i] = qkw_pre[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
-            const float4 b = *reinterpret_cast<const float4 *>(bias_row + min(ncol0 + i * 16 + lg * 4, N - 4));
-            bias_pre[i] = f32x4{b.x, b.y, b.z, b.w};
-        }
+        qkw_pre[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float4 b = *reinterpret_cast<const float4 *>(p.bias ? bias_row + min(ncol0 + i * 16 + lg * 4, N - 4) : g_zero_line);
+        bias_pre[i] = f32x4{b.x, b.y, b.z, b.w};
     }
     if (EPI == GA_GEMM_EPI_STORE_BF16) {
         const float *qkw = ncol0 < p.qk_cols0 ? p.qk_w0 : (ncol0 < p.qk_cols1 ? p.qk_w1 : nullptr);
@@ -644,19 +645,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
     // the emit multipliers w (1 + scale_b) of a folded modulated pre-norm, in the exchanged 8-column layout of the epilogue
     constexpr int EQ = EPI == GA_GEMM_EPI_RESIDUAL ? FN / 2 : 1;
     f32x4 emul[2 * EQ][2];     // [q]: norm weight, [EQ + q]: scale -- combined in the epilogue (no wait on these loads before the K loop)
-    bool emul_ok = false;
 #pragma unroll
     for (int q = 0; q < 2 * EQ; ++q) emul[q][0] = emul[q][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (EPI == GA_GEMM_EPI_RESIDUAL && p.emit_w) {
-        const int b0 = min(mrow0, M - 1) / p.rows_per_batch, b1 = min(mrow0 + FM * 16 - 1, M - 1) / p.rows_per_batch;
-        emul_ok = b0 == b1;
-        const float *sc = p.emit_scale + (size_t)b0 * p.emit_scale_stride;
+    if (EPI == GA_GEMM_EPI_RESIDUAL) {
+        const bool em = p.emit_w != nullptr;   // kernel-uniform
+        const float *sc = em ? p.emit_scale + (size_t)(min(mrow0, M - 1) / max(p.rows_per_batch, 1)) * p.emit_scale_stride : nullptr;
 #pragma unroll
         for (int q = 0; q < EQ; ++q) {
             const int n = min(ncol0 + q * 32 + (lg & 1) * 16 + (lg >> 1) * 8, N - 8);
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                const float4 w4 = *reinterpret_cast<const float4 *>(p.emit_w + n + 4 * hh), s4 = *reinterpret_cast<const float4 *>(sc + n + 4 * hh);
+                const float4 w4 = *reinterpret_cast<const float4 *>(em ? p.emit_w + n + 4 * hh : g_zero_line);
+                const float4 s4 = *reinterpret_cast<const float4 *>(em ? sc + n + 4 * hh : g_zero_line);
                 emul[q][hh] = f32x4{w4.x, w4.y, w4.z, w4.w};
                 emul[EQ + q][hh] = f32x4{s4.x, s4.y, s4.z, s4.w};
             }
@@ -779,8 +779,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
     }   // product
 
     if constexpr (FN == 4) {
-        gemm_epilogue<EPI, FM, 4, PRE, RSS>(p, acc, reinterpret_cast<const ResidualPrefetch<FM> *>(&pre),
-                                            reinterpret_cast<const RowSsPrefetch<FM> *>(&rss), mrow0, ncol0, lane, nullptr, bias_pre, qkw_pre, nullptr, nullptr, bias_one_row, emul, emul_ok);
+        gemm_epilogue<EPI, FM, 4, PRE, RSS, true>(p, acc, reinterpret_cast<const ResidualPrefetch<FM> *>(&pre),
+                                                  reinterpret_cast<const RowSsPrefetch<FM> *>(&rss), mrow0, ncol0, lane, nullptr, bias_pre, qkw_pre, nullptr, nullptr, emul);
     } else {
         // 32-column waves: the two waves of a 64-column group add their row sums of squares through LDS (the ring is idle now)
         static_assert(WN == 2, "a 64-column tile is two 32-column waves");
@@ -789,10 +789,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
         // the workgroup's 64 columns are a q or k head with a per-head RMSNorm: its two waves exchange their halves of the row sums
         const bool qk2 = EPI == GA_GEMM_EPI_STORE_BF16 && n0 < p.qk_cols1;   // workgroup-uniform
         if (emit || qk2) __syncthreads();
-        gemm_epilogue<EPI, FM, 2, PRE, RSS>(p, acc, reinterpret_cast<const ResidualPrefetch<FM> *>(&pre),
+        gemm_epilogue<EPI, FM, 2, PRE, RSS, true>(p, acc, reinterpret_cast<const ResidualPrefetch<FM> *>(&pre),
                                             reinterpret_cast<const RowSsPrefetch<FM> *>(&rss), mrow0, ncol0, lane, part, bias_pre, qkw_pre,
                                             qk2 ? part : nullptr,
-                                            reinterpret_cast<const float *>(smem) + ((wn ^ 1) * WM + wm) * FM * 16, bias_one_row, emul, emul_ok);
+                                            reinterpret_cast<const float *>(smem) + ((wn ^ 1) * WM + wm) * FM * 16, emul);
         if (emit) {
             __syncthreads();
             const float *all = reinterpret_cast<const float *>(smem);
@@ -861,13 +861,17 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
         const long long wg_mid = (long long)((a->N + 63) / 64) * ((a->M + 95) / 96);
         const long long wg_small = (long long)((a->N + 63) / 64) * ((a->M + 63) / 64);
         int ring = 0;
+        // per-batch operands (bias rows, emit multipliers) are requested once per wave in the ring kernels: a wave's 48 (16) rows must
+        // lie in one batch item
+        const bool per_batch = a->bias_stride != 0 || a->emit_scale != nullptr;
+        const bool rows48 = !per_batch || a->rows_per_batch % 48 == 0, rows16 = !per_batch || a->rows_per_batch % 16 == 0;
         if (nk % 4 == 0 && nk >= 8) {
-            if (wg_big >= 160) ring = 1;
+            if (wg_big >= 160 && rows48) ring = 1;
             // (per-head norm on the 96 x 64 tile: its two 32-column waves exchange their sums through LDS, a barrier more than the
             //  64-column waves of the other tiles need -- worth it while the grid is one residency round, 2 x 256 workgroups:
             //  DiT-L's qkv at M = 768 13.4 -> 12.1 us; DiT-B's at M = 1536, 576 workgroups, is faster on 64 x 64, same-box A/B)
-            else if (wg_mid >= 160 && (!(a->qk_cols0 || a->qk_cols1) || wg_mid <= 512)) ring = 2;
-            else if (wg_small >= 96) ring = 3;
+            else if (wg_mid >= 160 && rows48 && (!(a->qk_cols0 || a->qk_cols1) || wg_mid <= 512)) ring = 2;
+            else if (wg_small >= 96 && rows16) ring = 3;
         }
 #ifdef GA_TUNING  // tuning builds only: GA_GEMM_RING = 0 old kernel, 1 / 2 / 3 force a ring tile
         if (const char *e = getenv("GA_GEMM_RING")) { const int c = atoi(e); if (c == 0 || (nk % 4 == 0 && nk >= 8 && c >= 1 && c <= 3)) ring = c; }
