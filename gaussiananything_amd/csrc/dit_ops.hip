@@ -542,7 +542,8 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     // (measured, DiT-L: 1536 rows 3.42 -> 3.22 ms per evaluation, DiT-B 1.49 -> 1.40; at 6144 rows the stand-alone norm launches are
     //  bandwidth-sized and the fold is 1 % behind -- left off there)
     static const bool fold_mod_env = [] { const char *e = getenv("GA_DIT_FOLD_MOD"); return !e || atoi(e) != 0; }();   // A/B aid
-    const bool fold_mod = fold_mod_env && can_fold(m, 0) && m->depth <= 64 && Mrows <= 3072;
+    static const int fold_rows = [] { const char *e = getenv("GA_DIT_FOLD_ROWS"); return e ? atoi(e) : 3072; }();                      // A/B aid
+    const bool fold_mod = fold_mod_env && can_fold(m, 0) && m->depth <= 64 && Mrows <= fold_rows;
     static const bool sb_tail_env = [] { const char *e = getenv("GA_DIT_SBTAIL"); return !e || atoi(e) != 0; }();
     // the shift rows of block i + 1 ride behind the self-attention grid of block i while that grid leaves CUs idle (a CFG pair: 192
     // workgroups + 56 of the tail on 256 CUs); on a full grid they would queue behind it (8 items: 9.2 -> 9.8 ms) -- one launch up front then
