@@ -729,3 +729,37 @@ def test_backward_segment_numbers_in_closed_form_do_not_collide():
         assert np.all(nxt - (first + nseg) <= 1)             # at most one unused number
         capacity = int(start[-1])
         assert int(nxt[-1]) <= capacity // 128 + tiles       # < the capacity / 128 + tiles + 1 rows allocated
+
+
+def test_ctypes_mirrors_have_the_layout_of_the_c_headers(tmp_path):
+    """Every argument struct the Python host passes through the C-ABI is declared twice: in include/*.h and as a ctypes.Structure.
+    A C program compiled against the headers prints sizeof and every field's offsetof; they must be what ctypes computes for the
+    mirror (same field names, same order, same padding) -- a field appended on one side only would otherwise shift silently."""
+    import ctypes
+    import importlib
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mirrors = []
+    for mod in ("gaussiananything_amd._lib", "gaussiananything_amd.dit_ops", "gaussiananything_amd.decode_ops"):
+        m = importlib.import_module(mod)
+        for name in dir(m):
+            obj = getattr(m, name)
+            if isinstance(obj, type) and issubclass(obj, ctypes.Structure) and name.startswith("Ga") and obj.__module__ == mod:
+                mirrors.append(obj)
+    assert len(mirrors) >= 20
+    lines = ["#include <stddef.h>", "#include <stdio.h>"] + [f'#include "{h}"' for h in sorted(os.listdir(os.path.join(root, "include")))]
+    lines.append("int main(void) {")
+    for cls in mirrors:
+        lines.append(f'  printf("{cls.__name__} %zu\\n", sizeof({cls.__name__}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cls.__name__}.{fname} %zu\\n", offsetof({cls.__name__}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), "-o", str(exe), str(src)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cls in mirrors:
+        assert int(got[cls.__name__]) == ctypes.sizeof(cls), cls.__name__
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cls.__name__}.{fname}"]) == getattr(cls, fname).offset, (cls.__name__, fname)
