@@ -763,3 +763,26 @@ def test_ctypes_mirrors_have_the_layout_of_the_c_headers(tmp_path):
         assert int(got[cls.__name__]) == ctypes.sizeof(cls), cls.__name__
         for fname, _ in cls._fields_:
             assert int(got[f"{cls.__name__}.{fname}"]) == getattr(cls, fname).offset, (cls.__name__, fname)
+
+
+def test_the_algebra_of_the_folded_modulated_prenorm():
+    """What the GEMM epilogues of the denoiser rely on (include/ga_dit.h, 'folding a MODULATED RMSNorm'), in fp64 on the oracle's own
+    RMSNorm: (norm(x) w (1 + scale_b) + shift_b) W^T + bias  ==  rsqrt(mean x^2 + eps) ((x w (1 + scale_b)) W^T) + (bias + shift_b W^T),
+    with the row sums of squares taken in 64-column groups of the RAW x, and a row that skipped the producer's product (k_rows)."""
+    from oracle import dit as od
+    g = torch.Generator().manual_seed(5)
+    B, L, D, N = 3, 7, 256, 192
+    x = torch.randn(B * L, D, generator=g, dtype=torch.float64) * 3
+    w = 1 + 0.2 * torch.randn(D, generator=g, dtype=torch.float64)
+    scale, shift = (0.3 * torch.randn(2, B, D, generator=g, dtype=torch.float64)).unbind(0)
+    W = torch.randn(N, D, generator=g, dtype=torch.float64) / D ** 0.5
+    bias = torch.randn(N, generator=g, dtype=torch.float64)
+    rep = lambda v: v.repeat_interleave(L, 0)
+    normed = od.rmsnorm(x, w)
+    ref = (normed * (1 + rep(scale)) + rep(shift)) @ W.T + bias
+    emit = x * (w[None] * (1 + rep(scale)))                                   # producer: emit_x (before the bf16 rounding)
+    ss = x.pow(2).reshape(B * L, D // 64, 64).sum(-1)                         # producer: emit_ss partial sums
+    rs = torch.rsqrt(ss.sum(-1, keepdim=True) / D + 1e-5)                     # consumer: row_ss
+    bias_rows = bias[None] + shift @ W.T                                      # ga_dit_shift_bias
+    out = rs * (emit @ W.T) + rep(bias_rows)
+    assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)        # (the oracle's norm takes its mean in fp32)
