@@ -77,11 +77,14 @@ __device__ __forceinline__ void static_for(F &&f)
 // MF: MFMA edge (16: v_mfma_f32_16x16x32_bf16, 32: v_mfma_f32_32x32x16_bf16); WM x WN waves; FM x FN fragments per wave;
 // NST ring slots; PIPE 0: all fragment reads of a K-tile, then its MFMAs; 1: k-step software pipeline (fragments of the next
 // k-step requested before the MFMAs of the current one, tile hand-over inside the last k-step); EPI 0 bias, 1 bias + GELU
-template <int MF, int WM, int WN, int FM, int FN, int NST, int PIPE, int EPI, int R, int ABL = 0>
-__global__ __launch_bounds__(64 * WM * WN) void lab_kernel(P p)
+// WK (round 4, PIPE 0 / MF 16 only): WK wave groups share the tile, group wk takes the k-steps wk * KS/WK ... of every K-tile (same LDS
+// traffic, twice the waves per SIMD to hide ds_read -> MFMA latency); the groups' accumulators meet in LDS after the K loop
+template <int MF, int WM, int WN, int FM, int FN, int NST, int PIPE, int EPI, int R, int ABL = 0, int WK = 1>
+__global__ __launch_bounds__(64 * WM * WN * WK) void lab_kernel(P p)
 {
     using acc_t = typename AccT<MF>::T;
-    constexpr int NW = WM * WN, BM = WM * FM * MF, BN = WN * FN * MF, BK = 64;
+    static_assert(WK == 1 || (PIPE == 0 && MF == 16 && EPI < 2), "the k-step split is built for the batch-read loop");
+    constexpr int NW = WM * WN * WK, BM = WM * FM * MF, BN = WN * FN * MF, BK = 64;
     constexpr int KS = MF == 16 ? 2 : 4;   // k-steps per K-tile
     constexpr int CPK = 8 / KS;            // 16-byte chunks per k-step
     constexpr int ROWS = BN + BM;
@@ -93,7 +96,8 @@ __global__ __launch_bounds__(64 * WM * WN) void lab_kernel(P p)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave / WM, wm = wave % WM;
+    const int wk = wave / (WM * WN), w2 = wave % (WM * WN);
+    const int wn = w2 / WM, wm = w2 % WM;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
     const int M = p.M, N = p.N, K = p.K;
     // ABL (timing-only ablations, wrong results): 1 no output stores, 2 every workgroup reads the A rows of tile 0, 4 ... the W rows
@@ -173,13 +177,26 @@ __global__ __launch_bounds__(64 * WM * WN) void lab_kernel(P p)
             WAIT_VM(decltype(flyc)::value * DPT);
             __builtin_amdgcn_s_barrier();
             if constexpr (decltype(stagec)::value) stage(std::integral_constant<int, (b + NST - 1) % NST>{}, kt + NST - 1);
-            bf16x8 fw[KS][FN], fa[KS][FM];
-            static_for<0, KS>([&](auto ksc) __attribute__((always_inline)) {
-                read_frags(bc, ksc, fw[decltype(ksc)::value], fa[decltype(ksc)::value]);
-            });
+            constexpr int KSW = KS / WK;       // k-steps of this wave group
+            bf16x8 fw[KSW][FN], fa[KSW][FM];
+            if constexpr (WK == 1) {
+                static_for<0, KS>([&](auto ksc) __attribute__((always_inline)) {
+                    read_frags(bc, ksc, fw[decltype(ksc)::value], fa[decltype(ksc)::value]);
+                });
+            } else {
+                const uint16_t *bw = smem + b * SLOT, *ba = bw + BN * BK;
+#pragma unroll
+                for (int t = 0; t < KSW; ++t) {
+                    const int off = lane_off ^ ((wk * KSW + t) * CPK * 8);
+#pragma unroll
+                    for (int i = 0; i < FN; ++i) fw[t][i] = *reinterpret_cast<const bf16x8 *>(bw + (wn * FN + i) * MF * BK + off);
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) fa[t][j] = *reinterpret_cast<const bf16x8 *>(ba + (wm * FM + j) * MF * BK + off);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) mfmas(fw[ks], fa[ks]);
+            for (int ks = 0; ks < KSW; ++ks) mfmas(fw[ks], fa[ks]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
         int kt = 0;
@@ -276,6 +293,26 @@ __global__ __launch_bounds__(64 * WM * WN) void lab_kernel(P p)
         });
     }
 
+    if constexpr (WK > 1) {   // the wave groups' partial accumulators meet in LDS (the ring is idle); group 0 carries on
+        __syncthreads();
+        f32x4 *red = reinterpret_cast<f32x4 *>(smem);
+        static_assert(WK == 2, "one hand-over");
+        if (wk == 1) {
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j) red[((w2 * FN + i) * FM + j) * 64 + lane] = acc[i][j];
+        }
+        __syncthreads();
+        if (wk == 1) return;
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                const f32x4 o = red[((w2 * FN + i) * FM + j) * 64 + lane];
+                acc[i][j][0] += o[0]; acc[i][j][1] += o[1]; acc[i][j][2] += o[2]; acc[i][j][3] += o[3];
+            }
+    }
     // epilogue: bias (+ GELU), 16-byte bf16 stores after a lane-pair exchange
     if (EPI >= 2) __syncthreads();
     const int nbase = n0 + wn * FN * MF, mbase = m0 + wm * FM * MF;
@@ -383,16 +420,16 @@ struct Bufs {
 static const char *g_filter = nullptr;
 static int g_iters = 200, g_pada = 0, g_padw = 0, g_pado = 0, g_wtiled = 0;
 
-template <int MF, int WM, int WN, int FM, int FN, int NST, int PIPE, int EPI, int R, int ABL = 0>
+template <int MF, int WM, int WN, int FM, int FN, int NST, int PIPE, int EPI, int R, int ABL = 0, int WK = 1>
 static void run_variant_r(const char *name, const Shape &s, Bufs &b)
 {
     if (g_filter && !strstr(name, g_filter)) return;
     constexpr int BM = WM * FM * MF, BN = WN * FN * MF;
     constexpr size_t lds = (size_t)NST * (BM + BN) * 64 * 2;
-    auto kern = lab_kernel<MF, WM, WN, FM, FN, NST, PIPE, EPI, R, ABL>;
+    auto kern = lab_kernel<MF, WM, WN, FM, FN, NST, PIPE, EPI, R, ABL, WK>;
     CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     P p{s.M, s.N, s.K, b.A, b.W, b.bias, b.out, s.K + g_pada, s.N + g_pado, s.K + g_padw, g_wtiled};
-    const dim3 grid((s.N + BN - 1) / BN, (s.M + BM - 1) / BM), block(64 * WM * WN);
+    const dim3 grid((s.N + BN - 1) / BN, (s.M + BM - 1) / BM), block(64 * WM * WN * WK);
     // correctness on the full output
     CK(hipMemset(b.out, 0xff, (size_t)s.M * (s.N + g_pado) * 2));
     CK(hipMemset(b.bad, 0, 4)); CK(hipMemset(b.maxerr, 0, 4));
@@ -464,6 +501,13 @@ static void run_abls(const char *name, const Shape &s, Bufs &b)
     run_abl<MF, WM, WN, FM, FN, NST, PIPE, 57>(name, s, b);
 }
 
+template <int MF, int WM, int WN, int FM, int FN, int NST>
+static void run_wk2(const char *name, const Shape &s, Bufs &b)
+{
+    if ((s.K / 64) % NST || s.K / 64 < 2 * NST) return;
+    run_variant_r<MF, WM, WN, FM, FN, NST, 0, 0, 0, 0, 2>(name, s, b);
+}
+
 int main(int argc, char **argv)
 {
     if (argc > 1) g_filter = argv[1];
@@ -510,6 +554,17 @@ int main(int argc, char **argv)
             run_variant<16, 2, 1, 2, 4, 4, 2, E>("m16  64x64 2w(32x64) nst4 asm", s, b);
             run_variant<16, 4, 1, 3, 4, 4, 2, E>("m16 192x64 4w(48x64) nst4 asm", s, b);
             run_variant<16, 2, 2, 2, 2, 4, 0, E>("m16  64x64 4w(32x32) nst4 batch", s, b);
+            continue;
+        }
+        if (getenv("LAB_WK")) {   // round 4: the residual GEMMs' tile with a second wave group on the other k-step
+            run_variant<16, 2, 2, 3, 2, 4, 0, E>("m16  96x64 4w nst4 batch", s, b);
+            run_variant<16, 2, 2, 4, 2, 4, 0, E>("m16 128x64 4w nst4 batch", s, b);
+            run_wk2<16, 2, 2, 4, 2, 4>("m16 128x64 8w(wk2) nst4 batch", s, b);
+            run_variant<16, 2, 2, 2, 2, 4, 0, E>("m16  64x64 4w nst4 batch", s, b);
+            run_wk2<16, 2, 2, 2, 2, 4>("m16  64x64 8w(wk2) nst4 batch", s, b);
+            run_wk2<16, 2, 2, 2, 4, 4>("m16  64x128 8w(wk2) nst4 batch", s, b);
+            run_wk2<16, 2, 2, 4, 4, 4>("m16 128x128 8w(wk2) nst4 batch", s, b);
+            run_variant<16, 2, 2, 4, 4, 4, 0, E>("m16 128x128 4w nst4 batch", s, b);
             continue;
         }
         if (getenv("LAB_BEST")) {
