@@ -88,8 +88,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void lab_kernel(P p)
     constexpr int KS = MF == 16 ? 2 : 4;   // k-steps per K-tile
     constexpr int CPK = 8 / KS;            // 16-byte chunks per k-step
     constexpr int ROWS = BN + BM;
-    static_assert(ROWS % (8 * NW) == 0, "DMA rows must divide among the waves");
-    constexpr int DPT = ROWS / 8 / NW;     // DMA instructions per wave per K-tile
+    // UNEVEN (WK > 1 only): ROWS / 8 row groups do not divide among the waves -- the first (ROWS / 8) % NW waves issue DPT instructions per
+    // K-tile, the others DPT - 1, each group with its own counted waits
+    constexpr bool UNEVEN = (ROWS / 8) % NW != 0;
+    static_assert(!UNEVEN || (WK > 1 && PIPE == 0), "DMA rows must divide among the waves");
+    constexpr int DPT = (ROWS / 8 + NW - 1) / NW;     // DMA instructions per wave per K-tile (at most)
     constexpr int SLOT = ROWS * BK;        // elements per ring slot
     static_assert((NST - 2) * DPT <= 63, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
@@ -108,9 +111,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void lab_kernel(P p)
     // DMA sources: instruction i of this wave fills rows q*8 .. q*8+7 of the slot image [W rows | A rows], q = i*NW + wave
     const uint16_t *src[DPT];
     int kstep[DPT];
+    const bool full = !UNEVEN || ((DPT - 1) * NW + wave) < ROWS / 8;   // wave-uniform: this wave issues all DPT instructions
 #pragma unroll
     for (int i = 0; i < DPT; ++i) {
-        const int row = (i * NW + wave) * 8 + (lane >> 3);
+        const int row = min((i * NW + wave) * 8 + (lane >> 3), ROWS - 1);
         kstep[i] = (row < BN && p.wtiled) ? 512 : BK;
         if (row < BN) {
             const int sw = MF == 16 ? (row & 7) : ((row >> 1) & 7);
@@ -141,7 +145,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void lab_kernel(P p)
         uint16_t *base = smem + BUF * SLOT;
         if ((ABL & 16) && kt >= NST - 1) return;
 #pragma unroll
-        for (int i = 0; i < DPT; ++i) glds16(src[i] + (size_t)kt * kstep[i], base + (i * NW + wave) * 8 * BK);
+        for (int i = 0; i < DPT; ++i)
+            if (i + 1 < DPT || full) glds16(src[i] + (size_t)kt * kstep[i], base + (i * NW + wave) * 8 * BK);
     };
     auto read_frags = [&](auto bufc, auto ksc, bf16x8(&fw)[FN], bf16x8(&fa)[FM]) __attribute__((always_inline)) {
         constexpr int BUF = decltype(bufc)::value, ks = decltype(ksc)::value;
@@ -174,7 +179,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void lab_kernel(P p)
     if constexpr (PIPE == 0) {
         auto tile = [&](auto bc, int kt, auto stagec, auto flyc) __attribute__((always_inline)) {
             constexpr int b = decltype(bc)::value;
-            WAIT_VM(decltype(flyc)::value * DPT);
+            if constexpr (UNEVEN) {
+                if (full) WAIT_VM(decltype(flyc)::value * DPT);
+                else WAIT_VM(decltype(flyc)::value * (DPT - 1));
+            } else WAIT_VM(decltype(flyc)::value * DPT);
             __builtin_amdgcn_s_barrier();
             if constexpr (decltype(stagec)::value) stage(std::integral_constant<int, (b + NST - 1) % NST>{}, kt + NST - 1);
             constexpr int KSW = KS / WK;       // k-steps of this wave group
@@ -558,6 +566,7 @@ int main(int argc, char **argv)
         }
         if (getenv("LAB_WK")) {   // round 4: the residual GEMMs' tile with a second wave group on the other k-step
             run_variant<16, 2, 2, 3, 2, 4, 0, E>("m16  96x64 4w nst4 batch", s, b);
+            run_wk2<16, 2, 2, 3, 2, 4>("m16  96x64 8w(wk2, 3+2 DMA) nst4 batch", s, b);
             run_variant<16, 2, 2, 4, 2, 4, 0, E>("m16 128x64 4w nst4 batch", s, b);
             run_wk2<16, 2, 2, 4, 2, 4>("m16 128x64 8w(wk2) nst4 batch", s, b);
             run_variant<16, 2, 2, 2, 2, 4, 0, E>("m16  64x64 4w nst4 batch", s, b);
