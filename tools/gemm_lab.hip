@@ -33,6 +33,7 @@ struct P {
     uint16_t *out;
     long long lda, ldo, ldw;
     int wtiled;   // 1: W stored as [N/8][K/64][8][64] (every DMA instruction reads 1 KiB of consecutive bytes)
+    int xmap;     // 1: XCD-contiguous tile ids (see lab_kernel)
 };
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
@@ -101,7 +102,14 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void lab_kernel(P p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave / (WM * WN), w2 = wave % (WM * WN);
     const int wn = w2 / WM, wm = w2 % WM;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    // LAB_XMAP (p.xmap): workgroups are dealt to the 8 XCDs round-robin by their linear id; remapped so that every XCD owns a CONTIGUOUS
+    // range of tile ids (x fastest: whole rows of tiles, i.e. all of W and 1/8 of A per XCD's L2 instead of 1/8 of W and all of A)
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xmap) {
+        const int gx = gridDim.x, total = gx * gridDim.y, id = by * gx + bx;
+        if (total % 8 == 0) { const int nid = (id & 7) * (total >> 3) + (id >> 3); bx = nid % gx; by = nid / gx; }
+    }
+    const int n0 = bx * BN, m0 = by * BM;
     const int M = p.M, N = p.N, K = p.K;
     // ABL (timing-only ablations, wrong results): 1 no output stores, 2 every workgroup reads the A rows of tile 0, 4 ... the W rows
     // of tile 0, 8 no MFMAs, 16 no DMA after the prologue, 32 only the last NST + R K-tiles
@@ -426,7 +434,7 @@ struct Bufs {
     int wcopies; size_t wstride;
 };
 static const char *g_filter = nullptr;
-static int g_iters = 200, g_pada = 0, g_padw = 0, g_pado = 0, g_wtiled = 0;
+static int g_iters = 200, g_pada = 0, g_padw = 0, g_pado = 0, g_wtiled = 0, g_xmap = 0;
 
 template <int MF, int WM, int WN, int FM, int FN, int NST, int PIPE, int EPI, int R, int ABL = 0, int WK = 1>
 static void run_variant_r(const char *name, const Shape &s, Bufs &b)
@@ -436,7 +444,7 @@ static void run_variant_r(const char *name, const Shape &s, Bufs &b)
     constexpr size_t lds = (size_t)NST * (BM + BN) * 64 * 2;
     auto kern = lab_kernel<MF, WM, WN, FM, FN, NST, PIPE, EPI, R, ABL, WK>;
     CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    P p{s.M, s.N, s.K, b.A, b.W, b.bias, b.out, s.K + g_pada, s.N + g_pado, s.K + g_padw, g_wtiled};
+    P p{s.M, s.N, s.K, b.A, b.W, b.bias, b.out, s.K + g_pada, s.N + g_pado, s.K + g_padw, g_wtiled, g_xmap};
     const dim3 grid((s.N + BN - 1) / BN, (s.M + BM - 1) / BM), block(64 * WM * WN * WK);
     // correctness on the full output
     CK(hipMemset(b.out, 0xff, (size_t)s.M * (s.N + g_pado) * 2));
@@ -464,7 +472,7 @@ static void run_variant_r(const char *name, const Shape &s, Bufs &b)
     }
     const double fl = 2.0 * s.M * s.N * s.K;
     if (ABL) bad = 0;
-    printf("pad a%d w%d o%d wt%d ", g_pada, g_padw, g_pado, g_wtiled);
+    printf("pad a%d w%d o%d wt%d xm%d ", g_pada, g_padw, g_pado, g_wtiled, g_xmap);
     printf("%-34s %-18s grid %4d lds %6zu  cold %7.2f us %7.1f TF | warm %7.2f us %7.1f TF | %s maxerr %.3g\n", name, s.name,
            grid.x * grid.y, lds, us[0], fl / us[0] / 1e6, us[1], fl / us[1] / 1e6, bad ? "WRONG" : "ok", maxerr);
     fflush(stdout);
@@ -527,6 +535,7 @@ int main(int argc, char **argv)
     if (getenv("LAB_PADW")) g_padw = atoi(getenv("LAB_PADW"));
     if (getenv("LAB_PADO")) g_pado = atoi(getenv("LAB_PADO"));
     if (getenv("LAB_WTILED")) g_wtiled = atoi(getenv("LAB_WTILED"));
+    if (getenv("LAB_XMAP")) g_xmap = atoi(getenv("LAB_XMAP"));
     const size_t maxA = (size_t)6144 * (4096 + 512), maxW = (size_t)4096 * 4096, maxO = (size_t)6144 * (4096 + 512);
     Bufs b;
     b.wcopies = 40;   // 40 x 8 MiB > the 256 MiB Infinity Cache
