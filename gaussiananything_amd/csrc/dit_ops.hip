@@ -513,6 +513,9 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     if (m->stage2 && !a->fps_xyz) return GA_DIT_ERR_NULL_ARG;
     const int B = a->batch, L = a->tokens, D = m->hidden, Mrows = B * L;
     if (B <= 0 || B > 16 || L <= 0 || a->ctx_tokens <= 0) return GA_DIT_ERR_BAD_SHAPE;
+    // a sampler step writes states / velocities of in_channels floats per token: a model that also predicts sigma (out_channels !=
+    // in_channels) has no such step -- refused before anything is enqueued (the reference trips body_fn's shape assert there)
+    if (a->step && (m->out_channels != m->in_channels || (a->step->cfg && (B % 2 != 0)))) return GA_DIT_ERR_BAD_SHAPE;
     const Ws w = carve(m, B, L, a->workspace);
     if (a->workspace_bytes < w.total || ((uintptr_t)a->workspace & 255)) return GA_DIT_ERR_BAD_SHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

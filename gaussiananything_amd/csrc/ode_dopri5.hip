@@ -12,7 +12,9 @@
 // accept kernel -- that reads and writes time, step size, decisions and counters in a small device block, so the host captures it
 // into a HIP graph once and replays it; it only looks at the `done` word after a replay.
 //   ga_ode_dopri5_stage    ystage = y + dt sum_j B[i][j] k_j ; timesteps[] = t + A[i] dt           (i = 0..5; i = 5 gives y1)
-//   ga_ode_dopri5_error    ctl.sumsq += sum ((dt sum_j Cerr[j] k_j) / (atol + rtol max(|y|, |y1|)))^2
+//   ga_ode_dopri5_error    ctl.partial[block] = sum over the block's elements of ((dt sum_j Cerr[j] k_j) / (atol + rtol max(|y|, |y1|)))^2
+//                          (fixed element -> thread -> wave -> block assignment; the controller adds the partials in a fixed order:
+//                          the accept / reject decision is bit-reproducible from run to run and from replay to replay)
 //   ga_ode_dopri5_control  ratio -> accept / reject, next dt, the grid times inside an accepted step, done
 //   ga_ode_dopri5_accept   (accepted steps only) dense output at those grid times, y <- y1, k1 <- k7
 // The arithmetic follows gaussiananything_amd/transport/odeint.py operation by operation (time and step size in fp64, the
@@ -82,21 +84,25 @@ __global__ __launch_bounds__(256) void error_kernel(int64_t n, const float *__re
     __shared__ double part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(ctl + GA_ODE_SUMSQ, (part[0] + part[1]) + (part[2] + part[3]));
+    if (threadIdx.x == 0) ctl[GA_ODE_CTL_WORDS + blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);    // (no atomics: order-free)
 }
 
 // one thread: torchdiffeq's controller (rk_common._optimal_step_size) and the bookkeeping of the attempted step
-__global__ void control_kernel(int64_t n, double *__restrict__ ctl, const double *__restrict__ t_grid, int ngrid)
+__global__ __launch_bounds__(64) void control_kernel(int64_t n, int nparts, double *__restrict__ ctl, const double *__restrict__ t_grid, int ngrid)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const double t = ctl[GA_ODE_T], dt = ctl[GA_ODE_DT];
-    const double ratio = sqrt(ctl[GA_ODE_SUMSQ] / (double)n);
-    ctl[GA_ODE_SUMSQ] = 0.0;
-    ctl[GA_ODE_RATIO] = ratio;
-    ctl[GA_ODE_STEPS] += 1.0;
+    // the error norm: lane l adds the partials l, l + 64, ... in that order, then a fixed shuffle tree
+    double sumsq = 0.0;
+    for (int b = (int)threadIdx.x; b < nparts; b += 64) sumsq += ctl[GA_ODE_CTL_WORDS + b];
+    for (int o = 32; o > 0; o >>= 1) sumsq += __shfl_down(sumsq, o, 64);
+    if (threadIdx.x != 0) return;
     ctl[GA_ODE_ACCEPT] = 0.0;
     ctl[GA_ODE_JCOUNT] = 0.0;
-    if (ctl[GA_ODE_DONE] != 0.0) return;                 // (a replay past the end: nothing moves)
+    if (ctl[GA_ODE_DONE] != 0.0) return;                 // (a replay past the end: nothing moves, no counter either)
+    const double t = ctl[GA_ODE_T], dt = ctl[GA_ODE_DT];
+    const double ratio = sqrt(sumsq / (double)n);
+    ctl[GA_ODE_SUMSQ] = sumsq;                           // (diagnostic: the sum the decision was taken on)
+    ctl[GA_ODE_RATIO] = ratio;
+    ctl[GA_ODE_STEPS] += 1.0;
     if (!(ratio == ratio) || isinf(ratio) || !(dt == dt) || isinf(dt) || t + dt == t) {   // NaN / inf model output, step size underflow
         ctl[GA_ODE_ERROR] = !(ratio == ratio) || isinf(ratio) ? 1.0 : 2.0;
         ctl[GA_ODE_DONE] = 1.0;
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(256) void accept_kernel(int64_t n, float *__restric
     }
 }
 
-inline int grid_for(int64_t n) { return (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048); }
+inline int grid_for(int64_t n) { return (int)((n + 255) / 256 < GA_ODE_MAX_PARTIALS ? (n + 255) / 256 : GA_ODE_MAX_PARTIALS); }
 
 }  // namespace gaode
 
@@ -184,7 +190,7 @@ int ga_ode_dopri5_finish(const GaOdeDopri5 *o, void *stream)
     for (int j = 0; j < 7; ++j) { if (!o->k[j]) return GA_DIT_ERR_NULL_ARG; kp.k[j] = o->k[j]; }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(error_kernel, dim3(grid_for(o->n)), dim3(256), 0, s, o->n, o->y, o->ystage, kp, o->ctl);
-    hipLaunchKernelGGL(control_kernel, dim3(1), dim3(64), 0, s, o->n, o->ctl, o->t_grid, o->grid_len);
+    hipLaunchKernelGGL(control_kernel, dim3(1), dim3(64), 0, s, o->n, grid_for(o->n), o->ctl, o->t_grid, o->grid_len);
     hipLaunchKernelGGL(accept_kernel, dim3(grid_for(o->n)), dim3(256), 0, s, o->n, o->y, o->ystage, o->k[0], kp, o->ctl, o->t_grid, o->out);
     return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
 }

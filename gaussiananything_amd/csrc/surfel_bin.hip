@@ -543,7 +543,8 @@ __global__ __launch_bounds__(kFT) void surfel_fill_sched_kernel(ScanArgs sa, con
         const int i = (blockIdx.x * kFillSplats + k) * kFT + tid;
         rcs[k] = i < dm.N ? *reinterpret_cast<const ushort4 *>(rect + 4 * ((size_t)v * dm.N + i)) : make_ushort4(0, 0, 0, 0);
     }
-    const int per = (T + 1023) / kFT;          // consecutive tile counters per thread (<= kLdsTiles / kFT)
+    static_assert(kLdsTiles % kFT == 0, "a thread holds kLdsTiles / kFT consecutive tile counters");
+    const int per = (T + kFT - 1) / kFT;       // consecutive tile counters per thread (<= kLdsTiles / kFT because T <= kLdsTiles)
     uint32_t tc[kLdsTiles / kFT];
 #pragma unroll
     for (int j = 0; j < kLdsTiles / kFT; ++j) {
@@ -1070,6 +1071,12 @@ void launch_binning(const GaSurfelForwardArgs &a, const Dims &d, const Workspace
     const unsigned nbx = (unsigned)std::max(1, (d.N + kFT * kFillSplats - 1) / (kFT * kFillSplats));
     const int nsched = (int)std::min<unsigned>(nbx, (unsigned)((nt + kFT - 1) / kFT));   // one schedule slot per thread of a row-0 workgroup
     // (16-bit halves in the schedule's class bins; the schedule workgroups' notes of the long lists fit point_list)
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {   // 2 * kLdsTiles words of dynamic LDS (64 KiB at 8192 tiles) beside the kernels' static LDS: opted into once
+        (void)hipFuncSetAttribute((const void *)surfel_fill_sched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kLdsTiles * (int)sizeof(uint32_t));
+        (void)hipFuncSetAttribute((const void *)surfel_fill_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kLdsTiles * (int)sizeof(uint32_t));
+        lds_attr_set = true;
+    }
     if (d.tiles <= kLdsTiles && nt <= 0xFFFF && (int64_t)nsched * 2 * (a.capacity / kSortCap + 1) <= a.capacity) {
         hipLaunchKernelGGL(surfel_fill_sched_kernel, dim3(nbx, (unsigned)d.V + 1u), dim3(kFT), 2 * d.tiles * sizeof(uint32_t), s, sa,
                            ws.rect, ws.depth, d, ws.view_total, ws.keys, nsched, ws.point_list, ws.seg_scratch);

@@ -342,6 +342,8 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         kernel (GaDitSamplerStep), a one-thread kernel moves the step counter / time / step size on, and one step is
         captured into a HIP graph and replayed -- nothing but this library's kernels between two steps, no host
         synchronisation.  Bit-identical to the eager loop over ``forward_with_cfg`` / ``forward_cond``."""
+        if self.out_channels != self.in_channels:
+            raise ValueError("the fused sampler step needs a velocity of the state's shape (learn_sigma=False)")
         dev = y0.device
         tt = [float(v) for v in t_grid]
         n = len(tt)
@@ -414,6 +416,8 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         decisions as ``transport/odeint.py`` / ``oracle/ode.py`` (the initial step size is chosen on the host as there: two
         evaluations).  Returns the states at every requested time."""
         from ..transport.odeint import _initial_step
+        if self.out_channels != self.in_channels:
+            raise ValueError("the device-resident dopri5 needs a velocity of the state's shape (learn_sigma=False)")
         dev = y0.device
         tt = [float(v) for v in t_grid]
         ng = len(tt)
@@ -429,7 +433,7 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
             st = {"sig": None, "y": y, "out": torch.empty((ng,) + tuple(y.shape), dtype=torch.float32, device=dev),
                   "k": [torch.empty_like(y) for _ in range(7)], "ystage": torch.empty_like(y),
                   "tvec": torch.empty(B, dtype=torch.float32, device=dev),
-                  "ctl": torch.zeros(ops.GA_ODE_CTL_WORDS, dtype=torch.float64, device=dev),
+                  "ctl": torch.zeros(ops.GA_ODE_CTL_ALLOC, dtype=torch.float64, device=dev),
                   "tg": torch.empty(ng, dtype=torch.float64, device=dev), "graph": None,
                   "host": torch.empty(ops.GA_ODE_CTL_WORDS, dtype=torch.float64).pin_memory(), "keep": tuple(context.values())}
         y, out, k, ystage, tvec, ctl, tg, host = (st[q] for q in ("y", "out", "k", "ystage", "tvec", "ctl", "tg", "host"))
@@ -452,7 +456,7 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         dt0 = _initial_step(rhs, tt[0], y, k[0], rtol, atol)
         head = torch.zeros(ops.GA_ODE_CTL_WORDS, dtype=torch.float64)
         head[ops.GA_ODE_T], head[ops.GA_ODE_DT], head[ops.GA_ODE_ATOL], head[ops.GA_ODE_RTOL], head[ops.GA_ODE_JNEXT] = tt[0], dt0, atol, rtol, 1
-        ctl.copy_(head)
+        ctl[:ops.GA_ODE_CTL_WORDS].copy_(head)
         evals_before = nfe[0]
         if ng > 1:
             if st["graph"] is None:
@@ -478,7 +482,7 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
             done_evt = torch.cuda.Event()
             while True:
                 graph.replay()
-                host.copy_(ctl, non_blocking=True)
+                host.copy_(ctl[:ops.GA_ODE_CTL_WORDS], non_blocking=True)
                 done_evt.record()
                 done_evt.synchronize()
                 if host[ops.GA_ODE_DONE] != 0 or host[ops.GA_ODE_STEPS] >= max_steps:
@@ -491,7 +495,8 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
             if host[ops.GA_ODE_DONE] == 0:
                 raise RuntimeError(f"dopri5: more than {max_steps} attempted steps")
             if stats is not None:
-                stats.update(nfe=evals_before + 6 * steps, steps=steps, rejected=int(host[ops.GA_ODE_REJECTED]), graph=True, device_loop=True)
+                stats.update(nfe=evals_before + 6 * steps, steps=steps, rejected=int(host[ops.GA_ODE_REJECTED]), graph=True, device_loop=True,
+                             ctl=[float(v) for v in host])     # the controller's scalar block after the last step (tests: bit-reproducible)
         elif stats is not None:
             stats.update(nfe=evals_before, steps=0, rejected=0, graph=True, device_loop=True)
         return out.clone()

@@ -70,7 +70,8 @@ class GaOdeDopri5(ctypes.Structure):
 # indices into GaOdeDopri5.ctl (include/ga_dit.h)
 (GA_ODE_T, GA_ODE_DT, GA_ODE_SUMSQ, GA_ODE_ATOL, GA_ODE_RTOL, GA_ODE_DONE, GA_ODE_STEPS, GA_ODE_REJECTED, GA_ODE_ACCEPT, GA_ODE_TA,
  GA_ODE_TB, GA_ODE_DT_USED, GA_ODE_JNEXT, GA_ODE_JBEG, GA_ODE_JCOUNT, GA_ODE_ERROR, GA_ODE_RATIO) = range(17)
-GA_ODE_CTL_WORDS = 24
+GA_ODE_CTL_WORDS = 24          # the scalar head the host reads back
+GA_ODE_CTL_ALLOC = 24 + 2048    # + one error-norm partial per workgroup of the error launch (GA_ODE_MAX_PARTIALS)
 
 
 class GaDitForwardArgs(ctypes.Structure):

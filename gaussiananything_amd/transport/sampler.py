@@ -29,7 +29,10 @@ def integrate(model, x, t_grid, method, atol, rtol, model_kwargs, stats, drift=N
     owner, name = getattr(model, "__self__", None), getattr(model, "__name__", "")
     fusable = (drift is None and x.device.type == "cuda" and len(t_grid) > 4 and name in ("forward_with_cfg", "forward_cond")
                and "context" in model_kwargs and set(model_kwargs) <= {"context", "cfg_scale"}
-               and os.environ.get("GA_ODE_GRAPH", "1") != "0")
+               and os.environ.get("GA_ODE_GRAPH", "1") != "0"
+               # a sigma-predicting model (out_channels != in_channels) has no fused step: its output is not a velocity of the state's
+               # shape -- the eager loop fails on the shapes as the reference's body_fn assert does (transport/transport.py:219-224)
+               and getattr(owner, "out_channels", None) == getattr(owner, "in_channels", None))
     if fusable and method == "euler" and hasattr(owner, "sample_euler_fused"):
         out = owner.sample_euler_fused(x, t_grid.tolist(), model_kwargs["context"], cfg_scale=model_kwargs.get("cfg_scale", 1.0),
                                        cfg=(name == "forward_with_cfg"))

@@ -268,7 +268,7 @@ int ga_dit_sampler_advance(int32_t *counter, const float *t_grid, const float *d
  * state into y, f(t0, y0) into k[0], and t0 / the first step size / atol / rtol / JNEXT = 1 (out[0] = y0 is the caller's) into ctl. */
 #define GA_ODE_T 0          /* time of the state y (fp64)                                  */
 #define GA_ODE_DT 1         /* size of the NEXT attempted step                             */
-#define GA_ODE_SUMSQ 2      /* accumulator of the error norm (zero between steps)          */
+#define GA_ODE_SUMSQ 2      /* sum of squares the last decision was taken on (diagnostic)  */
 #define GA_ODE_ATOL 3
 #define GA_ODE_RTOL 4
 #define GA_ODE_DONE 5       /* 1: the last requested time has been produced (or ERROR set) */
@@ -283,7 +283,9 @@ int ga_dit_sampler_advance(int32_t *counter, const float *t_grid, const float *d
 #define GA_ODE_JCOUNT 14
 #define GA_ODE_ERROR 15     /* 1: non-finite error ratio (NaN / inf model output), 2: step size underflow */
 #define GA_ODE_RATIO 16     /* error ratio of the step just attempted (diagnostic)         */
-#define GA_ODE_CTL_WORDS 24
+#define GA_ODE_CTL_WORDS 24          /* the scalar head: what the host reads back after a replay                                      */
+#define GA_ODE_MAX_PARTIALS 2048     /* behind the head: one partial sum of the error norm per workgroup of the error launch, added  */
+#define GA_ODE_CTL_ALLOC (GA_ODE_CTL_WORDS + GA_ODE_MAX_PARTIALS)   /* by the controller in a fixed order (bit-reproducible steps)      */
 
 typedef struct GaOdeDopri5 {
     int64_t n;              /* floats of the state: B' * L * C                             */
@@ -293,7 +295,7 @@ typedef struct GaOdeDopri5 {
     float *k[7];            /* [n] each: k[0] = f(t, y) (FSAL), k[1..6] the stage derivatives */
     float *ystage;          /* [n] input of the next function evaluation; after stage 5: the 5th-order solution */
     float *timesteps;       /* [B'] time of the next function evaluation (fp32, as the reference passes it)     */
-    double *ctl;            /* [GA_ODE_CTL_WORDS] device scalars, see above                */
+    double *ctl;            /* [GA_ODE_CTL_ALLOC] device scalars (head of GA_ODE_CTL_WORDS) + the error-norm partials */
     const double *t_grid;   /* [grid_len] requested times, increasing                     */
     float *out;             /* [grid_len, n] dense output (slice 0 is the caller's)        */
 } GaOdeDopri5;

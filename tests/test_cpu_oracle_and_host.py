@@ -317,14 +317,16 @@ def test_bound_reference_transport_integrates_with_this_package(path_type, predi
         want = {m: ref_transport.Sampler(rt).sample_ode(sampling_method=m, num_steps=9)(x0, model, scale=1.5) for m in methods}
         theirs = ref_transport.integrators.ode.sample
         bind_reference_transport(ref_transport.integrators)
+        import torchdiffeq                 # (sys.modules holds the stand-in of _reference_transport here, never the real package)
+        stand_in = torchdiffeq.odeint
         try:
-            import torchdiffeq
-            torchdiffeq.odeint = None     # (the stand-in: a call would now fail)
+            torchdiffeq.odeint = None     # a call would now fail
             for m in methods:
                 sampler = ref_transport.Sampler(rt)
                 got = sampler.sample_ode(sampling_method=m, num_steps=9)(x0, model, scale=1.5)
                 assert got.shape == want[m].shape and torch.allclose(got, want[m], rtol=1e-4, atol=2e-5, equal_nan=True), (m, float((got - want[m]).abs().max()))
         finally:
+            torchdiffeq.odeint = stand_in
             ref_transport.integrators.ode.sample = theirs
     finally:
         restore()

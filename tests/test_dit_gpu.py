@@ -566,6 +566,86 @@ def test_device_resident_dopri5_takes_the_decisions_of_the_host_loop(gpu_device,
         assert not torch.equal(other[-1], keep[-1]) and torch.equal(other[0], 0.5 * x.float())
 
 
+def test_device_dopri5_is_bit_reproducible_and_refuses_sigma_models(gpu_device):
+    """(i) csrc/ode_dopri5.hip adds the error norm in a FIXED order (per-workgroup partials, summed by the controller): two
+    integrations of the same problem give bit-identical controller blocks -- error ratio, sum of squares, step sizes, counters -- and
+    states, whatever order the workgroups arrive in (round 4 accumulated with atomicAdd(double): a ratio near 1 could flip a decision).
+    (ii) a sigma-predicting model (out_channels = 2 x in_channels) has no fused sampler step: ga_dit_forward refuses the step before
+    anything is enqueued (round 4 would have written B*L*2C floats into B*L*C buffers), the Python entry raises."""
+    from gaussiananything_amd import dit_ops as ops
+    from gaussiananything_amd.dit import DiT_I23D_PCD_PixelArt_noclip
+    from gaussiananything_amd.transport import Sampler, create_transport
+    z, model, ctx = _load_golden(1, gpu_device)
+    x = z["x"].to(gpu_device)
+    sampler = Sampler(create_transport("GVP", "velocity", None, None, None, snr_type="uniform"))
+    runs = []
+    for _ in range(3):
+        fn = sampler.sample_ode(sampling_method="dopri5", num_steps=17, atol=1e-6, rtol=1e-3)
+        with torch.no_grad():
+            out = fn(x, model.forward_with_cfg, context=ctx, cfg_scale=z["cfg_scale"])
+        st = dict(sampler.last_ode.last_stats)
+        assert st.get("device_loop") and len(st["ctl"]) == ops.GA_ODE_CTL_WORDS
+        runs.append((out.clone(), st))
+    for out, st in runs[1:]:
+        assert st["ctl"] == runs[0][1]["ctl"], (st["ctl"], runs[0][1]["ctl"])
+        assert torch.equal(out, runs[0][0])
+    assert runs[0][1]["ctl"][ops.GA_ODE_RATIO] > 0.0 and runs[0][1]["ctl"][ops.GA_ODE_SUMSQ] > 0.0
+    kw = dict(z["kwargs"], learn_sigma=True)
+    sig = DiT_I23D_PCD_PixelArt_noclip(**kw).to(gpu_device)
+    assert sig.out_channels == 2 * sig.in_channels
+    with torch.no_grad():
+        y = sig(x, z["t"].to(gpu_device), ctx)
+        assert y.shape[-1] == 2 * x.shape[-1]                 # the plain forward of such a model is fine
+        with pytest.raises(ValueError):
+            sig.sample_dopri5_device(x, [0.0, 0.5, 1.0], ctx)
+        with pytest.raises(ValueError):
+            sig.sample_euler_fused(x, [0.0, 0.5, 1.0], ctx)
+        vel = torch.empty_like(x)
+        step = ops.GaDitSamplerStep(1.0, 0, None, None, None, 0, None, vel.data_ptr())
+        with pytest.raises(RuntimeError):                     # the C-ABI itself: GA_DIT_ERR_BAD_SHAPE
+            sig.forward(x, z["t"].to(gpu_device), ctx, _step=step)
+
+
+@pytest.mark.parametrize("arch,C,cfg,method,points", [("DiT-PixArt-PCD-CLAY-B", 3, True, "euler", 25),
+                                                      ("DiT-PixArt-PCD-CLAY-B", 3, False, "dopri5", 9),
+                                                      ("DiT-PixArt-PCD-CLAY-L", 3, False, "euler", 25)])
+def test_full_depth_sampling_trajectory_against_the_fp32_oracle(gpu_device, arch, C, cfg, method, points):
+    """BASELINE.json configs[2] at REAL depth: the release denoisers (DiT-B depth 12 / DiT-L depth 24, seeded weights of SURVEY 8d
+    config #3) integrated from t = 0 to t = 1 through the HIP path -- bf16 MFMA operands, the fused Euler step / the device-resident
+    dopri5 -- against the all-fp32 trajectory: oracle/dit.py integrated by oracle/ode.py on the CPU
+    (/root/reference/transport/integrators.py:100-119 over /root/reference/dit/dit_i23d.py:1537-1546).  Euler over 25 grid points
+    (24 evaluations, guided for B) and the reference's default dopri5 (rtol 1e-3, atol 1e-6) to t = 1; the quantity asserted and
+    printed is the relative L2 distance of the END state (and of every saved state).  Bar 3e-2: one evaluation sits at ~6e-3 of the
+    fp32 output (test_release_models_full_depth_against_oracle), the drift over a trajectory is measured here (printed)."""
+    from gaussiananything_amd.transport import Sampler, create_transport
+    from oracle import trajectory as otraj
+    model, sd = otraj.release_model(arch, C)
+    x0, ctx = otraj.release_inputs(C, cfg=cfg)
+    stats_o = {}
+    ref = otraj.integrate(sd, x0, ctx, 4.0, method, points, cfg=cfg, threads=min(64, len(os.sched_getaffinity(0))), stats=stats_o)
+    model.to(gpu_device)
+    sampler = Sampler(create_transport("GVP", "velocity", None, None, None, snr_type="uniform"))
+    fn = sampler.sample_ode(sampling_method=method, num_steps=points, atol=1e-6, rtol=1e-3)
+    with torch.no_grad():
+        out = fn(x0.to(gpu_device), model.forward_with_cfg if cfg else model.forward_cond,
+                 context={k: v.to(gpu_device) for k, v in ctx.items()}, cfg_scale=4.0)
+    st = dict(sampler.last_ode.last_stats)
+    assert out.shape == ref.shape
+    got = out.double().cpu().numpy()
+    end = otraj.rel_l2(got[-1], ref[-1])
+    worst = max(otraj.rel_l2(got[i], ref[i]) for i in range(1, points))
+    moved = otraj.rel_l2(ref[-1], ref[0])
+    print(f"\n{arch} {method} x {points} points (cfg {cfg}): end-state rel. L2 {end:.3e}, worst saved state {worst:.3e}; "
+          f"the state moved by {moved:.2f} of its norm; evaluations HIP {st.get('nfe')} / oracle {stats_o.get('nfe')}, "
+          f"rejected {st.get('rejected')} / {stats_o.get('rejected')}")
+    assert moved > 0.05                                # (a trajectory that does not move would prove nothing)
+    assert end < 3e-2 and worst < 3e-2, (end, worst)
+    if method == "euler":
+        assert st["nfe"] == stats_o["nfe"] == points - 1 and st.get("fused")
+    else:
+        assert st.get("device_loop") and st["nfe"] >= 7 and stats_o["nfe"] >= 7
+
+
 def test_cpu_tensors_raise(gpu_device):
     z, model, ctx = _load_golden(1, gpu_device)
     with pytest.raises(RuntimeError):
