@@ -382,7 +382,12 @@ def bench_cascade(dev, cams, rank, world, dist, dopri5=True):
 
 def parity_check(g, cams, H, W, dev):
     """Untimed: the bench workload itself through the HIP path against the C oracle, every view -- integer artefacts (radii,
-    tile rects, per-tile ranges, depth-ordered point lists) bit-identical, pixel MSE per output channel (bar 1e-5)."""
+    tile rects, per-tile ranges, depth-ordered point lists) bit-identical, pixel MSE per output channel (bar 1e-5), and beside the
+    MSE the absolute differences: the largest one per channel group, the number of pixels beyond 1e-4 (bar: <= 3e-4 of the pixels of
+    any channel, never more than 24 in one 16 x 16 tile -- a wrong tile is 256 -- and <= 0.25 outside the median-depth channel, whose
+    `T > 0.5` pick jumps from one splat's depth to another's), and the same count for the fp32 oracle against ITS OWN loop in double
+    (oracle/surfel_raster.c, -DORACLE_BLEND_F64): the pixels where threshold decisions flip or an edge-on splat's cross product
+    cancels are no more frequent for the HIP kernel than for any other fp32 evaluation order."""
     from gaussiananything_amd import synthetic
     from gaussiananything_amd.diff_surfel_rasterization import rasterize_views
     from oracle import surfel as osurf
@@ -400,9 +405,15 @@ def parity_check(g, cams, H, W, dev):
     plist = ws.section("point_list", torch.int32, max(D, 1)).cpu().numpy()[:D]
     color, radii, allmap = color.cpu().numpy(), radii.cpu().numpy(), allmap.cpu().numpy()
     exact, worst, total = True, 0.0, 0
+    max_abs, max_abs_median = 0.0, 0.0
+    beyond = np.zeros(10, np.int64)
+    beyond64 = np.zeros(10, np.int64)
+    tile_worst = 0
+    args = [t.numpy() for t in (m, o, c, s, r)]
     for v in range(V):
-        ov = osurf.rasterize(m.numpy(), o.numpy(), c.numpy(), s.numpy(), r.numpy(), cams["cam_view"][v].numpy(),
-                             cams["cam_view_proj"][v].numpy(), np.ones(3, np.float32), H, W)
+        cam = (cams["cam_view"][v].numpy(), cams["cam_view_proj"][v].numpy(), np.ones(3, np.float32), H, W)
+        ov = osurf.rasterize(*args, *cam)
+        o64 = osurf.rasterize(*args, *cam, blend_f64=True)
         ts = tile_start[v * tiles:(v + 1) * tiles + 1]
         cnt = ov["ranges"][:, 1].astype(np.int64) - ov["ranges"][:, 0].astype(np.int64)
         exact &= bool(np.array_equal(radii[v], ov["radii"]) and np.array_equal(rect[v].astype(np.uint32), ov["rect"])
@@ -411,10 +422,54 @@ def parity_check(g, cams, H, W, dev):
         total += ov["D"]
         worst = max(worst, float(np.mean((color[v] - ov["color"]) ** 2)),
                     *[float(np.mean((allmap[v, ch] - ov["allmap"][ch]) ** 2)) for ch in range(7)])
+        d = np.concatenate([np.abs(color[v] - ov["color"]), np.abs(allmap[v] - ov["allmap"])], 0)       # [10, H, W]
+        d64 = np.concatenate([np.abs(ov["color"] - o64["color"]), np.abs(ov["allmap"] - o64["allmap"])], 0)
+        med = 3 + 5                                                                                         # allmap channel 5: median depth
+        max_abs = max(max_abs, float(np.delete(d, med, 0).max()))
+        max_abs_median = max(max_abs_median, float(d[med].max()))
+        beyond += (d > 1e-4).reshape(10, -1).sum(1)
+        beyond64 += (d64 > 1e-4).reshape(10, -1).sum(1)
+        Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
+        pad = np.zeros((10, Hp, Wp), bool)
+        pad[:, :H, :W] = d > 1e-4
+        tile_worst = max(tile_worst, int(pad.reshape(10, Hp // 16, 16, Wp // 16, 16).sum((2, 4)).max()))
     exact &= total == D
+    frac = float(beyond.max()) / (V * H * W)
+    ok = bool(exact and worst <= 1e-5 and frac <= 3e-4 and tile_worst <= 24 and max_abs <= 0.25)
     return {"against": "oracle/surfel_raster.c (CPU port; parity unpinned vs upstream, see DESIGN.md)", "views": V,
             "bins_bit_identical": bool(exact), "num_rendered_D": D, "max_channel_mse": float(f"{worst:.3e}"),
-            "mse_bar": 1e-5, "pass": bool(exact and worst <= 1e-5)}
+            "mse_bar": 1e-5, "max_abs": float(f"{max_abs:.3e}"), "max_abs_median_depth_channel": float(f"{max_abs_median:.3e}"),
+            "pixels_beyond_1e-4_worst_channel": int(beyond.max()), "pixels_beyond_1e-4_fraction": float(f"{frac:.3e}"),
+            "pixels_beyond_1e-4_fp32_oracle_vs_its_fp64_blend": int(beyond64.max()),
+            "most_pixels_beyond_1e-4_in_one_tile": tile_worst,
+            "max_abs_bars": "<= 3e-4 of the pixels of any channel beyond 1e-4, <= 24 of them in one 16x16 tile, <= 0.25 anywhere outside the "
+                            "median-depth channel (decision flips / edge-on splats: as frequent between the fp32 oracle and its own fp64 blend)",
+            "pass": ok}
+
+
+def trajectory_parity(dev, points=25):
+    """BASELINE configs[2] at real depth, untimed: DiT-PixArt-PCD-CLAY-B (depth 12, seeded weights) integrated from t = 0 to 1 with the
+    guided Euler sampler over `points` grid points through the HIP path (bf16 MFMA operands, fused on-device step) against the all-fp32
+    trajectory (oracle/dit.py integrated by oracle/ode.py on the host cores): relative L2 of the end state.  The same quantity for
+    dopri5 and DiT-L is asserted by tests/test_dit_gpu.py::test_full_depth_sampling_trajectory_against_the_fp32_oracle."""
+    from gaussiananything_amd.transport import Sampler, create_transport
+    from oracle import trajectory as otraj
+    model, sd = otraj.release_model("DiT-PixArt-PCD-CLAY-B", 3)
+    x0, ctx = otraj.release_inputs(3, cfg=True)
+    t0 = time.perf_counter()
+    ref = otraj.integrate(sd, x0, ctx, 4.0, "euler", points, cfg=True, threads=host_threads())
+    cpu_s = time.perf_counter() - t0
+    model.to(dev)
+    sampler = Sampler(create_transport("GVP", "velocity", None, None, None, snr_type="uniform"))
+    fn = sampler.sample_ode(sampling_method="euler", num_steps=points)
+    with torch.no_grad():
+        out = fn(x0.to(dev), model.forward_with_cfg, context={k: v.to(dev) for k, v in ctx.items()}, cfg_scale=4.0)
+    got = out.double().cpu().numpy()
+    end = otraj.rel_l2(got[-1], ref[-1])
+    return {"model": "DiT-PixArt-PCD-CLAY-B depth 12, CFG batch 2 x 768 tokens, scale 4", "method": f"euler, {points} grid points = {points - 1} evaluations",
+            "trajectory_rel_l2": float(f"{end:.3e}"), "worst_saved_state_rel_l2": float(f"{max(otraj.rel_l2(got[i], ref[i]) for i in range(1, points)):.3e}"),
+            "state_moved_by": round(otraj.rel_l2(ref[-1], ref[0]), 3), "bar": 3e-2, "pass": bool(end < 3e-2),
+            "oracle_cpu_seconds": round(cpu_s, 1), "against": "oracle/dit.py (pinned to the reference's classes) integrated by oracle/ode.py, fp32 / fp64"}
 
 
 def bench_conditioner(dev, reps=5):
@@ -532,7 +587,7 @@ def bench_backward(m, o, c, s, r, cams, H, W, dev, reps=8):
     return {"forward_autograd_ms": round(float(np.median(fwd)), 4), "loss_plus_backward_ms": round(float(np.median(bwd)), 4),
             "grads_finite": bool(all(torch.isfinite(t.grad).all() for t in leaves)),
             "note": "forward through the autograd Function (own workspace per call); backward = ga_surfel_backward + the loss's "
-                    "elementwise kernels (~0.1 ms); per-kernel times: profiles/r3_backward_kernel_stats.txt"}
+                    "elementwise kernels (~0.1 ms); per-kernel times: profiles/r3_backward_kernel_stats.txt (the backward is unchanged since round 3)"}
 
 
 def bench_mesh_export(g, cams, dev):
@@ -558,6 +613,57 @@ def bench_mesh_export(g, cams, dev):
     res["note"] = ("volume allocation (0.87 GB zero-fill) + 8 x ga_tsdf_integrate + marching cubes, then the device connected-component "
                    "filter; per-phase times: profiles/r2_tsdf_bench.json; Open3D on the CPU in the reference")
     return res
+
+
+def summary_of(out):
+    """The line's figures once more, compact, as its last key: stage times [us], parity verdicts, ms per evaluation and fraction of the
+    bf16 MFMA peak per denoiser, the two attention launches, the cascade, the CPU baselines."""
+    def g(d, *ks):
+        for k in ks:
+            d = d.get(k) if isinstance(d, dict) else None
+        return d
+    sm = {"Msplats_s": out.get("value"), "ms_step": out.get("ms_per_step"), "n_gpus": out.get("n_gpus")}
+    if out.get("stage_ms"):
+        sm["stage_us"] = {k[:4]: round(v * 1e3, 1) for k, v in out["stage_ms"].items()}
+    if out.get("roofline"):
+        sm["blend"] = {"hbm_frac": out["roofline"]["frac"], "valu_issue": out["roofline"].get("valu_issue_frac"),
+                       "valu_Minsts": None if not out["roofline"].get("valu_wave_instructions_per_launch") else
+                       round(out["roofline"]["valu_wave_instructions_per_launch"] / 1e6, 1),
+                       "traffic_MB": None if not out["roofline"].get("traffic") else round(out["roofline"]["traffic"] / 1e6, 1)}
+    if out.get("stress_scene"):
+        sm["stress_ms"] = out["stress_scene"]["ms_per_step"]
+    if out.get("parity"):
+        pr = out["parity"]
+        sm["parity"] = {"pass": pr.get("pass"), "bins_exact": pr.get("bins_bit_identical"), "mse": pr.get("max_channel_mse"),
+                        "max_abs": pr.get("max_abs"), "px>1e-4": pr.get("pixels_beyond_1e-4_worst_channel"),
+                        "px>1e-4_o32_vs_o64": pr.get("pixels_beyond_1e-4_fp32_oracle_vs_its_fp64_blend"),
+                        "traj_rel_l2": pr.get("trajectory_rel_l2")}
+    if out.get("cpu_baseline"):
+        sm["cpu_Msplats_s"] = [out["cpu_baseline"]["value"], out["cpu_baseline"]["cores"]]
+    if out.get("dit"):
+        sm["dit"] = {d["arch"].replace("DiT-PixArt-PCD-CLAY-", ""): [d["ms_per_nfe"], d.get("frac_of_mfma_peak")] for d in out["dit"]}
+        sm["dit_is"] = "[ms/NFE, frac bf16 MFMA peak]"
+        b = out["dit"][0]
+        sm["ditB_dopri5"] = [g(b, "dopri5_parity_mode", "sec"), g(b, "dopri5_parity_mode", "nfe")]
+        sm["ditB_cpu_ms_nfe"] = g(b, "cpu_baseline", "value")
+    if out.get("dit_batched"):
+        sm["dit_x4_ms"] = out["dit_batched"]["ms_per_nfe"]
+    if out.get("attention"):
+        at = out["attention"]
+        sm["attn_us"] = [g(at, "self_attention_2x16x768x768", "us"), g(at, "cross_attention_1x16x768x1369", "us")]
+        ks = g(at, "mfma_busy_from_counters", "kernels")
+        sm["attn_mfma_busy"] = [round(v["mfma_busy"], 3) for v in ks.values()] if ks else None
+    if out.get("decode"):
+        sm["decode_ms"] = out["decode"]["ms_per_decode"]
+    if out.get("conditioner"):
+        sm["cond_ms"] = out["conditioner"]["ms_per_image"]
+    if out.get("backward"):
+        sm["bwd_ms"] = [out["backward"]["forward_autograd_ms"], out["backward"]["loss_plus_backward_ms"]]
+    if out.get("cascade"):
+        sm["sec_per_sample"] = out.get("sec_per_sample")
+        sm["sec_per_sample_dopri5"] = out.get("sec_per_sample_dopri5")
+        sm["dopri5_nfe"] = [g(out["cascade"], "dopri5", "nfe_stage1"), g(out["cascade"], "dopri5", "nfe_stage2")]
+    return sm
 
 
 def self_launch(n, argv):
@@ -764,6 +870,11 @@ def main():
             out["parity"] = parity_check(g, cams, H, W, dev)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g, cams, H, W)
+        if world == 1 and not a.no_dit and not a.no_parity:
+            tp = trajectory_parity(dev)     # BASELINE configs[2] at real depth against the fp32 oracle trajectory (CPU: ~40 s)
+            out.setdefault("parity", {})["trajectory"] = tp
+            out["parity"]["trajectory_rel_l2"] = tp["trajectory_rel_l2"]
+            out["parity"]["pass"] = bool(out["parity"].get("pass", True) and tp["pass"])
         if world == 1 and not a.no_dit:
             # second half of the headline metric ("sec/sample 250-step cascaded"): the two release-size denoisers
             out["dit"] = [bench_dit(dev, arch, a.dit_nfe, 3, parity_mode=(arch == "DiT-PixArt-PCD-CLAY-B")) for arch in
@@ -790,6 +901,7 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:
+        out["summary"] = summary_of(out)     # LAST key: the figures of the line in <= 1500 characters (a 2000-character tail keeps them)
         try:   # RCCL's version banner sits in the C stdio buffer: let it out BEFORE the one JSON line, not after it
             ctypes.CDLL(None).fflush(None)
         except OSError:

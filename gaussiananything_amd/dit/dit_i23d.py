@@ -14,7 +14,9 @@ names :1665-1697 -- on top of the hand-written HIP kernels behind include/ga_dit
 from __future__ import annotations
 
 import ctypes
+import contextlib
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -145,6 +147,34 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         self.initialize_weights()
         self._pack = None
         self._ctx_cache = None
+        self._busy = threading.RLock()        # see _exclusive()
+        self._last_use = None                # (stream, event recorded behind the last call's work)
+
+    # -- re-entrancy ----------------------------------------------------------------------------------------------------
+    # The workspace, the cached K / V projections, the resident conditioning and the captured sampler steps with their state buffers
+    # belong to the MODULE (one set per shape): that is what lets a captured step serve the next sample.  Two calls on one module
+    # therefore must not overlap.  (i) Calls from different STREAMS of one thread are serialised on the device: a call first makes
+    # its stream wait for the event recorded behind the previous call's work.  (ii) Calls from different host THREADS at the same
+    # time are refused with an error -- use one module per concurrent sampling loop (the weights can be shared tensors).
+    @contextlib.contextmanager
+    def _exclusive(self, dev):
+        if torch.cuda.is_current_stream_capturing():        # inside the caller's own capture: ordering is the caller's
+            yield
+            return
+        if not self._busy.acquire(blocking=False):
+            raise RuntimeError("this DiT module is already inside a forward / sampling call on another thread: its workspace, cached "
+                               "context and captured sampler steps are per module -- use one module per concurrent sampling loop "
+                               "(INTEGRATION.md section 3)")
+        try:
+            cur = torch.cuda.current_stream(dev)
+            if self._last_use is not None and self._last_use[0] != cur:
+                cur.wait_event(self._last_use[1])
+            yield
+            ev = self._last_use[1] if self._last_use is not None and self._last_use[0] == cur else torch.cuda.Event()
+            ev.record(cur)
+            self._last_use = (cur, ev)
+        finally:
+            self._busy.release()
 
     # -- initialisation (dit_models_xformers.py:1119-1159, dit_i23d.py:209-214,508-509) ---------------------------------
     def initialize_weights(self):
@@ -258,6 +288,10 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         assert isinstance(context, dict)
         if x.device.type != "cuda":
             raise RuntimeError("gaussiananything_amd DiT only runs on an MI355X (HIP) device; there is no CPU path")
+        with self._exclusive(x.device):
+            return self._forward(x, timesteps, context, _step)
+
+    def _forward(self, x, timesteps, context, _step):
         dev = x.device
         pack = self._prepare(dev)
         B, L, C = x.shape
@@ -334,8 +368,12 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
             sig.append((t.data_ptr(), tuple(t.shape)))
         return tuple(sig)
 
-    @torch.no_grad()
     def sample_euler_fused(self, y0, t_grid, context, cfg_scale=1.0, cfg=True):
+        with self._exclusive(y0.device):
+            return self._sample_euler_fused(y0, t_grid, context, cfg_scale, cfg)
+
+    @torch.no_grad()
+    def _sample_euler_fused(self, y0, t_grid, context, cfg_scale=1.0, cfg=True):
         """The reference's fixed-grid Euler sampling loop (transport/integrators.py:100-119 with method "euler":
         y_{k+1} = y_k + (t_{k+1} - t_k) f(t_k, y_k), all grid states returned) with the whole step on the device: the
         function evaluation, the CFG combine of ``forward_with_cfg`` and the state update leave through the final-layer
@@ -406,8 +444,12 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         return out.clone() if sig is not None else out
 
 
-    @torch.no_grad()
     def sample_dopri5_device(self, y0, t_grid, context, cfg_scale=1.0, cfg=True, atol=1e-6, rtol=1e-3, stats=None, max_steps=1 << 16):
+        with self._exclusive(y0.device):
+            return self._sample_dopri5_device(y0, t_grid, context, cfg_scale, cfg, atol, rtol, stats, max_steps)
+
+    @torch.no_grad()
+    def _sample_dopri5_device(self, y0, t_grid, context, cfg_scale=1.0, cfg=True, atol=1e-6, rtol=1e-3, stats=None, max_steps=1 << 16):
         """The reference's DEFAULT sampler -- torchdiffeq's dopri5 behind ``ode.sample`` (transport/integrators.py:100-119,
         flow_matching_trainer.py:715) -- with the adaptive loop on the device (csrc/ode_dopri5.hip): one attempted step = six
         (stage input, function evaluation with the guided velocity leaving through the final-layer kernel) pairs, the error norm, a

@@ -14,7 +14,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle_surfel.so")
+_LIB64_PATH = os.path.join(_HERE, "_build", "liboracle_surfel_f64.so")   # blend arithmetic in double (yardstick, see surfel_raster.c)
 _lib = None
+_lib64 = None
 
 
 class _Pre(ctypes.Structure):
@@ -32,7 +34,7 @@ class _Pre(ctypes.Structure):
 def build(force: bool = False) -> str:
     """Compile the C oracle with gcc (a few hundred ms).  Building the checker is not using it."""
     src = os.path.join(_HERE, "surfel_raster.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    if force or any(not os.path.exists(q) or os.path.getmtime(q) < os.path.getmtime(src) for q in (_LIB_PATH, _LIB64_PATH)):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
 
@@ -44,6 +46,15 @@ def lib():
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.oracle_count.restype = ctypes.c_int64
     return _lib
+
+
+def lib_f64():
+    global _lib64
+    if _lib64 is None:
+        build()
+        _lib64 = ctypes.CDLL(_LIB64_PATH)
+        _lib64.oracle_count.restype = ctypes.c_int64
+    return _lib64
 
 
 def _p(a):
@@ -58,14 +69,14 @@ def _f32(a, shape=None):
 
 
 def rasterize(means3D, opacities, colors, scales, rotations, viewmatrix, projmatrix, bg, H, W,
-              scale_modifier=1.0, threads=None):
+              scale_modifier=1.0, threads=None, blend_f64=False):
     """One view.  Matrices follow the reference's row-vector convention (cam_view / cam_view_proj).
 
     Returns a dict: color[3,H,W], allmap[7,H,W], radii[N] i32, rect[N,4] u32, tiles_touched[N] u32,
     depths/xy/trans/normal_opacity (f32), point_list[D] u32, keys[D] u64, ranges[tiles,2] u32,
     final_T[H,W], n_contrib[H,W], n_walked[H,W] (list entries each pixel visited), D, pairs.
     """
-    L = lib()
+    L = lib_f64() if blend_f64 else lib()     # (preprocess and binning are the same fp32 code in both libraries)
     means3D = _f32(means3D, (-1, 3)); N = means3D.shape[0]
     opacities = _f32(opacities, (N,)); colors = _f32(colors, (N, 3))
     scales = _f32(scales, (N, 2)); rotations = _f32(rotations, (N, 4))

@@ -220,6 +220,20 @@ void oracle_bin(int N, int H, int W, const OraclePre *o, int64_t D, uint64_t *ke
     }
 }
 
+/* Arithmetic type of the blend.  float = the oracle proper.  -DORACLE_BLEND_F64 builds the SAME loop with every per-pair
+ * operation in double (inputs are still the fp32 preprocess artefacts; outputs rounded to float at the end): a yardstick for how far
+ * ANY fp32 evaluation order -- this file's included -- sits from exact arithmetic at a pixel (threshold decisions that flip,
+ * cancellation in the cross product of nearly edge-on splats).  tools/parity_maxabs.py prints HIP-vs-this beside this-vs-f64. */
+#ifdef ORACLE_BLEND_F64
+typedef double breal;
+#define BEXP exp
+#define BMIN fmin
+#else
+typedef float breal;
+#define BEXP expf
+#define BMIN fminf
+#endif
+
 /* Per-tile front-to-back blend (upstream renderCUDA, RENDER_AXUTILITY=1, DUAL_VISIABLE=1).
  * pair_count (optional): number of (pixel, list entry) evaluations actually started, i.e. the real K. */
 void oracle_blend(int N, int H, int W, const OraclePre *o, const float *colors, const float *bg,
@@ -237,35 +251,35 @@ void oracle_blend(int N, int H, int W, const OraclePre *o, const float *colors, 
             for (int lx = 0; lx < BLOCK_X; ++lx) {
                 const int pxi = tx * BLOCK_X + lx, pyi = ty * BLOCK_Y + ly;
                 if (pxi >= W || pyi >= H) continue;
-                const float pxf = (float)pxi, pyf = (float)pyi;
-                float T = 1.0f, C[3] = {0, 0, 0}, Nr[3] = {0, 0, 0};
-                float Dp = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
+                const breal pxf = (breal)pxi, pyf = (breal)pyi;
+                breal T = 1.0f, C[3] = {0, 0, 0}, Nr[3] = {0, 0, 0};
+                breal Dp = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
                 uint32_t contributor = 0, last_contributor = 0;
                 for (uint32_t j = r0; j < r1; ++j) {
                     const uint32_t id = point_list[j];
                     ++contributor; ++pairs;
                     const float *Tu = o->trans + 9 * id, *Tv = Tu + 3, *Tw = Tu + 6;
-                    const float kx = pxf * Tw[0] - Tu[0], ky = pxf * Tw[1] - Tu[1], kz = pxf * Tw[2] - Tu[2];
-                    const float lx_ = pyf * Tw[0] - Tv[0], ly_ = pyf * Tw[1] - Tv[1], lz_ = pyf * Tw[2] - Tv[2];
-                    const float p0 = ky * lz_ - kz * ly_, p1 = kz * lx_ - kx * lz_, p2 = kx * ly_ - ky * lx_;
+                    const breal kx = pxf * Tw[0] - Tu[0], ky = pxf * Tw[1] - Tu[1], kz = pxf * Tw[2] - Tu[2];
+                    const breal lx_ = pyf * Tw[0] - Tv[0], ly_ = pyf * Tw[1] - Tv[1], lz_ = pyf * Tw[2] - Tv[2];
+                    const breal p0 = ky * lz_ - kz * ly_, p1 = kz * lx_ - kx * lz_, p2 = kx * ly_ - ky * lx_;
                     if (p2 == 0.0f) continue;
-                    const float sx = p0 / p2, sy = p1 / p2;
-                    const float rho3d = sx * sx + sy * sy;
-                    const float dx = o->xy[2 * id] - pxf, dy = o->xy[2 * id + 1] - pyf;
-                    const float rho2d = FILTER_INV_SQUARE * (dx * dx + dy * dy);
-                    const float rho = fminf(rho3d, rho2d);
-                    const float depth = (rho3d <= rho2d) ? (sx * Tw[0] + sy * Tw[1]) + Tw[2] : Tw[2];
+                    const breal sx = p0 / p2, sy = p1 / p2;
+                    const breal rho3d = sx * sx + sy * sy;
+                    const breal dx = o->xy[2 * id] - pxf, dy = o->xy[2 * id + 1] - pyf;
+                    const breal rho2d = FILTER_INV_SQUARE * (dx * dx + dy * dy);
+                    const breal rho = BMIN(rho3d, rho2d);
+                    const breal depth = (rho3d <= rho2d) ? (sx * Tw[0] + sy * Tw[1]) + Tw[2] : Tw[2];
                     if (depth < NEAR_N) continue;
                     const float *no = o->normal_opacity + 4 * id;
-                    const float power = -0.5f * rho;
+                    const breal power = -0.5f * rho;
                     if (power > 0.0f) continue;
-                    const float alpha = fminf(0.99f, no[3] * expf(power));
+                    const breal alpha = BMIN((breal)0.99f, no[3] * BEXP(power));
                     if (alpha < 1.0f / 255.0f) continue;
-                    const float test_T = T * (1 - alpha);
+                    const breal test_T = T * (1 - alpha);
                     if (test_T < 0.0001f) break; /* done */
-                    const float w = alpha * T;
-                    const float A = 1 - T;
-                    const float m = FAR_N / (FAR_N - NEAR_N) * (1 - NEAR_N / depth);
+                    const breal w = alpha * T;
+                    const breal A = 1 - T;
+                    const breal m = FAR_N / (FAR_N - NEAR_N) * (1 - NEAR_N / depth);
                     distortion += (m * m * A + M2 - 2 * m * M1) * w;
                     Dp += depth * w;
                     M1 += m * w;
@@ -277,15 +291,15 @@ void oracle_blend(int N, int H, int W, const OraclePre *o, const float *colors, 
                     last_contributor = contributor;
                 }
                 const size_t pid = (size_t)pyi * W + pxi, HW = (size_t)H * W;
-                if (final_T) final_T[pid] = T;
+                if (final_T) final_T[pid] = (float)T;
                 if (n_contrib) n_contrib[pid] = last_contributor;
                 if (n_walked) n_walked[pid] = contributor; /* list entries visited, the stopping one included */
-                for (int ch = 0; ch < 3; ++ch) out_color[ch * HW + pid] = C[ch] + T * bg[ch];
-                out_others[DEPTH_OFFSET * HW + pid] = Dp;
-                out_others[ALPHA_OFFSET * HW + pid] = 1 - T;
-                for (int ch = 0; ch < 3; ++ch) out_others[(NORMAL_OFFSET + ch) * HW + pid] = Nr[ch];
-                out_others[MIDDEPTH_OFFSET * HW + pid] = median_depth;
-                out_others[DISTORTION_OFFSET * HW + pid] = distortion;
+                for (int ch = 0; ch < 3; ++ch) out_color[ch * HW + pid] = (float)(C[ch] + T * bg[ch]);
+                out_others[DEPTH_OFFSET * HW + pid] = (float)Dp;
+                out_others[ALPHA_OFFSET * HW + pid] = (float)(1 - T);
+                for (int ch = 0; ch < 3; ++ch) out_others[(NORMAL_OFFSET + ch) * HW + pid] = (float)Nr[ch];
+                out_others[MIDDEPTH_OFFSET * HW + pid] = (float)median_depth;
+                out_others[DISTORTION_OFFSET * HW + pid] = (float)distortion;
             }
     }
     if (pair_count) *pair_count = pairs;

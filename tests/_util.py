@@ -5,12 +5,12 @@ import torch
 from gaussiananything_amd import synthetic
 
 
-def oracle_view(g, cams, v, H, W, bg=(1.0, 1.0, 1.0), scale_modifier=1.0):
+def oracle_view(g, cams, v, H, W, bg=(1.0, 1.0, 1.0), scale_modifier=1.0, blend_f64=False):
     from oracle import surfel as osurf
     m, o, s, r, c = synthetic.split_gaussians(g)
     return osurf.rasterize(m.numpy(), o.numpy(), c.numpy(), s.numpy(), r.numpy(), cams["cam_view"][v].numpy(),
                            cams["cam_view_proj"][v].numpy(), np.asarray(bg, np.float32), H, W,
-                           scale_modifier=scale_modifier)
+                           scale_modifier=scale_modifier, blend_f64=blend_f64)
 
 
 def hip_views(g, cams, views, H, W, device, bg=(1.0, 1.0, 1.0), scale_modifier=1.0):

@@ -646,6 +646,68 @@ def test_full_depth_sampling_trajectory_against_the_fp32_oracle(gpu_device, arch
         assert st.get("device_loop") and st["nfe"] >= 7 and stats_o["nfe"] >= 7
 
 
+def test_sampling_calls_from_two_streams_and_two_threads_on_one_module(gpu_device):
+    """The workspace, the cached K / V, the resident conditioning and the captured sampler steps belong to the module
+    (/root/reference/nsr/lsgm/flow_matching_trainer.py:700-744 samples one request at a time; a serving loop with overlap would not).
+    (i) Two sampling calls issued back to back from two different streams, with nothing synchronised in between, give the results of
+    the same calls run one after the other: the second call's stream waits for the event behind the first call's work.
+    (ii) A second host thread entering the module while a call is in progress gets a RuntimeError instead of shared buffers."""
+    import threading
+    from gaussiananything_amd.transport import Sampler, create_transport
+    z, model, ctx = _load_golden(1, gpu_device)
+    x = z["x"].to(gpu_device)
+    ctx2 = {k: (v * 0.5).contiguous() for k, v in ctx.items()}
+    sampler = Sampler(create_transport("GVP", "velocity", None, None, None, snr_type="uniform"))
+
+    def run(xx, cc, method):
+        fn = sampler.sample_ode(sampling_method=method, num_steps=12, atol=1e-6, rtol=1e-3)
+        with torch.no_grad():
+            return fn(xx, model.forward_with_cfg, context=cc, cfg_scale=z["cfg_scale"])
+
+    for method in ("euler", "dopri5"):
+        want_a = run(x, ctx, method).clone()
+        torch.cuda.synchronize()
+        want_b = run(0.7 * x, ctx2, method).clone()
+        torch.cuda.synchronize()
+        sa, sb = torch.cuda.Stream(gpu_device), torch.cuda.Stream(gpu_device)
+        for rep in range(3):
+            with torch.cuda.stream(sa):
+                got_a = run(x, ctx, method)
+            with torch.cuda.stream(sb):              # (no synchronisation: stream sb would race stream sa's replays without the event)
+                got_b = run(0.7 * x, ctx2, method)
+            torch.cuda.synchronize()
+            assert torch.equal(got_a, want_a) and torch.equal(got_b, want_b), (method, rep)
+    # (ii) another thread while a call is in progress
+    seen = {}
+    inside, leave = threading.Event(), threading.Event()
+    real = model._forward
+
+    def slow_forward(*a, **k):
+        inside.set()
+        leave.wait(20)
+        return real(*a, **k)
+
+    def first():
+        try:
+            model._forward = slow_forward
+            with torch.no_grad():
+                seen["first"] = model(x, z["t"].to(gpu_device), ctx)
+        finally:
+            model._forward = real
+
+    th = threading.Thread(target=first)
+    th.start()
+    assert inside.wait(20)
+    with pytest.raises(RuntimeError, match="one module per concurrent sampling loop"):
+        with torch.no_grad():
+            model(x, z["t"].to(gpu_device), ctx)
+    leave.set()
+    th.join(30)
+    with torch.no_grad():
+        again = model(x, z["t"].to(gpu_device), ctx)
+    assert torch.equal(again, seen["first"])
+
+
 def test_cpu_tensors_raise(gpu_device):
     z, model, ctx = _load_golden(1, gpu_device)
     with pytest.raises(RuntimeError):
