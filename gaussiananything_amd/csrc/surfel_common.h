@@ -33,7 +33,11 @@ constexpr int kBinSplats = GA_BIN_SPLATS;           // splats per thread in the 
 #ifndef GA_PRE_SPLATS
 #define GA_PRE_SPLATS 2
 #endif
-constexpr int kPreSplats = GA_PRE_SPLATS;  // splats per thread in the preprocess kernel
+constexpr int kPreSplats = GA_PRE_SPLATS;  // groups of 256 Gaussians per workgroup of the preprocess kernel (1, 2 or 4)
+#ifndef GA_PRE_VIEWS
+#define GA_PRE_VIEWS 2
+#endif
+constexpr int kPreViews = GA_PRE_VIEWS;    // views a thread of the preprocess kernel walks with its Gaussian's camera-independent part in registers
 constexpr int kViewSlots = 64;          // words the per-view entry count is spread over (same-address atomics serialise)
 constexpr int kLdsTiles = 8192;         // per-view tile counters aggregated in LDS up to this many tiles (32 KiB)
 // Segmented blend: lists of >= kLongList entries (length class >= kSegClass; class b holds 2^(b-1) <= n < 2^b) are cut into

@@ -18,6 +18,8 @@ typedef struct {
 } SimOut;
 
 #define MAXCH 512
+static int g_chunk = 64;   /* entries per window unit (64: the kernel's chunks; 32: half-chunk windows, round 5 study) */
+void blend_sim_set_chunk(int c) { g_chunk = c; }
 
 /* windowed schedule on one wave: cnt[lane][chunk]; window of W chunks; kU entries per trip; a step ends when the tail
  * chunk is exhausted in every lane (W = 2 is the current kernel).  Returns trips; *chunks = chunks staged. */
@@ -115,7 +117,7 @@ void blend_sim(int H, int W_img, int ntiles_x, int ntiles_y, const uint32_t *ran
             for (int sg = 0; sg < segs; ++sg) {
                 const int sb = sg * cps * 64, se = (sb + cps * 64 < n) ? sb + cps * 64 : n;
                 if (sb >= n) break;
-                const int nch = (se - sb + 63) / 64;
+                const int nch = (se - sb + g_chunk - 1) / g_chunk;
                 if (nch > MAXCH) continue;
                 memset(cnt, 0, sizeof(cnt));
                 int lastc[4][64];
@@ -125,7 +127,7 @@ void blend_sim(int H, int W_img, int ntiles_x, int ntiles_y, const uint32_t *ran
                 double pairs = 0;
                 for (int j = sb; j < se; ++j) {
                     const uint32_t id = point_list[r0 + j];
-                    const int ch = (j - sb) / 64;
+                    const int ch = (j - sb) / g_chunk;
                     uint32_t colm = 0, rowm = 0;
                     for (int k = 0; k < 16; ++k) {
                         const float px = (float)(tx * 16 + k), py = (float)(ty * 16 + k);
@@ -144,7 +146,7 @@ void blend_sim(int H, int W_img, int ntiles_x, int ntiles_y, const uint32_t *ran
                             int w, l;
                             if (map == 0) { w = (y >> 3) * 2 + (x >> 3); l = (y & 7) * 8 + (x & 7); }
                             else { w = (y & 1) * 2 + (x & 1); l = (y >> 1) * 8 + (x >> 1); }
-                            if (ch < 8 && ((colm >> x) & 1) && ((rowm >> y) & 1)) proxy[w][l]++;
+                            if (ch < 8 * 64 / g_chunk && ((colm >> x) & 1) && ((rowm >> y) & 1)) proxy[w][l]++;
                             if (j < walked) {
                                 /* the lane is alive at this entry: its wave has to stage this chunk */
                                 if (ch > lastc[w][l]) lastc[w][l] = ch;
