@@ -80,6 +80,32 @@ __global__ __launch_bounds__(256) void small_linear_kernel(GaSmallLinearArgs a)
 #pragma unroll
     for (int b = 0; b < 16; ++b) acc[b] = 0.f;
     const uint16_t *w = a.W + (size_t)n * a.K;
+    if (a.act_in == 2) {   // x = timesteps [B]; the input row is TimestepEmbedder.timestep_embedding(t) (K = 256), formed here
+        // exactly as timestep_freq_kernel forms it: [cos(t f_j) | sin(t f_j)], f_j = exp(-ln(10000) j / 128)
+        const int k = lane * 8;
+        if (k < a.K) {
+            const uint4 wr = *reinterpret_cast<const uint4 *>(w + k);
+            const uint32_t ww[4] = {wr.x, wr.y, wr.z, wr.w};
+            float fr[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = k + e, f = j < 128 ? j : j - 128;
+                fr[e] = expf(-9.210340371976184f * (float)f / 128.0f);
+            }
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                if (b < a.B) {
+                    const float tb = a.x[b];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float arg = tb * fr[e];
+                        const float xv = (k + e) < 128 ? cosf(arg) : sinf(arg);
+                        const float wv = (e & 1) ? __uint_as_float(ww[e >> 1] & 0xffff0000u) : __uint_as_float(ww[e >> 1] << 16);
+                        acc[b] += bf16_to_f32(f32_to_bf16(xv)) * wv;
+                    }
+                }
+        }
+    } else
 #pragma unroll 2
     for (int k = lane * 8; k < a.K; k += 512) {
         const uint4 wr = *reinterpret_cast<const uint4 *>(w + k);
@@ -392,7 +418,7 @@ extern "C" int ga_small_linear(const GaSmallLinearArgs *a, void *stream)
 {
     using namespace gadit;
     if (!a || !a->x || !a->W || !a->y) return GA_DIT_ERR_NULL_ARG;
-    if (a->B <= 0 || a->B > 16 || a->N <= 0 || a->K <= 0 || a->K % 8 != 0) return GA_DIT_ERR_BAD_SHAPE;
+    if (a->B <= 0 || a->B > 16 || a->N <= 0 || a->K <= 0 || a->K % 8 != 0 || (a->act_in == 2 && a->K != 256)) return GA_DIT_ERR_BAD_SHAPE;
     hipLaunchKernelGGL(small_linear_kernel, dim3((a->N + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
     return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
 }
@@ -505,6 +531,17 @@ extern "C" int ga_dit_cache_context(const GaDitModel *m, int32_t batch, int32_t 
     return GA_DIT_OK;
 }
 
+extern "C" int ga_dit_pooled_vector(const GaDitModel *m, int32_t batch, const float *img_vector, float *scratch, float *out, void *stream)
+{
+    using namespace gadit;
+    if (!model_ok(m) || !img_vector || !scratch || !out) return GA_DIT_ERR_NULL_ARG;
+    if (batch <= 0 || batch > 16) return GA_DIT_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(layernorm_rows_kernel, dim3(batch), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), img_vector, m->pool_ln_w,
+                       m->pool_ln_b, scratch, m->context_dim, 1e-5f);
+    GaSmallLinearArgs l2{batch, m->hidden, m->context_dim, 0, 0, scratch, m->pool_w, m->pool_b, nullptr, out};
+    return ga_small_linear(&l2, stream);
+}
+
 extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, void *stream)
 {
     using namespace gadit;
@@ -522,14 +559,16 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     (void)hipGetLastError();
 
     // ---- conditioning path: t = t_embedder(timesteps) + pooled_vec_embedder(img_vector); t0 = adaLN(SiLU(t))
-    hipLaunchKernelGGL(timestep_freq_kernel, dim3((B * 256 + 255) / 256), dim3(256), 0, s, a->timesteps, w.tfreq, B);
-    GaSmallLinearArgs l1{B, D, 256, 0, 1, w.tfreq, m->t_mlp0_w, m->t_mlp0_b, nullptr, w.t1};
+    // (round 5: the sinusoidal features are formed inside the first linear -- one launch less -- and the pooled-vector branch, which
+    //  does not depend on the time, is taken from the caller when it has been computed once per conditioning: ga_dit_pooled_vector)
+    GaSmallLinearArgs l1{B, D, 256, 2, 1, a->timesteps, m->t_mlp0_w, m->t_mlp0_b, nullptr, w.t1};
     GA_TRY(ga_small_linear(&l1, stream));
-    hipLaunchKernelGGL(layernorm_rows_kernel, dim3(B), dim3(64), 0, s, a->img_vector, m->pool_ln_w, m->pool_ln_b, w.pln,
-                       m->context_dim, 1e-5f);
-    GaSmallLinearArgs l2{B, D, m->context_dim, 0, 0, w.pln, m->pool_w, m->pool_b, nullptr, w.pvec};
-    GA_TRY(ga_small_linear(&l2, stream));
-    GaSmallLinearArgs l3{B, D, D, 0, 0, w.t1, m->t_mlp2_w, m->t_mlp2_b, w.pvec, w.tvec};
+    const float *pvec = a->pooled_vec;
+    if (!pvec) {
+        GA_TRY(ga_dit_pooled_vector(m, B, a->img_vector, w.pln, w.pvec, stream));
+        pvec = w.pvec;
+    }
+    GaSmallLinearArgs l3{B, D, D, 0, 0, w.t1, m->t_mlp2_w, m->t_mlp2_b, pvec, w.tvec};
     GA_TRY(ga_small_linear(&l3, stream));
     GaSmallLinearArgs l4{B, 6 * D, D, 1, 0, w.tvec, m->adaln_w, m->adaln_b, nullptr, w.t0};
     GA_TRY(ga_small_linear(&l4, stream));
@@ -550,12 +589,18 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     static const bool sb_tail_env = [] { const char *e = getenv("GA_DIT_SBTAIL"); return !e || atoi(e) != 0; }();
     // the shift rows of block i + 1 ride behind the self-attention grid of block i while that grid leaves CUs idle (a CFG pair: 192
     // workgroups + 56 of the tail on 256 CUs); on a full grid they would queue behind it (8 items: 9.2 -> 9.8 ms) -- one launch up front then
-    bool sb_tail = false;
+    bool sb_tail = false, sb_tail0 = false;
+    const int ca_batch = (a->ca_batch <= 0 || a->ca_batch > B) ? B : a->ca_batch;
     if (fold_mod && sb_tail_env) {
         const GaAttentionArgs probe{B, m->heads, L, L, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0};
         sb_tail = attention_workgroups(&probe) + shift_bias_wgs(3 * D, 4 * D) <= 256;
+        // round 5: block 0's rows ride the same way behind block 0's CROSS-attention grid (its qkv projection is the first consumer):
+        // the stand-alone 12 us launch in front of the blocks is gone when that grid leaves the CUs free as well
+        const GaAttentionArgs probe_ca{ca_batch, m->heads, L, a->ctx_tokens, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0};
+        static const bool sb_tail0_env = [] { const char *e = getenv("GA_DIT_SBTAIL0"); return !e || atoi(e) != 0; }();   // A/B aid
+        sb_tail0 = sb_tail0_env && sb_tail && attention_workgroups(&probe_ca) + shift_bias_wgs(3 * D, 4 * D) <= 256;
     }
-    if (fold_mod) {
+    if (fold_mod && !sb_tail0) {
         ShiftBiasArgs sb{};
         for (int i = 0; i < m->depth; ++i) {
             sb.W[2 * i] = m->blocks[i].qkv_w; sb.bias[2 * i] = m->blocks[i].qkv_b;
@@ -580,7 +625,6 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     const size_t kv_rows = (size_t)B * a->ctx_tokens;
     const int64_t Mp = ((int64_t)a->ctx_tokens + 63) / 64 * 64, Lp = ((int64_t)L + 63) / 64 * 64;
     if (Lp != L && hipMemsetAsync(w.vt, 0, w.vt_bytes, s) != hipSuccess) return GA_DIT_ERR_LAUNCH;  // zero key padding
-    const int ca_batch = (a->ca_batch <= 0 || a->ca_batch > B) ? B : a->ca_batch;
     const int Mca = ca_batch * L;
     for (int i = 0; i < m->depth; ++i) {
         const GaDitBlockWeights &bw = m->blocks[i];
@@ -602,7 +646,12 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         GA_UNLESS(32, ga_gemm_bf16(&gq, stream));
         GaAttentionArgs ca{ca_batch, m->heads, L, a->ctx_tokens, w.qkv, a->ca_k + (size_t)i * kv_rows * D,
                            a->ca_vt + (size_t)i * B * D * Mp, D, D, Mp, nullptr, nullptr, w.att, D};
-        GA_UNLESS(2, ga_attention_bf16(&ca, stream));
+        if (i == 0 && sb_tail0) {
+            ShiftBiasJob job{{bw.qkv_w, bw.fc1_w}, {bw.qkv_b, bw.fc1_b}, w.mod, w.sbias,
+                             6 * (long long)D, 3 * (long long)D, 3 * D, 4 * D, D, B, m->gemm_weights_tiled};
+            GA_UNLESS(2, attention_with_tail(&ca, &job, stream));
+        } else
+            GA_UNLESS(2, ga_attention_bf16(&ca, stream));
         GaGemmArgs go{};
         go.M = Mca; go.N = D; go.K = D; go.epilogue = GA_GEMM_EPI_RESIDUAL; go.A = w.att; go.lda = D; go.W = bw.ca_out_w; go.w_tiled = m->gemm_weights_tiled;
         go.bias = bw.ca_out_b; go.out = w.xres; go.ldo = D; go.gate = nullptr; go.rows_per_batch = L;

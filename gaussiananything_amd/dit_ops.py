@@ -77,11 +77,12 @@ GA_ODE_CTL_ALLOC = 24 + 2048    # + one error-norm partial per workgroup of the 
 class GaDitForwardArgs(ctypes.Structure):
     _fields_ = [("batch", i32), ("tokens", i32), ("ctx_tokens", i32), ("x", c_p), ("timesteps", c_p),
                 ("img_vector", c_p), ("fps_xyz", c_p), ("ca_k", c_p), ("ca_vt", c_p), ("out", c_p), ("workspace", c_p),
-                ("workspace_bytes", ctypes.c_size_t), ("ca_batch", i32), ("step", ctypes.POINTER(GaDitSamplerStep))]
+                ("workspace_bytes", ctypes.c_size_t), ("ca_batch", i32), ("step", ctypes.POINTER(GaDitSamplerStep)),
+                ("pooled_vec", c_p)]
 
 
 DIT_EXPORTS = ("ga_gemm_bf16", "ga_attention_bf16", "ga_rmsnorm_modulate", "ga_small_linear", "ga_dit_workspace_bytes",
-               "ga_dit_cache_context", "ga_dit_forward", "ga_dit_shift_bias", "ga_dit_sampler_advance", "ga_ode_dopri5_stage", "ga_ode_dopri5_finish",
+               "ga_dit_cache_context", "ga_dit_forward", "ga_dit_pooled_vector", "ga_dit_shift_bias", "ga_dit_sampler_advance", "ga_ode_dopri5_stage", "ga_ode_dopri5_finish",
                "ga_dit_version")
 _ERR = {-1: "GA_DIT_ERR_NULL_ARG", -2: "GA_DIT_ERR_BAD_SHAPE", -4: "GA_DIT_ERR_LAUNCH"}
 _bound = False
@@ -103,6 +104,8 @@ def lib():
         L.ga_dit_cache_context.argtypes = [ctypes.POINTER(GaDitModel), i32, i32, c_p, c_p, c_p, c_p]
         L.ga_dit_forward.restype = ctypes.c_int
         L.ga_dit_forward.argtypes = [ctypes.POINTER(GaDitModel), ctypes.POINTER(GaDitForwardArgs), c_p]
+        L.ga_dit_pooled_vector.restype = ctypes.c_int
+        L.ga_dit_pooled_vector.argtypes = [ctypes.POINTER(GaDitModel), i32, c_p, c_p, c_p, c_p]
         L.ga_dit_sampler_advance.restype = ctypes.c_int
         L.ga_dit_sampler_advance.argtypes = [c_p, c_p, c_p, i32, c_p, i32, c_p, c_p]
         L.ga_dit_shift_bias.restype = ctypes.c_int

@@ -145,7 +145,8 @@ int ga_rmsnorm_modulate(const GaRmsNormArgs *args, void *stream);
 /* Small dense layer for the conditioning path (a handful of rows):
  *   y[b][n] = act_out( sum_k act_in(x[b][k]) * W[n][k] + bias[n] ) (+ add[b][n]);  act: 0 none, 1 SiLU.  B <= 16, K % 8 == 0. */
 typedef struct GaSmallLinearArgs {
-    int32_t B, N, K, act_in, act_out;
+    int32_t B, N, K, act_in, act_out;   /* act_*: 0 none, 1 SiLU; act_in 2: x is [B] timesteps, the input row is the reference's
+                                           sinusoidal timestep_embedding(t, 256) formed on the fly (K = 256)                      */
     const float *x;      /* [B, K]            */
     const ga_bf16 *W;    /* [N, K]            */
     const float *bias;   /* [N] or NULL       */
@@ -242,6 +243,10 @@ typedef struct GaDitForwardArgs {
      * those items skip the q projection, the 1369-key attention and the output projection -- bit-identical result. */
     int32_t ca_batch;
     const GaDitSamplerStep *step;   /* host pointer, NULL = plain function evaluation into `out`                */
+    /* [B', D] fp32 or NULL: pooled_vec_embedder(img_vector) = Linear(LayerNorm(img_vector)) (dit_i23d.py:540-545) as ga_dit_pooled_vector
+     * computed it for THIS img_vector.  It does not depend on the time: a sampling loop computes it once per conditioning instead of
+     * in each of its ~250 evaluations (two launches of the evaluation's serial head).  NULL: computed inside, into the workspace. */
+    const float *pooled_vec;
 } GaDitForwardArgs;
 
 size_t ga_dit_workspace_bytes(const GaDitModel *model, int32_t batch, int32_t tokens, int32_t ctx_tokens);
@@ -253,6 +258,10 @@ int ga_dit_cache_context(const GaDitModel *model, int32_t batch, int32_t ctx_tok
                          ga_bf16 *ca_k, ga_bf16 *ca_vt, void *stream);
 
 int ga_dit_forward(const GaDitModel *model, const GaDitForwardArgs *args, void *stream);
+
+/* pooled_vec_embedder of the reference model (LayerNorm with affine over context_dim, then Linear context_dim -> D, bf16-rounded
+ * inputs as under autocast): img_vector [B', ctx] fp32 -> out [B', D] fp32; scratch [B', ctx] fp32.  See GaDitForwardArgs.pooled_vec. */
+int ga_dit_pooled_vector(const GaDitModel *model, int32_t batch, const float *img_vector, float *scratch, float *out, void *stream);
 
 /* host: one tiny kernel closing a fused sampler step: ++*counter; timesteps[0..batch) = t_grid[*counter];
  * *dt = dt_grid[*counter] (both grids fp32 device arrays of num_steps - 1 entries; reads past the end are clamped). */

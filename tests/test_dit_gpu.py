@@ -369,6 +369,21 @@ def test_model_matches_reference_golden(gpu_device, stage):
         ycfg = model.forward_with_cfg(x, t, ctx, z["cfg_scale"])
     assert y.dtype == torch.float32 and y.shape == z["y"].shape
     assert torch.equal(y, y2)
+    # the pooled-vector branch is computed once per conditioning vector (GaDitForwardArgs.pooled_vec): same bits as inside the evaluation,
+    # and a vector changed in place is noticed
+    assert model._pooled_cache is not None
+    model.pooled_once = False
+    with torch.no_grad():
+        assert torch.equal(model(x, t, ctx), y)
+    model.pooled_once = True
+    saved = ctx["img_vector"].clone()
+    ctx["img_vector"].add_(torch.linspace(-1.0, 1.0, saved.shape[-1], device=gpu_device))   # (not a scaling: the branch starts with a LayerNorm)
+    with torch.no_grad():
+        y_other = model(x, t, ctx)
+    ctx["img_vector"].copy_(saved)
+    assert not torch.equal(y_other, y)
+    with torch.no_grad():
+        assert torch.equal(model(x, t, ctx), y)
     ref = z["y"].to(gpu_device)
     assert rel_l2(y, ref) < 1.5e-2, rel_l2(y, ref)
     assert float((y - ref).abs().max()) < 5e-2 * float(ref.abs().max())
