@@ -124,44 +124,6 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
     const int Lq = a.Lq, Lk = a.Lk;
     uint16_t *sK = smem + ks * 6 * TPS * TILE, *sV = sK + 3 * TPS * TILE;
 
-    // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + c16][kk*32 + g*8 .. +7], normalised, scaled
-    bf16x8 qf[2];
-    {
-        const int row = min(q0 + c16, Lq - 1);
-        const uint16_t *qp = a.q + ((size_t)b * Lq + row) * a.q_stride + h * HD;
-        float qv[16];
-        float ss = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const uint4 raw = *reinterpret_cast<const uint4 *>(qp + kk * 32 + g * 8);
-            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                qv[kk * 8 + 2 * e] = __uint_as_float(w[e] << 16);
-                qv[kk * 8 + 2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) ss += qv[e] * qv[e];
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        float rs = 0.125f * 1.4426950408889634f;  // 64^-1/2 * log2(e)
-        if (a.q_norm_weight) rs *= rsqrtf(ss * (1.0f / HD) + 1e-5f);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float v = qv[kk * 8 + e];
-                if (a.q_norm_weight) v *= a.q_norm_weight[kk * 32 + g * 8 + e];
-                qf[kk][e] = (short)f32_to_bf16(v * rs);
-            }
-    }
-
-    f32x4 o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = 0.f, l_run = 0.f;  // the group's first tile sets the first reference maximum
-
     const int ntiles = (Lk + KB - 1) / KB, nfull = Lk / KB;
     const uint16_t *vt_base = a.vt + ((size_t)b * a.heads + h) * HD * a.vt_ld;
     const uint16_t *k_base = a.k + (size_t)b * Lk * a.k_stride + h * HD;
@@ -188,6 +150,186 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
 #pragma unroll
         for (int u = 0; u < TPS; ++u) dma_tile(stage * TPS + u, slot * TPS + u);
     };
+    int s0 = 0, s1 = 1, s2 = 2;   // ring slots of the current stage, the next one, and the one being filled
+    bool walk_primed = false;     // the projection below has already requested the key walk's first two stages
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + c16][kk*32 + g*8 .. +7], normalised, scaled
+    bf16x8 qf[2];
+    if (!KNORM && NW == 4 && TPS == 1 && a.qp_a != nullptr) {   // kernel-uniform
+        // THE Q PROJECTION INSIDE THE WORKGROUP (round 5; GaAttentionArgs.qp_*): Q[64 queries x 64] of this head = A rows x W_head^T over
+        // K = qp_k, instead of a GEMM launch of its own in front of the attention (the cross-attention of the denoiser: one launch and
+        // the q round trip through memory less per block).  A 64-wide K-slice of W_head is 64 rows x 128 bytes -- the shape of a K tile
+        // -- and so is the slice of the workgroup's 64 A rows: both are staged by the key walk's LDS-DMA pattern, W into the K ring of
+        // the wave's key group (read with the K walk's permuted fragment rows), A into its V^T ring (read with the V^T walk's natural
+        // rows), which leaves the accumulators of S^T = W_slice A_slice^T in exactly the lanes the Q fragments live in:
+        // acc[kf][r] <-> Q[q0 + c16][32 (kf >> 1) + 8 g + 4 (kf & 1) + r].  The key groups split the K-slices (group ks takes slices
+        // ks, ks + KS, ...) and their partial sums meet in LDS in a fixed order.  Ring: 3 slots, two slices ahead; one counted vmcnt
+        // + one raw barrier per slice as in the key walk (everything is DMA: no compiler-managed load sits in the pipeline -- with the
+        // A fragments as register loads hipcc put s_waitcnt vmcnt(0) in front of every DMA issue of the loop).  The request stream
+        // simply continues into the key walk: request group G is W / A slice group G while G < steps_q and stage G - steps_q of the key
+        // walk after that (both are four DMA instructions per wave), so the walk's first two K / V^T stages are already in flight
+        // when the projection ends and it starts with the slots rotated to where they landed.
+        constexpr int DPQ = 4;                      // DMA instructions per wave per slice: two W pieces + two A pieces of 8 rows
+        const int nsl = a.qp_k >> 6, steps_q = (nsl + KS - 1) / KS;
+        const int qbase = q0 - wq * 16;             // first query row of the workgroup
+        float tot = 0.f;
+        if (a.qp_row_ss) {   // RMSNorm row scale folded out of the A operand (same summation order as the GEMM consumer); used after the loop
+            const float *rp = a.qp_row_ss + ((size_t)b * Lq + min(q0 + c16, Lq - 1)) * a.qp_row_ss_tiles;
+            for (int t4 = 0; t4 < a.qp_row_ss_tiles; t4 += 4) {
+                const float4 q4 = *reinterpret_cast<const float4 *>(rp + t4);
+                tot += (q4.x + q4.y) + (q4.z + q4.w);
+            }
+        }
+        static_assert(KNORM || TPS != 1 || NW != 4 || DPW * TPS == 4, "a stage of the key walk is four DMA instructions per wave, like a slice group");
+        float qnw[16];       // per-head norm weights of my 16 head columns, requested in front of the DMA stream (a load behind it would wait for all of it)
+        {
+            float4 w4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w4[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (a.q_norm_weight) {   // kernel-uniform
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    w4[2 * kk] = *reinterpret_cast<const float4 *>(a.q_norm_weight + kk * 32 + g * 8);
+                    w4[2 * kk + 1] = *reinterpret_cast<const float4 *>(a.q_norm_weight + kk * 32 + g * 8 + 4);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { qnw[4 * i] = w4[i].x; qnw[4 * i + 1] = w4[i].y; qnw[4 * i + 2] = w4[i].z; qnw[4 * i + 3] = w4[i].w; }
+        }
+        auto dma_q = [&](int grp, int slot) {
+            if (grp >= steps_q) { dma_stage((grp - steps_q) * KS + ks, slot); return; }   // the key walk's stages 0, 1 (workgroup-uniform)
+            const int sl = min(grp * KS + ks, nsl - 1);   // past the end: a harmless re-fetch (keeps the vmcnt arithmetic exact)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int p = wq * 2 + i, r8 = p * 8, row = r8 + (lane >> 3), chunk = (lane & 7) ^ swz_of(row);
+                const uint16_t *src = a.qp_w_tiled ? a.qp_w + ((size_t)(h * 8 + p) * nsl + sl) * 512 + (lane >> 3) * 64 + chunk * 8
+                                                   : a.qp_w + (size_t)(h * 64 + row) * a.qp_k + sl * 64 + chunk * 8;
+                glds16(src, sK + slot * TILE + r8 * 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int p = wq * 2 + i, r8 = p * 8, row = r8 + (lane >> 3), chunk = (lane & 7) ^ swz_of(row);
+                const int qrow = min(qbase + row, Lq - 1);
+                glds16(a.qp_a + ((size_t)b * Lq + qrow) * a.qp_lda + sl * 64 + chunk * 8, sV + slot * TILE + r8 * 64);
+            }
+        };
+        f32x4 acc[4];
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) acc[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int krow = 8 * (c16 >> 2) + (c16 & 3);
+        dma_q(0, 0);
+        dma_q(1, 1);
+        for (int t = 0; t < steps_q; ++t) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPQ) : "memory");   // my pieces of slice group t; group t + 1 may be in flight
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (t * KS + ks < nsl) {   // group-uniform
+                const uint16_t *bk = sK + s0 * TILE, *bx = sV + s0 * TILE;
+                bf16x8 frag[4][2], xf[2];
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+                        frag[kf][kk] = *reinterpret_cast<const bf16x8 *>(bk + swz((kf >> 1) * 32 + (kf & 1) * 4 + krow, kk * 4 + g));
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) xf[kk] = *reinterpret_cast<const bf16x8 *>(bx + swz(wq * 16 + c16, kk * 4 + g));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int kf = 0; kf < 4; ++kf) acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag[kf][kk], xf[kk], acc[kf], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            dma_q(t + 2, s2);     // the slot slice group t - 1 left (everybody is past this step's barrier)
+            __builtin_amdgcn_sched_barrier(0);
+            const int r = s0; s0 = s1; s1 = s2; s2 = r;
+        }
+        walk_primed = true;
+        // s0 / s1 now name the slots the key walk's stages 0 / 1 are landing in; s2 held the last slice group
+        if (KS > 1) {   // all key groups need the whole sum: partial accumulators through LDS, added in group order.  The exchange area is
+                        // the FREE slot s2 of every group's rings (K tile: waves 0, 1; V^T tile: waves 2, 3) -- the others have DMA in flight
+            __builtin_amdgcn_s_barrier();          // everybody has read the last slice group (raw: __syncthreads would drain vmcnt)
+            auto xslot = [&](int k2) { return reinterpret_cast<float *>((wq < 2 ? smem + k2 * 6 * TPS * TILE : smem + k2 * 6 * TPS * TILE + 3 * TPS * TILE) + s2 * TILE) + (wq & 1) * 16 * 64 + lane; };
+            float *mine = xslot(ks);
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[(kf * 4 + r) * 64] = acc[kf][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int k2 = 0; k2 < KS; ++k2) sum += xslot(k2)[(kf * 4 + r) * 64];
+                    acc[kf][r] = sum;
+                }
+            // (slot s2 is overwritten by the key walk's stage 2, requested behind the barrier of its first step: everybody has read by then)
+        }
+        const float rsc = a.qp_row_ss ? rsqrtf(tot * (1.0f / (float)a.qp_row_ss_dim) + a.qp_row_ss_eps) : 1.f;
+        // row scale, per-head RMSNorm, bf16 as the projection GEMM would have stored it, then the softmax scale as below
+        float xv[16];
+        float ss = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = acc[2 * kk + (e >> 2)][e & 3] * rsc;
+                xv[kk * 8 + e] = v;
+                ss += v * v;
+            }
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float rn = rsqrtf(ss * (1.0f / HD) + 1e-5f);
+        const float rs = 0.125f * 1.4426950408889634f;  // 64^-1/2 * log2(e)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = xv[kk * 8 + e];
+                if (a.q_norm_weight) v *= rn * qnw[kk * 8 + e];
+                qf[kk][e] = (short)f32_to_bf16(bf16_to_f32(f32_to_bf16(v)) * rs);
+            }
+    } else {
+        {
+            const int row = min(q0 + c16, Lq - 1);
+            const uint16_t *qp = a.q + ((size_t)b * Lq + row) * a.q_stride + h * HD;
+            float qv[16];
+            float ss = 0.f;
+    #pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const uint4 raw = *reinterpret_cast<const uint4 *>(qp + kk * 32 + g * 8);
+                const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+    #pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    qv[kk * 8 + 2 * e] = __uint_as_float(w[e] << 16);
+                    qv[kk * 8 + 2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+                }
+            }
+    #pragma unroll
+            for (int e = 0; e < 16; ++e) ss += qv[e] * qv[e];
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            float rs = 0.125f * 1.4426950408889634f;  // 64^-1/2 * log2(e)
+            if (a.q_norm_weight) rs *= rsqrtf(ss * (1.0f / HD) + 1e-5f);
+    #pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+    #pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = qv[kk * 8 + e];
+                    if (a.q_norm_weight) v *= a.q_norm_weight[kk * 32 + g * 8 + e];
+                    qf[kk][e] = (short)f32_to_bf16(v * rs);
+                }
+        }
+    }
+
+    f32x4 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = 0.f, l_run = 0.f;  // the group's first tile sets the first reference maximum
+
     // ---- staging, register form (KNORM): 512 16-byte chunks per tile and operand; chunk c -> row c>>3, part c&7
     uint4 rk[CPT], rv[CPT];
     auto issue = [&](int tile_raw) {
@@ -336,12 +478,11 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
         issue(ks);
         write_lds(0);
         issue(KS + ks);
-    } else {
+    } else if (!walk_primed) {
         dma_stage(ks, 0);
         dma_stage(KS + ks, 1);
     }
     const int nstages = (ntiles + TPS - 1) / TPS, steps = (nstages + KS - 1) / KS;
-    int s0 = 0, s1 = 1, s2 = 2;
     for (int t = 0; t < steps; ++t) {
         const int stage = t * KS + ks;
         t_stamp = t;
@@ -465,6 +606,11 @@ int attention_workgroups(const GaAttentionArgs *a)
     const int64_t wgs128 = (int64_t)((a->Lq + 127) / 128) * a->heads * a->batch;
     return (int)(wgs128 <= 128 ? (int64_t)((a->Lq + 63) / 64) * a->heads * a->batch : wgs128);
 }
+// the q projection can ride inside the attention workgroups (GaAttentionArgs.qp_*) when the launch takes the 64-query configuration
+bool attention_fuses_q(const GaAttentionArgs *a)
+{
+    return (int64_t)((a->Lq + 127) / 128) * a->heads * a->batch <= 128;
+}
 int attention_with_tail(const GaAttentionArgs *a, const ShiftBiasJob *job, void *stream)
 {
     if (!job || !job->W[0] || !job->W[1] || !job->shift || !job->out) return GA_DIT_ERR_NULL_ARG;
@@ -478,12 +624,18 @@ extern "C" int ga_attention_bf16(const GaAttentionArgs *a, void *stream) { retur
 static int gadit::dispatch_attention(const GaAttentionArgs *a, const ShiftBiasJob *job, void *stream)
 {
     using namespace gadit;
-    if (!a || !a->q || !a->k || !a->vt || !a->out) return GA_DIT_ERR_NULL_ARG;
+    if (!a || (!a->q && !a->qp_a) || !a->k || !a->vt || !a->out) return GA_DIT_ERR_NULL_ARG;
+    if (a->qp_a) {   // the q projection inside the workgroup: LDS-DMA path only, 16-byte aligned operands, K in 64-wide slices
+        if (!a->qp_w || a->k_norm_weight) return GA_DIT_ERR_NULL_ARG;
+        if (a->qp_k < 64 || a->qp_k % 64 || a->qp_lda % 8 || a->qp_lda < a->qp_k || ((uintptr_t)a->qp_a | (uintptr_t)a->qp_w) % 16 != 0 ||
+            (a->qp_row_ss && (a->qp_row_ss_tiles <= 0 || a->qp_row_ss_tiles % 4 != 0 || a->qp_row_ss_dim <= 0 || (uintptr_t)a->qp_row_ss % 16 != 0)))
+            return GA_DIT_ERR_BAD_SHAPE;
+    }
     if (a->batch <= 0 || a->heads <= 0 || a->Lq <= 0 || a->Lk <= 0 || a->q_stride % 8 || a->k_stride % 8 || a->vt_ld % 8 ||
         a->vt_ld < ((a->Lk + KB - 1) / KB) * KB || a->out_stride % 4)
         return GA_DIT_ERR_BAD_SHAPE;
     // 16-byte accesses (vector loads of q, LDS-DMA of k / vt, 8-byte stores of out)
-    if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->vt) % 16 != 0 || (uintptr_t)a->out % 8 != 0) return GA_DIT_ERR_BAD_SHAPE;
+    if (((a->qp_a ? 0 : (uintptr_t)a->q) | (uintptr_t)a->k | (uintptr_t)a->vt) % 16 != 0 || (uintptr_t)a->out % 8 != 0) return GA_DIT_ERR_BAD_SHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // 128-query workgroups when they fill the chip; otherwise (the conditional half of a CFG pair alone in the image
     // cross-attention: 6 x 16 x 1 = 96 workgroups for 256 CUs) 64-query workgroups with two key groups -- measured on
@@ -494,6 +646,7 @@ static int gadit::dispatch_attention(const GaAttentionArgs *a, const ShiftBiasJo
     constexpr int cfg = 0;
 #endif
     const int64_t wgs128 = (int64_t)((a->Lq + 127) / 128) * a->heads * a->batch;
+    if (a->qp_a && (cfg != 0 || wgs128 > 128)) return GA_DIT_ERR_BAD_SHAPE;   // only the 64-query configuration projects q itself (attention_fuses_q)
 #ifdef GA_TUNING
     if (cfg == 23) { launch_attention<2, 3>(*a, s, job); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
     if (cfg == 43) { launch_attention<4, 3>(*a, s, job); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }

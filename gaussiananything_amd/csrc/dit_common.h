@@ -136,5 +136,6 @@ __device__ __forceinline__ void shift_bias_block(const ShiftBiasJob &j, int wg, 
 // CFG pair fills 192 of the 256 CUs with one 96-KiB-LDS workgroup each: the job's weight stream runs on the idle ones)
 int attention_with_tail(const GaAttentionArgs *a, const ShiftBiasJob *job, void *stream);
 int attention_workgroups(const GaAttentionArgs *a);
+bool attention_fuses_q(const GaAttentionArgs *a);
 
 }  // namespace gadit

@@ -637,15 +637,25 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
             GaRmsNormArgs n0{Mca, D, L, w.xres, bw.prenorm_ca_w, nullptr, nullptr, 0, w.xn, nullptr, 0};
             GA_UNLESS(4, ga_rmsnorm_modulate(&n0, stream));
         }
-        GaGemmArgs gq{};
-        gq.M = Mca; gq.N = D; gq.K = D; gq.epilogue = GA_GEMM_EPI_STORE_BF16; gq.A = w.xn; gq.lda = D;
-        gq.W = folded ? bw.ca_q_w_prenorm : bw.ca_q_w; gq.w_tiled = m->gemm_weights_tiled;
-        gq.out = w.qkv; gq.ldo = D;
-        if (folded) { gq.row_ss = w.rowss; gq.row_ss_tiles = D / 64; gq.row_ss_dim = D; gq.row_ss_eps = 1e-5f; }
-        gq.qk_w0 = bw.ca_q_norm_w; gq.qk_cols0 = D; gq.qk_cols1 = D;           // q_norm fused into the projection
-        GA_UNLESS(32, ga_gemm_bf16(&gq, stream));
         GaAttentionArgs ca{ca_batch, m->heads, L, a->ctx_tokens, w.qkv, a->ca_k + (size_t)i * kv_rows * D,
                            a->ca_vt + (size_t)i * B * D * Mp, D, D, Mp, nullptr, nullptr, w.att, D};
+        // round 5: the q projection inside the attention workgroups when the cross-attention runs its 64-query configuration (one
+        // sample's conditional half): one launch per block less, q never goes through memory (GA_DIT_FUSE_Q=0: the GEMM launch, A/B aid)
+        static const bool fuse_q_env = [] { const char *e = getenv("GA_DIT_FUSE_Q"); return !e || atoi(e) != 0; }();
+        if (fuse_q_env && attention_fuses_q(&ca)) {
+            ca.q = nullptr;
+            ca.qp_a = w.xn; ca.qp_lda = D; ca.qp_k = D; ca.qp_w = folded ? bw.ca_q_w_prenorm : bw.ca_q_w; ca.qp_w_tiled = m->gemm_weights_tiled;
+            if (folded) { ca.qp_row_ss = w.rowss; ca.qp_row_ss_tiles = D / 64; ca.qp_row_ss_dim = D; ca.qp_row_ss_eps = 1e-5f; }
+            ca.q_norm_weight = bw.ca_q_norm_w;
+        } else {
+            GaGemmArgs gq{};
+            gq.M = Mca; gq.N = D; gq.K = D; gq.epilogue = GA_GEMM_EPI_STORE_BF16; gq.A = w.xn; gq.lda = D;
+            gq.W = folded ? bw.ca_q_w_prenorm : bw.ca_q_w; gq.w_tiled = m->gemm_weights_tiled;
+            gq.out = w.qkv; gq.ldo = D;
+            if (folded) { gq.row_ss = w.rowss; gq.row_ss_tiles = D / 64; gq.row_ss_dim = D; gq.row_ss_eps = 1e-5f; }
+            gq.qk_w0 = bw.ca_q_norm_w; gq.qk_cols0 = D; gq.qk_cols1 = D;           // q_norm fused into the projection
+            GA_UNLESS(32, ga_gemm_bf16(&gq, stream));
+        }
         if (i == 0 && sb_tail0) {
             ShiftBiasJob job{{bw.qkv_w, bw.fc1_w}, {bw.qkv_b, bw.fc1_b}, w.mod, w.sbias,
                              6 * (long long)D, 3 * (long long)D, 3 * D, 4 * D, D, B, m->gemm_weights_tiled};

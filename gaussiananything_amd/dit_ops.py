@@ -26,7 +26,8 @@ class GaGemmArgs(ctypes.Structure):
 class GaAttentionArgs(ctypes.Structure):
     _fields_ = [("batch", i32), ("heads", i32), ("Lq", i32), ("Lk", i32), ("q", c_p), ("k", c_p), ("vt", c_p),
                 ("q_stride", i64), ("k_stride", i64), ("vt_ld", i64), ("q_norm_weight", c_p), ("k_norm_weight", c_p),
-                ("out", c_p), ("out_stride", i64)]
+                ("out", c_p), ("out_stride", i64), ("qp_a", c_p), ("qp_w", c_p), ("qp_lda", i64), ("qp_k", i32), ("qp_w_tiled", i32),
+                ("qp_row_ss", c_p), ("qp_row_ss_tiles", i32), ("qp_row_ss_dim", i32), ("qp_row_ss_eps", ctypes.c_float)]
 
 
 class GaRmsNormArgs(ctypes.Structure):
@@ -181,21 +182,36 @@ def transpose_v(v):
     return vt.reshape(B * H * 64, Lp)
 
 
-def attention(q, k, vt, q_norm_weight=None, k_norm_weight=None):
+def attention(q, k, vt, q_norm_weight=None, k_norm_weight=None, qp=None):
     """q [B,Lq,H,64], k [B,Lk,H,64] bf16 views (token stride arbitrary, head stride 64), vt = V^T [B*H*64, Lpad]
-    -> [B,Lq,H*64] bf16."""
-    _need_cuda(q, k, vt)
-    B, Lq, H, d = q.shape
+    -> [B,Lq,H*64] bf16.  ``qp`` = dict(a=[B*Lq, K] bf16 rows, w=[H*64, K] bf16 weight (or its tile_weight image with tiled=True),
+    row_ss=[B*Lq, tiles] fp32 / row_ss_dim / row_ss_eps optional, B=, Lq=, H=): the q projection inside the attention workgroups
+    (GaAttentionArgs.qp_*); ``q`` is then None."""
+    _need_cuda(k, vt)
+    if qp is None:
+        _need_cuda(q)
+        B, Lq, H, d = q.shape
+        assert d == 64 and q.stride(3) == 1 and q.stride(2) == 64
+        qs = q.stride(1) if Lq > 1 else q.stride(0)
+        assert q.stride(0) == Lq * qs
+    else:
+        B, Lq, H, qs = qp["B"], qp["Lq"], qp["H"], 0
+        assert qp["a"].dtype == torch.bfloat16 and qp["w"].dtype == torch.bfloat16 and qp["a"].stride(-1) == 1
     Lk = k.shape[1]
-    assert d == 64 and q.stride(3) == 1 and q.stride(2) == 64 and k.stride(2) == 64 and vt.stride(1) == 1
+    assert k.shape[3] == 64 and k.stride(2) == 64 and vt.stride(1) == 1
     # the C-ABI addresses row (b, i) at (b * L + i) * stride; a size-1 token axis has no meaningful stride of its own in torch
-    qs = q.stride(1) if Lq > 1 else q.stride(0)
     ks = k.stride(1) if Lk > 1 else k.stride(0)
-    assert q.stride(0) == Lq * qs and k.stride(0) == Lk * ks and vt.shape[0] == B * H * 64
-    out = torch.empty((B, Lq, H * 64), device=q.device, dtype=torch.bfloat16)
-    a = GaAttentionArgs(B, H, Lq, Lk, q.data_ptr(), k.data_ptr(), vt.data_ptr(), qs, ks, vt.stride(0),
+    assert k.stride(0) == Lk * ks and vt.shape[0] == B * H * 64
+    out = torch.empty((B, Lq, H * 64), device=k.device, dtype=torch.bfloat16)
+    a = GaAttentionArgs(B, H, Lq, Lk, q.data_ptr() if qp is None else None, k.data_ptr(), vt.data_ptr(), qs, ks, vt.stride(0),
                         _ptr(q_norm_weight), _ptr(k_norm_weight), out.data_ptr(), H * 64)
-    check(lib().ga_attention_bf16(ctypes.byref(a), _stream(q)), "ga_attention_bf16")
+    if qp is not None:
+        rs = qp.get("row_ss")
+        a.qp_a, a.qp_w, a.qp_lda, a.qp_k = qp["a"].data_ptr(), qp["w"].data_ptr(), qp["a"].stride(0), qp["a"].shape[1]
+        a.qp_w_tiled = 1 if qp.get("tiled") else 0
+        if rs is not None:
+            a.qp_row_ss, a.qp_row_ss_tiles, a.qp_row_ss_dim, a.qp_row_ss_eps = rs.data_ptr(), rs.shape[1], qp["row_ss_dim"], qp.get("row_ss_eps", 1e-5)
+    check(lib().ga_attention_bf16(ctypes.byref(a), _stream(k)), "ga_attention_bf16")
     return out
 
 

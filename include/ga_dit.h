@@ -121,6 +121,19 @@ typedef struct GaAttentionArgs {
     const float *q_norm_weight, *k_norm_weight; /* [64] each                                        */
     ga_bf16 *out;
     int64_t out_stride;
+    /* Optional (round 5): the q PROJECTION inside the attention workgroup -- q = A W^T per head, instead of a projection launch in
+     * front (the denoiser's cross-attention, /root/reference/ldm/modules/attention.py:497-522: to_q has no bias).  qp_a != NULL: `q`
+     * is not read; row (b, i) of A starts at qp_a + (b*Lq + i)*qp_lda, qp_k elements (qp_k % 64 == 0); qp_w = the [heads*64, qp_k]
+     * weight, row-major or the tiled image of GaGemmArgs.w_tiled; qp_row_ss (optional) = the rows' partial sums of squares of a folded
+     * RMSNorm as GaGemmArgs.row_ss reads them (row scale rsqrt(sum / qp_row_ss_dim + qp_row_ss_eps) applied to the product).  The
+     * per-head RMSNorm q_norm_weight is applied to the product, which is rounded to bf16 as the projection GEMM would have stored it.
+     * k_norm_weight must be NULL (the LDS-DMA path). */
+    const ga_bf16 *qp_a, *qp_w;
+    int64_t qp_lda;
+    int32_t qp_k, qp_w_tiled;
+    const float *qp_row_ss;
+    int32_t qp_row_ss_tiles, qp_row_ss_dim;
+    float qp_row_ss_eps;
 } GaAttentionArgs;
 
 int ga_attention_bf16(const GaAttentionArgs *args, void *stream);

@@ -178,6 +178,44 @@ def test_attention(gpu_device, B, H, Lq, Lk, norm):
     assert rel_l2(out.float(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,K,fold,tiled", [(1, 16, 768, 1369, 1024, True, True), (1, 12, 768, 1369, 768, False, True),
+                                                     (1, 3, 200, 137, 192, True, False), (2, 4, 100, 64, 256, False, False)])
+def test_attention_with_the_q_projection_inside_the_workgroup(gpu_device, B, H, Lq, Lk, K, fold, tiled):
+    """GaAttentionArgs.qp_* (round 5): q = A W^T per head computed by the attention workgroups themselves -- the denoiser's
+    cross-attention (/root/reference/ldm/modules/attention.py:497-522: to_q without bias, per-head q RMSNorm) without a projection
+    launch in front -- against the two-launch sequence it replaces (ga_gemm_bf16 with the head norm and, `fold`, the RMSNorm row scale
+    in its epilogue, then ga_attention_bf16 on its output) and against fp32; both weight layouts, ragged query / key counts, K = 192
+    (one K-slice per key group)."""
+    from gaussiananything_amd import dit_ops as ops
+    g = torch.Generator().manual_seed(77)
+    D = H * 64
+    A = torch.randn(B * Lq, K, generator=g).to(gpu_device).bfloat16()
+    W = (torch.randn(D, K, generator=g) / K ** 0.5).to(gpu_device).bfloat16()
+    wq = (1 + 0.3 * torch.randn(64, generator=g)).to(gpu_device)
+    k = torch.randn(B, Lk, H, 64, generator=g).to(gpu_device).bfloat16()
+    v = torch.randn(B, Lk, H, 64, generator=g).to(gpu_device).bfloat16()
+    vt = ops.transpose_v(v)
+    row_ss = None
+    if fold:   # partial sums of squares of a (fictitious) un-normalised row, 64 columns each, K / 64 rounded up to a multiple of 4 tiles
+        tiles = (K // 64 + 3) // 4 * 4
+        row_ss = (torch.rand(B * Lq, tiles, generator=g) * 64 * 3).to(gpu_device)
+        row_ss[:, K // 64:] = 0
+    q2 = ops.gemm(A, ops.tile_weight(W) if tiled else W, None, ops.EPI_STORE_BF16, qk_w0=wq, qk_cols0=D, qk_cols1=D, row_ss=row_ss,
+                  row_ss_dim=K, w_tiled=tiled, N=D)
+    want = ops.attention(q2.view(B, Lq, H, 64), k, vt)
+    got = ops.attention(None, k, vt, q_norm_weight=wq,
+                        qp=dict(a=A, w=ops.tile_weight(W) if tiled else W, tiled=tiled, row_ss=row_ss, row_ss_dim=K, B=B, Lq=Lq, H=H))
+    assert rel_l2(got.float(), want.float()) < 4e-3, rel_l2(got.float(), want.float())      # (other summation order of the projection)
+    qf = A.float() @ W.float().T
+    if fold:
+        qf = qf * torch.rsqrt(row_ss.sum(1, keepdim=True) / K + 1e-5)
+    qf = qf.view(B, Lq, H, 64)
+    qf = qf * torch.rsqrt(qf.pow(2).mean(-1, keepdim=True) + 1e-5) * wq
+    sc = torch.einsum("bqhd,bkhd->bhqk", qf, k.float()) / 8.0
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(sc, -1), v.float()).reshape(B, Lq, D)
+    assert rel_l2(got.float(), ref) < 1.2e-2, rel_l2(got.float(), ref)
+
+
 def test_attention_online_softmax_rescale_is_exercised(gpu_device):
     """One key in the LAST tile dominates one query: the running-max rescale path must fire and stay exact."""
     from gaussiananything_amd import dit_ops as ops
