@@ -458,7 +458,8 @@ static Ws carve(const GaDitModel *m, int B, int L, void *base)
     unsigned char *p = static_cast<unsigned char *>(base);
     Ws w;
     const size_t Lp = ((size_t)L + 63) / 64 * 64;
-    const size_t o_xres = take(M * D * 4), o_xn = take(M * D * 2), o_qkv = take(M * 2 * D * 2), o_att = take(M * D * 2);
+    const size_t qkv_cols = (m->hidden / m->heads == 64) ? 2 : 3;   // head dims other than 64: v row-major beside q | k (no V^T image)
+    const size_t o_xres = take(M * D * 4), o_xn = take(M * D * 2), o_qkv = take(M * qkv_cols * D * 2), o_att = take(M * D * 2);
     const size_t o_vt = take((size_t)B * D * Lp * 2);
     const size_t o_hmid = take(M * 4 * D * 2), o_tfreq = take((size_t)B * 256 * 4), o_t1 = take((size_t)B * D * 4);
     const size_t o_pln = take((size_t)B * m->context_dim * 4), o_pvec = take((size_t)B * D * 4);
@@ -481,13 +482,13 @@ static Ws carve(const GaDitModel *m, int B, int L, void *base)
 // block i's cross-attention pre-norm can be folded into fc2 of block i-1 and its own q projection (include/ga_dit.h)
 static bool can_fold(const GaDitModel *m, int i)
 {
-    return m->blocks[i].ca_q_w_prenorm != nullptr && m->hidden % 256 == 0 && m->hidden <= 1024;
+    return m->blocks[i].ca_q_w_prenorm != nullptr && m->hidden % 256 == 0 && m->hidden <= 1024 && m->hidden / m->heads == 64;
 }
 
 static bool model_ok(const GaDitModel *m)
 {
     return m && m->blocks && m->hidden > 0 && m->hidden % 64 == 0 && m->hidden <= 2048 && m->depth > 0 && m->depth <= 64 &&
-           m->heads * 64 == m->hidden && m->in_channels > 0 && m->in_channels <= 16 && m->out_channels > 0 &&
+           m->heads > 0 && m->hidden % m->heads == 0 && (m->hidden / m->heads) % 8 == 0 && m->hidden / m->heads <= 128 && m->in_channels > 0 && m->in_channels <= 16 && m->out_channels > 0 &&
            m->out_channels <= 16 && m->context_dim > 0 && m->context_dim % 64 == 0;
 }
 
@@ -519,6 +520,16 @@ extern "C" int ga_dit_cache_context(const GaDitModel *m, int32_t batch, int32_t 
     if (batch <= 0 || ctx_tokens <= 0) return GA_DIT_ERR_BAD_SHAPE;
     const int rows = batch * ctx_tokens, D = m->hidden;
     const int64_t Mp = ((int64_t)ctx_tokens + 63) / 64 * 64;
+    if (D / m->heads != 64) {   // head dims other than 64 (ga_attention_hd_bf16): ca_k holds K | V row-major, [depth][rows, 2 D]; ca_vt is not used
+        for (int i = 0; i < m->depth; ++i) {
+            GaGemmArgs g{};
+            g.M = rows; g.N = 2 * D; g.K = m->context_dim; g.epilogue = GA_GEMM_EPI_STORE_BF16; g.A = ctx; g.lda = m->context_dim;
+            g.W = m->blocks[i].ca_kv_w; g.w_tiled = m->gemm_weights_tiled; g.out = ca_k + (size_t)i * rows * 2 * D; g.ldo = 2 * D;
+            GA_TRY(ga_gemm_bf16(&g, stream));
+            GA_TRY(ga_head_rmsnorm_bf16(ca_k + (size_t)i * rows * 2 * D, rows, 2 * D, m->heads, D / m->heads, m->blocks[i].ca_k_norm_w, stream));
+        }
+        return GA_DIT_OK;
+    }
     for (int i = 0; i < m->depth; ++i) {
         GaGemmArgs g{};
         g.M = rows; g.N = 2 * D; g.K = m->context_dim; g.epilogue = GA_GEMM_EPI_STORE_BF16;
@@ -548,7 +559,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     if (!model_ok(m) || !a) return GA_DIT_ERR_NULL_ARG;
     if (!a->x || !a->timesteps || !a->img_vector || !a->ca_k || !a->ca_vt || (!a->out && !a->step) || !a->workspace) return GA_DIT_ERR_NULL_ARG;
     if (m->stage2 && !a->fps_xyz) return GA_DIT_ERR_NULL_ARG;
-    const int B = a->batch, L = a->tokens, D = m->hidden, Mrows = B * L;
+    const int B = a->batch, L = a->tokens, D = m->hidden, Mrows = B * L, hd = D / m->heads;
     if (B <= 0 || B > 16 || L <= 0 || a->ctx_tokens <= 0) return GA_DIT_ERR_BAD_SHAPE;
     // a sampler step writes states / velocities of in_channels floats per token: a model that also predicts sigma (out_channels !=
     // in_channels) has no such step -- refused before anything is enqueued (the reference trips body_fn's shape assert there)
@@ -633,6 +644,50 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         // into the neighbouring GEMMs: the previous block's fc2 epilogue left bf16(x) in xn and the rows' sums of squares in
         // rowss (below); the q projection, with the norm weight folded into its columns, applies rsqrt(mean + eps) to its rows.
         const bool folded = i > 0 && can_fold(m, i);
+        if (hd != 64) {
+            // HEAD DIMS OTHER THAN 64 (DiT-PixArt-PCD-CLAY-XL: 16 heads of 72): the same block with nothing folded -- plain projections, the
+            // per-head q / k norms as a pass of their own, ga_attention_hd_bf16 on row-major q | k | v (correctness-first, dit_attention_hd.hip)
+            GaRmsNormArgs n0{Mca, D, L, w.xres, bw.prenorm_ca_w, nullptr, nullptr, 0, w.xn, nullptr, 0};
+            GA_TRY(ga_rmsnorm_modulate(&n0, stream));
+            GaGemmArgs gq{};
+            gq.M = Mca; gq.N = D; gq.K = D; gq.epilogue = GA_GEMM_EPI_STORE_BF16; gq.A = w.xn; gq.lda = D; gq.W = bw.ca_q_w;
+            gq.w_tiled = m->gemm_weights_tiled; gq.out = w.qkv; gq.ldo = D;
+            GA_TRY(ga_gemm_bf16(&gq, stream));
+            GA_TRY(ga_head_rmsnorm_bf16(w.qkv, Mca, D, m->heads, hd, bw.ca_q_norm_w, stream));
+            const ga_bf16 *ckv = a->ca_k + (size_t)i * kv_rows * 2 * D;
+            GaAttentionHdArgs ca{ca_batch, m->heads, L, a->ctx_tokens, hd, w.qkv, ckv, ckv + D, D, 2 * D, 2 * D, w.att, D};
+            GA_TRY(ga_attention_hd_bf16(&ca, stream));
+            GaGemmArgs go{};
+            go.M = Mca; go.N = D; go.K = D; go.epilogue = GA_GEMM_EPI_RESIDUAL; go.A = w.att; go.lda = D; go.W = bw.ca_out_w; go.w_tiled = m->gemm_weights_tiled;
+            go.bias = bw.ca_out_b; go.out = w.xres; go.ldo = D; go.gate = nullptr; go.rows_per_batch = L;
+            GA_TRY(ga_gemm_bf16(&go, stream));
+            GaRmsNormArgs n1{Mrows, D, L, w.xres, bw.norm1_w, mod + 1 * D, mod + 0 * D, 6 * (int64_t)D, w.xn, Mca < Mrows ? bw.ca_out_b : nullptr, Mca};
+            GA_TRY(ga_rmsnorm_modulate(&n1, stream));
+            GaGemmArgs gqkv{};
+            gqkv.M = Mrows; gqkv.N = 3 * D; gqkv.K = D; gqkv.epilogue = GA_GEMM_EPI_STORE_BF16; gqkv.A = w.xn; gqkv.lda = D; gqkv.W = bw.qkv_w;
+            gqkv.w_tiled = m->gemm_weights_tiled; gqkv.bias = bw.qkv_b; gqkv.out = w.qkv; gqkv.ldo = 3 * D;
+            GA_TRY(ga_gemm_bf16(&gqkv, stream));
+            GA_TRY(ga_head_rmsnorm_bf16(w.qkv, Mrows, 3 * D, m->heads, hd, bw.q_norm_w, stream));
+            GA_TRY(ga_head_rmsnorm_bf16(w.qkv + D, Mrows, 3 * D, m->heads, hd, bw.k_norm_w, stream));
+            GaAttentionHdArgs sa{B, m->heads, L, L, hd, w.qkv, w.qkv + D, w.qkv + 2 * D, 3 * D, 3 * D, 3 * D, w.att, D};
+            GA_TRY(ga_attention_hd_bf16(&sa, stream));
+            GaGemmArgs gp{};
+            gp.M = Mrows; gp.N = D; gp.K = D; gp.epilogue = GA_GEMM_EPI_RESIDUAL; gp.A = w.att; gp.lda = D; gp.W = bw.proj_w; gp.w_tiled = m->gemm_weights_tiled;
+            gp.bias = bw.proj_b; gp.out = w.xres; gp.ldo = D; gp.gate = mod + 2 * D; gp.gate_stride = 6 * (int64_t)D; gp.rows_per_batch = L;
+            GA_TRY(ga_gemm_bf16(&gp, stream));
+            GaRmsNormArgs n2{Mrows, D, L, w.xres, bw.norm2_w, mod + 4 * D, mod + 3 * D, 6 * (int64_t)D, w.xn, nullptr, 0};
+            GA_TRY(ga_rmsnorm_modulate(&n2, stream));
+            GaGemmArgs g1{};
+            g1.M = Mrows; g1.N = 4 * D; g1.K = D; g1.epilogue = GA_GEMM_EPI_GELU_BF16; g1.A = w.xn; g1.lda = D; g1.W = bw.fc1_w; g1.w_tiled = m->gemm_weights_tiled;
+            g1.bias = bw.fc1_b; g1.out = w.hmid; g1.ldo = 4 * D;
+            GA_TRY(ga_gemm_bf16(&g1, stream));
+            GaGemmArgs g2{};
+            g2.M = Mrows; g2.N = D; g2.K = 4 * D; g2.epilogue = GA_GEMM_EPI_RESIDUAL; g2.A = w.hmid; g2.lda = 4 * D; g2.W = bw.fc2_w;
+            g2.w_tiled = m->gemm_weights_tiled; g2.bias = bw.fc2_b; g2.out = w.xres; g2.ldo = D; g2.gate = mod + 5 * D; g2.gate_stride = 6 * (int64_t)D;
+            g2.rows_per_batch = L;
+            GA_TRY(ga_gemm_bf16(&g2, stream));
+            continue;
+        }
         if (!folded) {
             GaRmsNormArgs n0{Mca, D, L, w.xres, bw.prenorm_ca_w, nullptr, nullptr, 0, w.xn, nullptr, 0};
             GA_UNLESS(4, ga_rmsnorm_modulate(&n0, stream));

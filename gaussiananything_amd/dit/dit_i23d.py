@@ -120,8 +120,9 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         super().__init__()
         if enable_rope or has_caption:
             raise NotImplementedError("RoPE / caption conditioning are not used by the released i23d models")
-        if hidden_size % num_heads or hidden_size // num_heads != 64:
-            raise ValueError("the MI355X attention kernel is built for head_dim 64 (all CLAY configurations)")
+        if hidden_size % num_heads or (hidden_size // num_heads) % 8 or hidden_size // num_heads > 128 or hidden_size % 64:
+            raise ValueError("head_dim must be a multiple of 8 up to 128 and the width a multiple of 64 (64: the tuned kernels of the released "
+                             "models; anything else, e.g. the 16 x 72 of DiT-PixArt-PCD-CLAY-XL, takes ga_attention_hd_bf16)")
         assert patch_size == 1, "point-cloud latents are not patchified (patch_size=1 in every CLAY registry entry)"
         self.in_channels = in_channels
         self.out_channels = in_channels * 2 if learn_sigma else in_channels
@@ -268,12 +269,14 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         ctx = ctx_tokens.detach().to(torch.bfloat16).contiguous()
         Mp = (M + 63) // 64 * 64
         old = self._ctx_cache[1] if self._ctx_cache is not None else None
-        if old is not None and old[0].shape == (self.depth, B * M, self.embed_dim) and old[0].device == ctx.device:
+        hd64 = self.embed_dim // self.num_heads == 64
+        kcols = self.embed_dim if hd64 else 2 * self.embed_dim      # head dims other than 64: K | V row-major, no V^T image (ga_dit.h)
+        if old is not None and old[0].shape == (self.depth, B * M, kcols) and old[0].device == ctx.device:
             ck, cvt = old[0], old[1]   # same shapes: projected in place (the pad columns of cvt stay zero), so a captured sampler step
                                        # that has these addresses baked in serves the next sample's conditioning as well
         else:
-            ck = torch.empty((self.depth, B * M, self.embed_dim), dtype=torch.bfloat16, device=ctx.device)
-            cvt = torch.zeros((self.depth, B * self.embed_dim, Mp), dtype=torch.bfloat16, device=ctx.device)
+            ck = torch.empty((self.depth, B * M, kcols), dtype=torch.bfloat16, device=ctx.device)
+            cvt = torch.zeros((self.depth, B * self.embed_dim, Mp) if hd64 else (8,), dtype=torch.bfloat16, device=ctx.device)
         stream = ctypes.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream)
         ops.check(ops.lib().ga_dit_cache_context(ctypes.byref(pack["model"]), B, M, ctx.data_ptr(), ck.data_ptr(),
                                                  cvt.data_ptr(), stream), "ga_dit_cache_context")
@@ -596,10 +599,9 @@ def _clay(depth, hidden, heads, stage2=False):
 
 # the CLAY entries of the reference registry (dit_i23d.py:1665-1697)
 DiT_models = {
-    "DiT-PixArt-PCD-CLAY-XL": _clay(28, 1152, 18),  # NOTE: the reference uses 16 heads of 72 here; not supported (d != 64)
+    "DiT-PixArt-PCD-CLAY-XL": _clay(28, 1152, 16),  # 16 heads of 72 (dit_i23d.py:1526-1535): ga_attention_hd_bf16, nothing folded
     "DiT-PixArt-PCD-CLAY-L": _clay(24, 1024, 16),
     "DiT-PixArt-PCD-CLAY-B": _clay(12, 768, 12),
     "DiT-PixArt-PCD-CLAY-stage2-B": _clay(12, 768, 12, stage2=True),
     "DiT-PixArt-PCD-CLAY-stage2-L": _clay(24, 1024, 16, stage2=True),
 }
-del DiT_models["DiT-PixArt-PCD-CLAY-XL"]  # head_dim 72: outside the built kernel set (the release uses L)

@@ -30,6 +30,11 @@ class GaAttentionArgs(ctypes.Structure):
                 ("qp_row_ss", c_p), ("qp_row_ss_tiles", i32), ("qp_row_ss_dim", i32), ("qp_row_ss_eps", ctypes.c_float)]
 
 
+class GaAttentionHdArgs(ctypes.Structure):
+    _fields_ = [("batch", i32), ("heads", i32), ("Lq", i32), ("Lk", i32), ("head_dim", i32), ("q", c_p), ("k", c_p), ("v", c_p),
+                ("q_stride", i64), ("k_stride", i64), ("v_stride", i64), ("out", c_p), ("out_stride", i64)]
+
+
 class GaRmsNormArgs(ctypes.Structure):
     _fields_ = [("M", i32), ("D", i32), ("rows_per_batch", i32), ("x", c_p), ("weight", c_p), ("scale", c_p),
                 ("shift", c_p), ("mod_stride", i64), ("out", c_p), ("row_bias", c_p), ("row_bias_first", i32)]
@@ -82,7 +87,7 @@ class GaDitForwardArgs(ctypes.Structure):
                 ("pooled_vec", c_p)]
 
 
-DIT_EXPORTS = ("ga_gemm_bf16", "ga_attention_bf16", "ga_rmsnorm_modulate", "ga_small_linear", "ga_dit_workspace_bytes",
+DIT_EXPORTS = ("ga_gemm_bf16", "ga_attention_bf16", "ga_attention_hd_bf16", "ga_head_rmsnorm_bf16", "ga_rmsnorm_modulate", "ga_small_linear", "ga_dit_workspace_bytes",
                "ga_dit_cache_context", "ga_dit_forward", "ga_dit_pooled_vector", "ga_dit_shift_bias", "ga_dit_sampler_advance", "ga_ode_dopri5_stage", "ga_ode_dopri5_finish",
                "ga_dit_version")
 _ERR = {-1: "GA_DIT_ERR_NULL_ARG", -2: "GA_DIT_ERR_BAD_SHAPE", -4: "GA_DIT_ERR_LAUNCH"}
@@ -105,6 +110,8 @@ def lib():
         L.ga_dit_cache_context.argtypes = [ctypes.POINTER(GaDitModel), i32, i32, c_p, c_p, c_p, c_p]
         L.ga_dit_forward.restype = ctypes.c_int
         L.ga_dit_forward.argtypes = [ctypes.POINTER(GaDitModel), ctypes.POINTER(GaDitForwardArgs), c_p]
+        L.ga_head_rmsnorm_bf16.restype = ctypes.c_int
+        L.ga_head_rmsnorm_bf16.argtypes = [c_p, i64, i64, i32, i32, c_p, c_p]
         L.ga_dit_pooled_vector.restype = ctypes.c_int
         L.ga_dit_pooled_vector.argtypes = [ctypes.POINTER(GaDitModel), i32, c_p, c_p, c_p, c_p]
         L.ga_dit_sampler_advance.restype = ctypes.c_int
@@ -213,6 +220,28 @@ def attention(q, k, vt, q_norm_weight=None, k_norm_weight=None, qp=None):
             a.qp_row_ss, a.qp_row_ss_tiles, a.qp_row_ss_dim, a.qp_row_ss_eps = rs.data_ptr(), rs.shape[1], qp["row_ss_dim"], qp.get("row_ss_eps", 1e-5)
     check(lib().ga_attention_bf16(ctypes.byref(a), _stream(k)), "ga_attention_bf16")
     return out
+
+
+def attention_hd(q, k, v):
+    """Head dims other than 64: q [B,Lq,H,d], k / v [B,Lk,H,d] bf16 views (token stride arbitrary, head stride d), already head-normalised
+    -> [B,Lq,H*d] bf16."""
+    _need_cuda(q, k, v)
+    B, Lq, H, d = q.shape
+    Lk = k.shape[1]
+    for t in (q, k, v):
+        assert t.dtype == torch.bfloat16 and t.stride(3) == 1 and t.stride(2) == d and t.stride(0) == t.shape[1] * t.stride(1)
+    out = torch.empty((B, Lq, H * d), device=q.device, dtype=torch.bfloat16)
+    a = GaAttentionHdArgs(B, H, Lq, Lk, d, q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(1), k.stride(1), v.stride(1), out.data_ptr(), H * d)
+    check(lib().ga_attention_hd_bf16(ctypes.byref(a), _stream(q)), "ga_attention_hd_bf16")
+    return out
+
+
+def head_rmsnorm_(x, heads, head_dim, weight):
+    """in place on the first heads*head_dim columns of every row of x [rows, stride] bf16"""
+    _need_cuda(x, weight)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    check(lib().ga_head_rmsnorm_bf16(x.data_ptr(), x.shape[0], x.stride(0), heads, head_dim, weight.data_ptr(), _stream(x)), "ga_head_rmsnorm_bf16")
+    return x
 
 
 def rmsnorm_modulate(x, weight, scale=None, shift=None, rows_per_batch=1):

@@ -63,3 +63,23 @@ def split_gaussians(gaussians_b: torch.Tensor):
     return (gaussians_b[:, 0:3].contiguous().float(), gaussians_b[:, 3:4].contiguous().float(),
             gaussians_b[:, 4:6].contiguous().float(), gaussians_b[:, 6:10].contiguous().float(),
             gaussians_b[:, 10:13].contiguous().float())
+
+
+def recipe_state_dict(keys_shapes, seed: int):
+    """Seeded weights for a state dict given as [(key, shape), ...] -- what a fixture stores INSTEAD of megabytes of weights when the
+    reference outputs were computed on exactly these values (tests/golden/make_dit_golden.py: make_hd72).  CPU generator, one stream
+    per tensor: matrices N(0, 1 / fan_in), norm weights 1 + 0.1 N(0, 1), tables 0.1 N(0, 1), biases 0.02 N(0, 1)."""
+    out = {}
+    for i, (key, shape) in enumerate(keys_shapes):
+        g = torch.Generator().manual_seed(int(seed) * 100003 + i)
+        t = torch.randn(tuple(shape), generator=g)
+        if len(shape) >= 2 and "table" not in key:
+            t = t / float(shape[-1]) ** 0.5
+        elif "norm" in key and key.endswith("weight") or key.endswith(".0.weight") and len(shape) == 1:
+            t = 1.0 + 0.1 * t
+        elif "table" in key:
+            t = 0.1 * t
+        else:
+            t = 0.02 * t
+        out[key] = t
+    return out

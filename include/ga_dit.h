@@ -138,6 +138,25 @@ typedef struct GaAttentionArgs {
 
 int ga_attention_bf16(const GaAttentionArgs *args, void *stream);
 
+/* The same attention for head dims OTHER than 64 (head_dim % 8 == 0, <= 128): DiT-PixArt-PCD-CLAY-XL of the reference registry has 16
+ * heads of 72 (/root/reference/dit/dit_i23d.py:1526-1535, 1677).  q, k, v row-major: row (b, i) of q starts at q + (b*Lq + i)*q_stride +
+ * h*head_dim (k, v: b*Lk + j); q and k ALREADY carry their per-head RMSNorm (ga_head_rmsnorm_bf16); softmax scale head_dim^-1/2.
+ * 16-byte aligned operands, strides % 8 == 0; out 8-byte aligned, out_stride % 4 == 0.  A correctness-first kernel (the 64-wide one
+ * is the tuned path of the released models). */
+typedef struct GaAttentionHdArgs {
+    int32_t batch, heads, Lq, Lk, head_dim;
+    const ga_bf16 *q, *k, *v;
+    int64_t q_stride, k_stride, v_stride;   /* elements */
+    ga_bf16 *out;
+    int64_t out_stride;
+} GaAttentionHdArgs;
+
+int ga_attention_hd_bf16(const GaAttentionHdArgs *args, void *stream);
+
+/* In place: x[r][h][:] *= rsqrt(mean(x[r][h][:]^2) + 1e-5) * weight[:] for r < rows, h < heads (bf16 storage, fp32 arithmetic; row r starts
+ * at x + r*row_stride): the per-head q / k RMSNorm of dit/norm.py:29-43 for head dims the projection GEMM's epilogue does not cover. */
+int ga_head_rmsnorm_bf16(ga_bf16 *x, int64_t rows, int64_t row_stride, int32_t heads, int32_t head_dim, const float *weight, void *stream);
+
 /* out_bf16[m][:] = rmsnorm(x[m][:]; eps 1e-5) * weight * (1 + scale[b][:]) + shift[b][:],  b = m / rows_per_batch
  * (scale / shift NULL = plain RMSNorm).  dit/norm.py:29-43 + t2i_modulate.  D % 4 == 0, D <= 2048. */
 typedef struct GaRmsNormArgs {

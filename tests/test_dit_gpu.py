@@ -216,6 +216,58 @@ def test_attention_with_the_q_projection_inside_the_workgroup(gpu_device, B, H, 
     assert rel_l2(got.float(), ref) < 1.2e-2, rel_l2(got.float(), ref)
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,d", [(2, 16, 768, 768, 72), (1, 16, 768, 1369, 72), (2, 3, 100, 137, 40), (1, 2, 50, 64, 128), (1, 4, 33, 200, 8)])
+def test_attention_for_head_dims_other_than_64(gpu_device, B, H, Lq, Lk, d):
+    """ga_attention_hd_bf16 / ga_head_rmsnorm_bf16 (dit_attention_hd.hip): what DiT-PixArt-PCD-CLAY-XL's 16 heads of 72
+    (/root/reference/dit/dit_i23d.py:1526-1535) need -- per-head RMSNorm of q and k, softmax(q k^T / sqrt(d)) v -- against fp32, at the XL
+    shapes (self- and cross-attention), ragged sizes, and the smallest / largest head dims the kernel takes."""
+    from gaussiananything_amd import dit_ops as ops
+    g = torch.Generator().manual_seed(d)
+    qkv = torch.randn(B * Lq, 3 * H * d, generator=g).to(gpu_device).bfloat16()
+    kv = torch.randn(B * Lk, 2 * H * d, generator=g).to(gpu_device).bfloat16()
+    wq = (1 + 0.3 * torch.randn(d, generator=g)).to(gpu_device)
+    wk = (1 + 0.3 * torch.randn(d, generator=g)).to(gpu_device)
+    nrm = lambda t, w: t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-5) * w  # noqa: E731
+    q_ref = nrm(qkv[:, :H * d].float().view(B, Lq, H, d), wq)
+    k_ref = nrm(kv[:, :H * d].float().view(B, Lk, H, d), wk)
+    v_ref = kv[:, H * d:].float().view(B, Lk, H, d)
+    ops.head_rmsnorm_(qkv, H, d, wq)
+    ops.head_rmsnorm_(kv, H, d, wk)
+    assert rel_l2(qkv[:, :H * d].float().view(B, Lq, H, d), q_ref) < 6e-3 and rel_l2(kv[:, :H * d].float().view(B, Lk, H, d), k_ref) < 6e-3
+    assert torch.equal(kv[:, H * d:].float().view(B, Lk, H, d), v_ref)                      # (only the named columns are touched)
+    out = ops.attention_hd(qkv.view(B, Lq, 3 * H * d)[..., :H * d].unflatten(-1, (H, d)), kv.view(B, Lk, 2 * H * d)[..., :H * d].unflatten(-1, (H, d)),
+                           kv.view(B, Lk, 2 * H * d)[..., H * d:].unflatten(-1, (H, d)))
+    sc = torch.einsum("bqhd,bkhd->bhqk", q_ref, k_ref) / d ** 0.5
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(sc, -1), v_ref).reshape(B, Lq, H * d)
+    assert rel_l2(out.float(), ref) < 1.2e-2, rel_l2(out.float(), ref)
+
+
+def test_model_with_heads_of_72_matches_the_reference_golden(gpu_device):
+    """DiT-PixArt-PCD-CLAY-XL's head geometry (8 heads of 72 at width 576, depth 2) against outputs of the REFERENCE'S OWN classes
+    (tests/golden/dit_ref_hd72.pt, make_dit_golden.py: the weights are synthetic.recipe_state_dict, regenerated here): forward and
+    forward_with_cfg, the zero-context skip, and the fused Euler sampler on top of it."""
+    from gaussiananything_amd import synthetic
+    from gaussiananything_amd.dit import DiT_I23D_PCD_PixelArt_noclip
+    from gaussiananything_amd.transport import Sampler, create_transport
+    z = torch.load(synthetic.fixture_path("dit_ref_hd72.pt"))
+    model = DiT_I23D_PCD_PixelArt_noclip(**z["kwargs"])
+    model.load_state_dict(synthetic.recipe_state_dict(z["keys"], z["recipe_seed"]), strict=True)
+    model.to(gpu_device)
+    assert model.embed_dim // model.num_heads == 72
+    ctx = {k: v.to(gpu_device) for k, v in z["context"].items()}
+    x, t = z["x"].to(gpu_device), z["t"].to(gpu_device)
+    with torch.no_grad():
+        y = model(x, t, ctx)
+        ycfg = model.forward_with_cfg(x, t, ctx, z["cfg_scale"])
+    assert rel_l2(y, z["y"].to(gpu_device)) < 1.5e-2, rel_l2(y, z["y"].to(gpu_device))
+    assert rel_l2(ycfg, z["y_cfg"].to(gpu_device)) < 3e-2
+    assert model._ctx_cache[1][2] == 2                      # the zero-context half skipped its cross-attention
+    fn = Sampler(create_transport("GVP", "velocity", None, None, None, snr_type="uniform")).sample_ode(sampling_method="euler", num_steps=6)
+    with torch.no_grad():
+        traj = fn(x, model.forward_with_cfg, context=ctx, cfg_scale=z["cfg_scale"])
+    assert traj.shape == (6,) + tuple(x.shape) and bool(torch.isfinite(traj).all())
+
+
 def test_attention_online_softmax_rescale_is_exercised(gpu_device):
     """One key in the LAST tile dominates one query: the running-max rescale path must fire and stay exact."""
     from gaussiananything_amd import dit_ops as ops
