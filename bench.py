@@ -179,7 +179,7 @@ def bench_attention(dev, reps=50):
         fl = 4.0 * B * H * Lq * Lk * 64
         out[name] = {"us": round(us, 2), "tflops": round(fl / (us * 1e-6) / 1e12, 1),
                      "frac_of_bf16_mfma_peak": round(fl / (us * 1e-6) / 1e12 / 2500.0, 4)}
-    pj = committed_pmc("r4_attention_pmc.json")
+    pj = committed_pmc("r5_attention_pmc.json")
     out["mfma_busy_from_counters"] = ({"kernels": pj["kernels"], "source": pj["source"] + " (committed rocprofv3 PMC pass of exactly these two "
                                         "launches: SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs; dit_attention.hip unchanged "
                                         "since), not measured in this run"} if pj else None)
@@ -828,7 +828,7 @@ def main():
             blend_bytes = 76.0 * int(st[0]) + 40.0 * P * v      # per launch (all V views), SURVEY.md 8d
             achieved = blend_bytes / (stage["blend"] * 1e-3) / 1e9
             traffic, tsrc, valu_frac, valu_insts = None, None, None, None  # PMC counters cannot be collected live: committed rocprofv3 passes
-            pj = committed_pmc("r4_blend_pmc.json") if (a.scene == "surface" and n == 100_000 and v == 8 and H == 512) else None
+            pj = committed_pmc("r5_blend_pmc.json") if (a.scene == "surface" and n == 100_000 and v == 8 and H == 512) else None
             if pj:
                 traffic, valu_frac, valu_insts = pj["traffic_bytes_per_launch"], pj["valu_issue_frac"], pj["SQ_INSTS_VALU"]
                 tsrc = f"committed PMC ({pj['source']}; surfel_blend.hip unchanged since), not measured in this run"

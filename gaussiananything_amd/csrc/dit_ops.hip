@@ -72,7 +72,15 @@ __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v));
 
 // One wave per output feature n; a lane owns 8 consecutive k of every 512-wide chunk (one 16-byte weight load, two float4
 // loads per batch row), so K = 1024 is two independent round trips instead of 16 dependent scalar ones.  K % 8 == 0.
-__global__ __launch_bounds__(256) void small_linear_kernel(GaSmallLinearArgs a)
+// optional second output of small_linear_kernel: mod[blk][b][n] = tables[blk][n] + y[b][n] for every block (round 5: the adaLN linear of
+// the evaluation's head writes the blocks' modulation tables itself; a launch of its own before)
+struct ModOut {
+    const float *tables[64];
+    float *mod;
+    int depth;
+};
+
+__global__ __launch_bounds__(256) void small_linear_kernel(GaSmallLinearArgs a, ModOut mo)
 {
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (n >= a.N) return;
@@ -92,18 +100,23 @@ __global__ __launch_bounds__(256) void small_linear_kernel(GaSmallLinearArgs a)
                 const int j = k + e, f = j < 128 ? j : j - 128;
                 fr[e] = expf(-9.210340371976184f * (float)f / 128.0f);
             }
-#pragma unroll
-            for (int b = 0; b < 16; ++b)
-                if (b < a.B) {
+            float accb = 0.f;
+#pragma unroll 1
+            for (int b = 0; b < a.B; ++b) {   // (not unrolled: 16 x 8 inlined libm sin / cos were 80 KB of code)
                     const float tb = a.x[b];
-#pragma unroll
+                    accb = 0.f;
+#pragma unroll 1
                     for (int e = 0; e < 8; ++e) {
                         const float arg = tb * fr[e];
                         const float xv = (k + e) < 128 ? cosf(arg) : sinf(arg);
-                        const float wv = (e & 1) ? __uint_as_float(ww[e >> 1] & 0xffff0000u) : __uint_as_float(ww[e >> 1] << 16);
-                        acc[b] += bf16_to_f32(f32_to_bf16(xv)) * wv;
+                        const uint32_t we = e < 2 ? ww[0] : (e < 4 ? ww[1] : (e < 6 ? ww[2] : ww[3]));
+                        const float wv = (e & 1) ? __uint_as_float(we & 0xffff0000u) : __uint_as_float(we << 16);
+                        accb += bf16_to_f32(f32_to_bf16(xv)) * wv;
                     }
-                }
+                    // acc[] is a register array: select the slot without dynamic indexing
+#pragma unroll
+                    for (int bb = 0; bb < 16; ++bb) acc[bb] = bb == b ? accb : acc[bb];
+            }
         }
     } else
 #pragma unroll 2
@@ -133,13 +146,13 @@ __global__ __launch_bounds__(256) void small_linear_kernel(GaSmallLinearArgs a)
 #pragma unroll
     for (int b = 0; b < 16; ++b)
         if (b < a.B) {
-            float v = wave_sum(acc[b]);
-            if (lane == 0) {
-                if (a.bias) v += a.bias[n];
-                if (a.act_out == 1) v = silu(v);
-                if (a.add) v += a.add[(size_t)b * a.N + n];
-                a.y[(size_t)b * a.N + n] = v;
-            }
+            float v = wave_sum(acc[b]);      // (the butterfly leaves the total in every lane)
+            if (a.bias) v += a.bias[n];
+            if (a.act_out == 1) v = silu(v);
+            if (a.add) v += a.add[(size_t)b * a.N + n];
+            if (lane == 0) a.y[(size_t)b * a.N + n] = v;
+            // the blocks' modulation tables: lane l serves block l (one load, one store each -- a loop in one lane was 24 dependent round trips)
+            for (int blk = lane; blk < mo.depth; blk += 64) mo.mod[((size_t)blk * a.B + b) * a.N + n] = mo.tables[blk][n] + v;
         }
 }
 
@@ -309,19 +322,21 @@ __device__ __forceinline__ void final_layer_row(const FinalArgs &a, int row, int
             sc[c] = make_float4(s4.x + t4.x, s4.y + t4.y, s4.z + t4.z, s4.w + t4.w);
         }
     }
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-        if (c * 256 + lane * 4 < D) s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
-    const float mean = wave_sum(s) / (float)D;
-    float q = 0.f;
+    // LayerNorm statistics in ONE pass (round 5: sum and sum of squares reduced together -- two dependent wave reductions before)
+    float s = 0.f, q = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c)
         if (c * 256 + lane * 4 < D) {
-            v[c].x -= mean; v[c].y -= mean; v[c].z -= mean; v[c].w -= mean;
-            q += v[c].x * v[c].x + v[c].y * v[c].y + v[c].z * v[c].z + v[c].w * v[c].w;
+            s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+            q += (v[c].x * v[c].x + v[c].y * v[c].y) + (v[c].z * v[c].z + v[c].w * v[c].w);
         }
-    const float rs = rsqrtf(wave_sum(q) / (float)D + 1e-6f);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    const float mean = s / (float)D;
+    const float rs = rsqrtf(fmaxf(q / (float)D - mean * mean, 0.f) + 1e-6f);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (c * 256 + lane * 4 < D) { v[c].x -= mean; v[c].y -= mean; v[c].z -= mean; v[c].w -= mean; }
     float acc[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) acc[c] = 0.f;
@@ -362,29 +377,42 @@ __global__ __launch_bounds__(256) void final_layer_kernel(FinalArgs a)
         }
         return;
     }
-    // fused sampler step: this wave owns row `row` of the conditional half and, with CFG, its unconditional twin
+    // fused sampler step.  Without CFG a wave owns one row; with CFG a workgroup owns two rows of the conditional half: waves 0, 1
+    // evaluate them, waves 2, 3 their unconditional twins (round 5: one wave did both rows one after the other), combined through LDS
     const int half = a.cfg ? a.M / 2 : a.M;
-    if (row >= half) return;
+    __shared__ float twin[2][16];
     float v[16];
-    final_layer_row(a, row, lane, v);
     if (a.cfg) {
-        float u[16];
-        final_layer_row(a, row + half, lane, u);
+        const int w = threadIdx.x >> 6, pair = w & 1, role = w >> 1, r2 = blockIdx.x * 2 + pair;
+        const bool have = r2 < half;
+        if (have) final_layer_row(a, r2 + role * half, lane, v);
+        if (role == 1 && have && lane < 16) {
+            float mine = 0.f;
 #pragma unroll
-        for (int o = 0; o < 16; ++o) v[o] = cfg_combine(v[o], u[o], a.cfg_scale);
+            for (int o = 0; o < 16; ++o) mine = lane == o ? v[o] : mine;
+            twin[pair][lane] = mine;
+        }
+        __syncthreads();
+        if (role == 1 || !have) return;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) v[o] = cfg_combine(v[o], twin[pair][o], a.cfg_scale);
+    } else {
+        if (row >= half) return;
+        final_layer_row(a, row, lane, v);
     }
+    const int rowc = a.cfg ? blockIdx.x * 2 + ((threadIdx.x >> 6) & 1) : row;   // my row of the (conditional) half
     if (lane < a.Cout) {
         float mine = 0.f;
 #pragma unroll
         for (int o = 0; o < 16; ++o) mine = lane == o ? v[o] : mine;
         if (a.dt == nullptr) {    // GaDitSamplerStep.velocity: the velocity itself, both halves
-            for (int h = 0; h < (a.cfg ? 2 : 1); ++h) a.state[(size_t)(row + h * half) * a.Cout + lane] = mine;
+            for (int h = 0; h < (a.cfg ? 2 : 1); ++h) a.state[(size_t)(rowc + h * half) * a.Cout + lane] = mine;
             return;
         }
         const float dtv = *a.dt;
         float *slice = a.traj ? a.traj + (size_t)(*a.counter + 1) * a.traj_stride : nullptr;
         for (int h = 0; h < (a.cfg ? 2 : 1); ++h) {
-            const size_t i = (size_t)(row + h * half) * a.Cout + lane;
+            const size_t i = (size_t)(rowc + h * half) * a.Cout + lane;
             const float y = euler_update(a.state[i], dtv, mine);   // both halves hold the same state and receive the same update
             a.state[i] = y;
             if (slice) slice[i] = y;
@@ -419,7 +447,8 @@ extern "C" int ga_small_linear(const GaSmallLinearArgs *a, void *stream)
     using namespace gadit;
     if (!a || !a->x || !a->W || !a->y) return GA_DIT_ERR_NULL_ARG;
     if (a->B <= 0 || a->B > 16 || a->N <= 0 || a->K <= 0 || a->K % 8 != 0 || (a->act_in == 2 && a->K != 256)) return GA_DIT_ERR_BAD_SHAPE;
-    hipLaunchKernelGGL(small_linear_kernel, dim3((a->N + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
+    gadit::ModOut none{};
+    hipLaunchKernelGGL(small_linear_kernel, dim3((a->N + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a, none);
     return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
 }
 
@@ -581,14 +610,12 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     }
     GaSmallLinearArgs l3{B, D, D, 0, 0, w.t1, m->t_mlp2_w, m->t_mlp2_b, pvec, w.tvec};
     GA_TRY(ga_small_linear(&l3, stream));
-    GaSmallLinearArgs l4{B, 6 * D, D, 1, 0, w.tvec, m->adaln_w, m->adaln_b, nullptr, w.t0};
-    GA_TRY(ga_small_linear(&l4, stream));
-    {
-        ModTableArgs mt{};
-        for (int i = 0; i < m->depth; ++i) mt.tables[i] = m->blocks[i].scale_shift_table;
-        mt.t0 = w.t0; mt.mod = w.mod; mt.depth = m->depth; mt.B = B; mt.D = D;
-        const int64_t tot = (int64_t)m->depth * B * 6 * D;
-        hipLaunchKernelGGL(mod_table_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, mt);
+    {   // t0 = adaLN(SiLU(t)), and with it mod[blk][b] = scale_shift_table_blk + t0[b] of every block (dit_models_xformers.py:769-770)
+        GaSmallLinearArgs l4{B, 6 * D, D, 1, 0, w.tvec, m->adaln_w, m->adaln_b, nullptr, w.t0};
+        ModOut mo{};
+        for (int i = 0; i < m->depth; ++i) mo.tables[i] = m->blocks[i].scale_shift_table;
+        mo.mod = w.mod; mo.depth = m->depth;
+        hipLaunchKernelGGL(small_linear_kernel, dim3((l4.N + 3) / 4), dim3(256), 0, s, l4, mo);
     }
     // the modulated pre-norms of the self-attention and the MLP fold into the neighbouring GEMMs like the cross-attention's (below):
     // their shifts go through the qkv / fc1 weights once per evaluation, for all blocks in one launch
@@ -796,7 +823,8 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
             }
             rows = st->cfg ? Mrows / 2 : Mrows;
         }
-        hipLaunchKernelGGL(final_layer_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, f);
+        // (with CFG a workgroup serves two rows of the conditional half: two waves each for the rows and their unconditional twins)
+        hipLaunchKernelGGL(final_layer_kernel, dim3(a->step && a->step->cfg ? (rows + 1) / 2 : (rows + 3) / 4), dim3(256), 0, s, f);
     }
     return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
 }

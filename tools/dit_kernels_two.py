@@ -18,6 +18,17 @@ if what == "attn":
         vt = ops.transpose_v(v)
         for _ in range(20): ops.attention(qq, k, vt, None, None)
         torch.cuda.synchronize()
+    # round 5: the cross-attention launch of the evaluation proper -- the q projection (K = 1024, tiled weight, folded row scale, per-head
+    # norm) inside the workgroups (GaAttentionArgs.qp_*): attention_fwd_kernel<4, 3, false> again, 20 launches behind the 20 above
+    B, H, Lq, Lk, K = 1, 16, 768, 1369, 1024
+    D = H * 64
+    A = torch.randn(B * Lq, K, device=dev).bfloat16(); W = (torch.randn(D, K, device=dev) / 32).bfloat16()
+    kv = torch.randn(B, Lk, 2 * D, device=dev).bfloat16()
+    k = kv[..., :D].unflatten(-1, (H, 64)); vt = ops.transpose_v(kv[..., D:].unflatten(-1, (H, 64)))
+    rss = torch.rand(B * Lq, 16, device=dev) * 64; wq = torch.ones(64, device=dev)
+    qp = dict(a=A, w=ops.tile_weight(W), tiled=True, row_ss=rss, row_ss_dim=K, B=B, Lq=Lq, H=H)
+    for _ in range(20): ops.attention(None, k, vt, q_norm_weight=wq, qp=qp)
+    torch.cuda.synchronize()
 else:
     for (M, N, K, epi) in [(1536, 3072, 1024, 0), (1536, 4096, 1024, 1), (1536, 1024, 4096, 2), (1536, 1024, 1024, 2), (768, 1024, 1024, 0)]:
         A = torch.randn(M, K, device=dev).bfloat16(); W = (torch.randn(40, N, K, device=dev) * 0.03).bfloat16()
