@@ -884,6 +884,10 @@ def main():
             out["attention"] = bench_attention(dev)
             from tools.gemm_yardstick import yardstick   # same-run, same-node: torch.matmul beside ga_gemm_bf16 (tools only)
             out["gemm_yardstick"] = yardstick(dev)
+            gj = committed_pmc("r5_gemm_pmc.json")   # MFMA busy of the GEMM kernels (committed counter pass, hash-keyed like the blend's)
+            out["gemm_yardstick"]["mfma_busy_from_counters"] = ({"kernels": {k: v["mfma_busy"] for k, v in gj["kernels"].items()},
+                                                                 "source": gj["source"] + " (committed rocprofv3 PMC pass; dit_gemm.hip unchanged since)"}
+                                                                if gj else None)
             out["decode"] = bench_decode(dev, cams)
             out["conditioner"] = bench_conditioner(dev)
         if world == 1 and not a.no_extras and not a.no_dit:   # (--no-dit is the quick rasterizer-only mode of the tools)

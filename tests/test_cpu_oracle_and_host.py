@@ -572,6 +572,12 @@ def test_committed_bench_line_follows_the_contract():
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+    # round 5: the absolute pixel bars and the full-depth trajectory on `parity`; the compact summary is the LAST key of the line
+    p = d["parity"]
+    assert p["pass"] is True and p["bins_bit_identical"] is True and p["max_abs"] <= 0.25 and p["pixels_beyond_1e-4_fraction"] <= 3e-4
+    assert 0 < p["trajectory_rel_l2"] < 3e-2 and p["trajectory"]["pass"] is True
+    assert list(d)[-1] == "summary" and len(json.dumps(d["summary"])) <= 1500
+    assert d["summary"]["sec_per_sample"] == d["sec_per_sample"] and d["summary"]["parity"]["traj_rel_l2"] == p["trajectory_rel_l2"]
 
 
 def test_dopri5_refuses_non_finite_models_and_step_underflow():

@@ -63,6 +63,19 @@ def main():
                "source_sha256": {rel: sha(rel) for rel in ("gaussiananything_amd/csrc/dit_attention.hip", "gaussiananything_amd/csrc/dit_common.h",
                                                          "gaussiananything_amd/csrc/Makefile")}},
               open(os.path.join(ROOT, "profiles", "r5_attention_pmc.json"), "w"), indent=1)
+    gm = {}
+    for name, c in counters(os.path.join(ROOT, "profiles", "r5_gemm_pmc.txt"), "gemm_").items():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+            gm[name[:60]] = {"mfma_busy": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (c["GRBM_GUI_ACTIVE"] / 8), 4),
+                             "SQ_VALU_MFMA_BUSY_CYCLES": c["SQ_VALU_MFMA_BUSY_CYCLES"], "GRBM_GUI_ACTIVE": c["GRBM_GUI_ACTIVE"]}
+    json.dump({"_comment": "MFMA busy of the GEMM launches of a DiT-L block (tools/dit_kernels_two.py gemm, cold weights; profiles/r5_gemm_pmc.txt): "
+                           "<0,4,2,3,4,4,2> qkv 1536x3072x1024, <1,4,2,3,4,4,2> fc1 1536x4096x1024 (GELU), <2,2,2,3,2,4,0> fc2 1536x1024x4096 and proj "
+                           "1536x1024x1024 (residual), <0,4,1,1,4,4,0> the 768x1024x1024 cross-attention projection shape",
+               "kernels": gm, "source": "profiles/r5_gemm_pmc.txt",
+               "source_sha256": {rel: sha(rel) for rel in ("gaussiananything_amd/csrc/dit_gemm.hip", "gaussiananything_amd/csrc/dit_common.h",
+                                                         "gaussiananything_amd/csrc/Makefile")}},
+              open(os.path.join(ROOT, "profiles", "r5_gemm_pmc.json"), "w"), indent=1)
+    print(json.dumps(gm, indent=1))
     print(json.dumps(blend, indent=1)[:600])
     print(json.dumps(att, indent=1))
 
