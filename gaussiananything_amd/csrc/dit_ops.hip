@@ -571,6 +571,30 @@ extern "C" int ga_dit_cache_context(const GaDitModel *m, int32_t batch, int32_t 
     return GA_DIT_OK;
 }
 
+namespace gadit {
+// The conditioning chain of an evaluation (timestep embedding -> + pooled vector -> adaLN -> modulation tables [-> block 0's shift
+// rows]) is three or four small dependent launches, ~30 us of pure latency, and nothing in front of block 0's cross-attention needs its
+// results: it CAN run on a helper stream beside the token embedding, its GEMM and block 0's pre-norm, forked from / joined to the caller's
+// stream with events (capture-safe: the helper stream joins a capture of the caller's stream and leaves it at the join) -- built and
+// measured in round 5, slower (see ga_dit_forward), kept behind GA_DIT_FORK=1.
+struct SideStream {
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ok = false;
+};
+static SideStream &side_stream()
+{
+    static thread_local SideStream ss = [] {
+        SideStream f;
+        f.ok = hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&f.join, hipEventDisableTiming) == hipSuccess;
+        return f;
+    }();
+    return ss;
+}
+}  // namespace gadit
+
 extern "C" int ga_dit_pooled_vector(const GaDitModel *m, int32_t batch, const float *img_vector, float *scratch, float *out, void *stream)
 {
     using namespace gadit;
@@ -601,21 +625,35 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     // ---- conditioning path: t = t_embedder(timesteps) + pooled_vec_embedder(img_vector); t0 = adaLN(SiLU(t))
     // (round 5: the sinusoidal features are formed inside the first linear -- one launch less -- and the pooled-vector branch, which
     //  does not depend on the time, is taken from the caller when it has been computed once per conditioning: ga_dit_pooled_vector)
+    // MEASURED SLOWER, off by default (GA_DIT_FORK=1 switches it on): DiT-L 3.05 -> 3.14 ms per step in the replayed Euler graph, 3.09 -> 3.20 per
+    // dopri5 evaluation, 3.06 -> 3.16 eager -- a cross-stream dependency costs this runtime ~45 us per hop, more than the ~25 us of
+    // chain it hides (the same sign as round 4's two concurrent CFG halves)
+    static const bool fork_env = [] { const char *e = getenv("GA_DIT_FORK"); return e && atoi(e) != 0; }();
+    SideStream *fk = fork_env ? &side_stream() : nullptr;
+    if (fk && (!fk->ok || hipEventRecord(fk->fork, s) != hipSuccess || hipStreamWaitEvent(fk->side, fk->fork, 0) != hipSuccess)) fk = nullptr;
+    hipStream_t cs = fk ? fk->side : s;      // the conditioning chain's stream
+    void *cstream = reinterpret_cast<void *>(cs);
+    bool joined = fk == nullptr;
+    auto join = [&]() {   // the caller's stream waits for the chain (before its first consumer: block 0's cross-attention launch and its tail)
+        if (joined) return true;
+        joined = true;
+        return hipEventRecord(fk->join, fk->side) == hipSuccess && hipStreamWaitEvent(s, fk->join, 0) == hipSuccess;
+    };
     GaSmallLinearArgs l1{B, D, 256, 2, 1, a->timesteps, m->t_mlp0_w, m->t_mlp0_b, nullptr, w.t1};
-    GA_TRY(ga_small_linear(&l1, stream));
+    if (ga_small_linear(&l1, cstream) != GA_DIT_OK) { join(); return GA_DIT_ERR_LAUNCH; }
     const float *pvec = a->pooled_vec;
     if (!pvec) {
-        GA_TRY(ga_dit_pooled_vector(m, B, a->img_vector, w.pln, w.pvec, stream));
+        if (ga_dit_pooled_vector(m, B, a->img_vector, w.pln, w.pvec, cstream) != GA_DIT_OK) { join(); return GA_DIT_ERR_LAUNCH; }
         pvec = w.pvec;
     }
     GaSmallLinearArgs l3{B, D, D, 0, 0, w.t1, m->t_mlp2_w, m->t_mlp2_b, pvec, w.tvec};
-    GA_TRY(ga_small_linear(&l3, stream));
+    if (ga_small_linear(&l3, cstream) != GA_DIT_OK) { join(); return GA_DIT_ERR_LAUNCH; }
     {   // t0 = adaLN(SiLU(t)), and with it mod[blk][b] = scale_shift_table_blk + t0[b] of every block (dit_models_xformers.py:769-770)
         GaSmallLinearArgs l4{B, 6 * D, D, 1, 0, w.tvec, m->adaln_w, m->adaln_b, nullptr, w.t0};
         ModOut mo{};
         for (int i = 0; i < m->depth; ++i) mo.tables[i] = m->blocks[i].scale_shift_table;
         mo.mod = w.mod; mo.depth = m->depth;
-        hipLaunchKernelGGL(small_linear_kernel, dim3((l4.N + 3) / 4), dim3(256), 0, s, l4, mo);
+        hipLaunchKernelGGL(small_linear_kernel, dim3((l4.N + 3) / 4), dim3(256), 0, cs, l4, mo);
     }
     // the modulated pre-norms of the self-attention and the MLP fold into the neighbouring GEMMs like the cross-attention's (below):
     // their shifts go through the qkv / fc1 weights once per evaluation, for all blocks in one launch
@@ -648,8 +686,11 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         sb.shift_which_off = 3 * (long long)D; sb.out_block_stride = (long long)B * 7 * D;
         // (GA_DIT_SBTAIL=0: all blocks here, A/B aid; default: block 0 here, block i + 1 behind the self-attention grid of block i)
         sb.N0 = 3 * D; sb.N1 = 4 * D; sb.K = D; sb.B = B; sb.jobs = sb_tail ? 1 : m->depth; sb.tiled = m->gemm_weights_tiled;
-        hipLaunchKernelGGL(shift_bias_kernel, dim3((unsigned)(sb.jobs * shift_bias_wgs(sb.N0, sb.N1))), dim3(1024), 0, s, sb);
+        hipLaunchKernelGGL(shift_bias_kernel, dim3((unsigned)(sb.jobs * shift_bias_wgs(sb.N0, sb.N1))), dim3(1024), 0, cs, sb);
     }
+    // every early return below joins first (a forked capture must be rejoined)
+#undef GA_TRY
+#define GA_TRY(expr) do { const int rc_ = (expr); if (rc_ != GA_DIT_OK) { join(); return rc_; } } while (0)
     // ---- token embedding: x = fc2(gelu_tanh(fc1(x))) (+ xyz positional embedding)
     {
         EmbedArgs e{Mrows, D, m->in_channels, m->stage2, a->x, m->xe_fc1_w, m->xe_fc1_b, a->fps_xyz, m->xyz_w, m->xyz_b,
@@ -662,7 +703,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     }
     const size_t kv_rows = (size_t)B * a->ctx_tokens;
     const int64_t Mp = ((int64_t)a->ctx_tokens + 63) / 64 * 64, Lp = ((int64_t)L + 63) / 64 * 64;
-    if (Lp != L && hipMemsetAsync(w.vt, 0, w.vt_bytes, s) != hipSuccess) return GA_DIT_ERR_LAUNCH;  // zero key padding
+    if (Lp != L && hipMemsetAsync(w.vt, 0, w.vt_bytes, s) != hipSuccess) { join(); return GA_DIT_ERR_LAUNCH; }  // zero key padding
     const int Mca = ca_batch * L;
     for (int i = 0; i < m->depth; ++i) {
         const GaDitBlockWeights &bw = m->blocks[i];
@@ -682,6 +723,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
             GA_TRY(ga_gemm_bf16(&gq, stream));
             GA_TRY(ga_head_rmsnorm_bf16(w.qkv, Mca, D, m->heads, hd, bw.ca_q_norm_w, stream));
             const ga_bf16 *ckv = a->ca_k + (size_t)i * kv_rows * 2 * D;
+            if (i == 0 && !join()) return GA_DIT_ERR_LAUNCH;
             GaAttentionHdArgs ca{ca_batch, m->heads, L, a->ctx_tokens, hd, w.qkv, ckv, ckv + D, D, 2 * D, 2 * D, w.att, D};
             GA_TRY(ga_attention_hd_bf16(&ca, stream));
             GaGemmArgs go{};
@@ -738,6 +780,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
             gq.qk_w0 = bw.ca_q_norm_w; gq.qk_cols0 = D; gq.qk_cols1 = D;           // q_norm fused into the projection
             GA_UNLESS(32, ga_gemm_bf16(&gq, stream));
         }
+        if (i == 0 && !join()) return GA_DIT_ERR_LAUNCH;     // the conditioning chain's results from here on (mod, tvec, block 0's shift rows)
         if (i == 0 && sb_tail0) {
             ShiftBiasJob job{{bw.qkv_w, bw.fc1_w}, {bw.qkv_b, bw.fc1_b}, w.mod, w.sbias,
                              6 * (long long)D, 3 * (long long)D, 3 * D, 4 * D, D, B, m->gemm_weights_tiled};
