@@ -133,7 +133,9 @@ typedef struct GaSurfelWorkspaceLayout {
 } GaSurfelWorkspaceLayout;
 
 #define GA_SURFEL_RECORD_FLOATS 24
+#ifndef GA_SURFEL_SORT_RUN
 #define GA_SURFEL_SORT_RUN 2048    /* entries sorted per LDS pass of the per-tile sort */
+#endif
 
 /* host: fills `out` for the given problem size; returns GA_OK or GA_ERR_BAD_SHAPE */
 int ga_surfel_workspace_layout(int32_t num_points, int32_t num_views, int32_t image_height, int32_t image_width,
