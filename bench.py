@@ -610,8 +610,8 @@ def bench_mesh_export(g, cams, dev):
         torch.cuda.synchronize(); t2 = time.perf_counter()
         res = {"fuse_and_extract_ms": round((t1 - t0) * 1e3, 3), "post_process_ms": round((t2 - t1) * 1e3, 3),
                "views": nv, "vertices": int(v.shape[0]), "triangles": int(t.shape[0]), "post_triangles": int(pt.shape[0])}
-    res["note"] = ("volume allocation (0.87 GB zero-fill) + 8 x ga_tsdf_integrate + marching cubes, then the device connected-component "
-                   "filter; per-phase times: profiles/r2_tsdf_bench.json; Open3D on the CPU in the reference")
+    res["note"] = ("volume allocation (0.87 GB zero-fill) + 8 x ga_tsdf_integrate + marching cubes, then the cluster filter (round 5: "
+                   "union-find kernel ga_mesh_cluster_labels, 9.9 -> 1.6 ms); per-phase times: profiles/r5_tsdf_bench.json; Open3D on the CPU in the reference")
     return res
 
 

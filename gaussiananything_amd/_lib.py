@@ -76,7 +76,7 @@ class GaTsdfFrame(ctypes.Structure):
 
 EXPORTS = ("ga_surfel_version", "ga_surfel_workspace_layout", "ga_surfel_workspace_layout2", "ga_surfel_forward", "ga_surfel_postprocess",
            "ga_surfel_backward", "ga_surfel_backward_scratch_bytes",
-           "ga_tsdf_integrate", "ga_tsdf_mesh_scratch_bytes", "ga_tsdf_mesh_count", "ga_tsdf_mesh_emit", "ga_mesh_write_obj")
+           "ga_tsdf_integrate", "ga_tsdf_mesh_scratch_bytes", "ga_tsdf_mesh_count", "ga_tsdf_mesh_emit", "ga_mesh_write_obj", "ga_mesh_cluster_labels")
 
 _lib = None
 
@@ -125,6 +125,8 @@ def lib():
         L.ga_tsdf_mesh_scratch_bytes.argtypes = [ctypes.POINTER(GaTsdfVolume)]
         L.ga_tsdf_mesh_count.restype = ctypes.c_int
         L.ga_tsdf_mesh_count.argtypes = [ctypes.POINTER(GaTsdfVolume), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+        L.ga_mesh_cluster_labels.restype = ctypes.c_int
+        L.ga_mesh_cluster_labels.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
         L.ga_mesh_write_obj.restype = ctypes.c_int
         L.ga_mesh_write_obj.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
         L.ga_tsdf_mesh_emit.restype = ctypes.c_int

@@ -446,6 +446,73 @@ extern "C" int ga_tsdf_mesh_emit(const GaTsdfVolume *volume, void *scratch, size
 // for the reference (flow_matching_trainer.py:1297, 1311).  Host arrays; returns 0, or GA_ERR_NULL_ARG / GA_ERR_LAUNCH (I/O).
 #include <cstdio>
 #include <vector>
+// ---- connected triangle clusters (utils/mesh_util.py:22-44 -> Open3D cluster_connected_triangles: triangles joined through shared
+// edges).  Lock-free union-find over the pairs of triangles that share an edge: a pair hooks the LARGER of its two roots under the
+// smaller one with a compare-and-swap and retries until both ends have one root, so one pass over the pairs is complete and the root of
+// a cluster is its smallest triangle index whatever the order the pairs are served in (deterministic labels).  Round 4 did this with
+// device-wide torch operations (min-label propagation + pointer jumping, seven rounds of ~8 launches over 1 M triangles: 9.9 ms).
+namespace gamesh {
+
+__device__ __forceinline__ int32_t cc_find(int32_t *parent, int32_t x)
+{
+    int32_t p = __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != x) {   // path halving (parents only ever decrease: a stale read costs a step, never correctness)
+        const int32_t g = __hip_atomic_load(parent + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g != p) __hip_atomic_store(parent + x, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = p;
+        p = g;
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(256) void cc_init_kernel(int32_t *parent, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) parent[i] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(256) void cc_hook_kernel(const int64_t *__restrict__ a, const int64_t *__restrict__ b, int64_t npairs, int32_t *parent)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npairs) return;
+    int32_t ra = cc_find(parent, (int32_t)a[i]), rb = cc_find(parent, (int32_t)b[i]);
+    while (ra != rb) {
+        if (ra < rb) { const int32_t t = ra; ra = rb; rb = t; }     // ra > rb: hook ra under rb if ra is still a root
+        const int32_t prev = atomicCAS(parent + ra, ra, rb);
+        if (prev == ra) break;
+        ra = cc_find(parent, prev);                                   // somebody hooked it first: follow and retry
+        rb = cc_find(parent, rb);
+    }
+}
+
+__global__ __launch_bounds__(256) void cc_flatten_kernel(int32_t *parent, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        // read-only walk: a path-halving store of another thread could land AFTER this thread's final store and leave a non-root label
+        int32_t x = (int32_t)i, p = __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (p != x) { x = p; p = __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        __hip_atomic_store(parent + i, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (readers see the old parent or the root: both lead to the root)
+    }
+}
+
+}  // namespace gamesh
+
+extern "C" int ga_mesh_cluster_labels(const int64_t *pair_a, const int64_t *pair_b, int64_t num_pairs, int32_t *labels, int64_t num_triangles,
+                                      void *stream_v)
+{
+    using namespace gamesh;
+    if (!labels || (num_pairs > 0 && (!pair_a || !pair_b))) return GA_ERR_NULL_ARG;
+    if (num_triangles <= 0 || num_triangles > 0x7FFFFFFFll || num_pairs < 0) return GA_ERR_BAD_SHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_v);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(cc_init_kernel, dim3((unsigned)((num_triangles + 255) / 256)), dim3(256), 0, s, labels, num_triangles);
+    if (num_pairs > 0)
+        hipLaunchKernelGGL(cc_hook_kernel, dim3((unsigned)((num_pairs + 255) / 256)), dim3(256), 0, s, pair_a, pair_b, num_pairs, labels);
+    hipLaunchKernelGGL(cc_flatten_kernel, dim3((unsigned)((num_triangles + 255) / 256)), dim3(256), 0, s, labels, num_triangles);
+    return hipGetLastError() == hipSuccess ? GA_OK : GA_ERR_LAUNCH;
+}
+
 extern "C" int ga_mesh_write_obj(const char *path, const float *vertices, const float *colors, const int32_t *triangles,
                                  int64_t num_vertices, int64_t num_triangles)
 {

@@ -140,6 +140,27 @@ def extract_mesh_bounded(rgbmaps, depthmaps, alpha_maps, cam_pathes, aabb, alpha
     return volume.extract_triangle_mesh()
 
 
+def _propagate_labels(a, b, nt, dev):
+    """min-label propagation with root hooking and pointer jumping, device-agnostic torch operations (round 2-4's device path)"""
+    label = torch.arange(nt, device=dev, dtype=torch.int32)   # (32-bit labels: native atomic min)
+    for _ in range(100000):
+        la, lb = label[a], label[b]
+        act = la != lb       # a pair whose ends already share a label changes nothing in this round; leaving it out keeps
+        aa, bb, la, lb = a[act], b[act], la[act].long(), lb[act].long()   # the atomics off the big clusters' representatives
+        m = torch.minimum(la, lb).to(torch.int32)
+        # hook the smaller label under both triangles and under their current representatives (links trees, not only
+        # neighbours: logarithmically many rounds instead of one per edge of the longest chain), then jump pointers
+        new = label.scatter_reduce(0, la, m, "amin").scatter_reduce(0, lb, m, "amin")
+        new = new.scatter_reduce(0, aa, m, "amin").scatter_reduce(0, bb, m, "amin")
+        new = new[new.long()]
+        new = new[new.long()]
+        if torch.equal(new, label):
+            break
+        label = new
+    post_process_mesh.rounds = _ + 1
+    return label
+
+
 def post_process_mesh(vertices, colors, triangles):
     """utils/mesh_util.py:22-44: keep the (at most) ten largest connected triangle clusters and none below 50 triangles
     (clusters = triangles joined through shared edges, Open3D's cluster_connected_triangles), then drop unreferenced vertices
@@ -161,31 +182,30 @@ def post_process_mesh(vertices, colors, triangles):
     owner = torch.arange(nt, device=dev).repeat(3)[order]
     same = key[1:] == key[:-1]
     a, b = owner[:-1][same], owner[1:][same]          # triangles that share an edge
-    label = torch.arange(nt, device=dev, dtype=torch.int32)   # (32-bit labels: native atomic min)
-    for _ in range(100000):
-        la, lb = label[a], label[b]
-        act = la != lb       # a pair whose ends already share a label changes nothing in this round; leaving it out keeps
-        aa, bb, la, lb = a[act], b[act], la[act].long(), lb[act].long()   # the atomics off the big clusters' representatives
-        m = torch.minimum(la, lb).to(torch.int32)
-        # hook the smaller label under both triangles and under their current representatives (links trees, not only
-        # neighbours: logarithmically many rounds instead of one per edge of the longest chain), then jump pointers
-        new = label.scatter_reduce(0, la, m, "amin").scatter_reduce(0, lb, m, "amin")
-        new = new.scatter_reduce(0, aa, m, "amin").scatter_reduce(0, bb, m, "amin")
-        new = new[new.long()]
-        new = new[new.long()]
-        if torch.equal(new, label):
-            break
-        label = new
-    post_process_mesh.rounds = _ + 1
+    if dev.type == "cuda":
+        # round 5: one lock-free union-find pass on the device (ga_mesh_cluster_labels, csrc/tsdf.hip): labels = the smallest triangle of
+        # each cluster, as the propagation below converges to
+        label = torch.empty(nt, device=dev, dtype=torch.int32)
+        a, b = a.contiguous(), b.contiguous()
+        _lib.check(_lib.lib().ga_mesh_cluster_labels(a.data_ptr(), b.data_ptr(), a.numel(), label.data_ptr(), nt,
+                                                     ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "ga_mesh_cluster_labels")
+        post_process_mesh.rounds = 1
+    else:
+        label = _propagate_labels(a, b, nt, dev)      # host tensors (the CPU tests): the same clusters with torch operations
     label = label.long()
-    cluster_n = torch.bincount(label, minlength=nt)    # only the clusters' smallest triangles carry a count
+    # cluster sizes at the clusters' smallest triangles.  Not torch.bincount: a generated object is ONE big cluster, i.e. a million
+    # atomic increments of one address (12 of the 14 ms of this function on the device); a sort and run lengths instead
+    uniq, counts = torch.unique_consecutive(torch.sort(label).values, return_counts=True)
+    cluster_n = torch.zeros(nt, dtype=torch.long, device=dev)
+    cluster_n[uniq] = counts
     sizes = torch.sort(cluster_n[cluster_n > 0]).values
     cluster_to_keep = min(int(sizes.numel()), 10)
     n_cluster = max(int(sizes[-cluster_to_keep]), 50)
     t = t[cluster_n[label] >= n_cluster]
-    used = torch.unique(t)
-    remap = torch.full((nv,), -1, dtype=torch.long, device=dev)
-    remap[used] = torch.arange(used.numel(), device=dev)
+    flags = torch.zeros(nv, dtype=torch.bool, device=dev)          # referenced vertices, ascending (what torch.unique's sort gave)
+    flags[t.reshape(-1)] = True
+    used = flags.nonzero().squeeze(1)
+    remap = torch.cumsum(flags, 0) - 1
     t = remap[t]
     t = t[(t[:, 0] != t[:, 1]) & (t[:, 1] != t[:, 2]) & (t[:, 0] != t[:, 2])]
     return vertices[used], colors[used], t.to(torch.int32)

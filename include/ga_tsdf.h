@@ -78,6 +78,13 @@ int ga_tsdf_mesh_count(const GaTsdfVolume *volume, void *scratch, size_t scratch
 int ga_tsdf_mesh_emit(const GaTsdfVolume *volume, void *scratch, size_t scratch_bytes, int64_t num_vertices, int64_t num_triangles,
                       float *vertices, float *colors, int32_t *triangles, void *stream);
 
+/* Connected triangle clusters of post_process_mesh (/root/reference/utils/mesh_util.py:22-44 -> Open3D's cluster_connected_triangles:
+ * triangles joined through shared edges): pair_a[i], pair_b[i] (device, int64) are two triangles that share an edge; on return
+ * labels[t] (device, int32 [num_triangles]) is the SMALLEST triangle index of t's cluster -- one lock-free union-find pass, the same
+ * labels whatever order the pairs are served in. */
+int ga_mesh_cluster_labels(const int64_t *pair_a, const int64_t *pair_b, int64_t num_pairs, int32_t *labels, int64_t num_triangles,
+                           void *stream);
+
 /* host: write a triangle mesh (HOST arrays: vertices [nv,3], colors [nv,3] in [0,1] or NULL, triangles [nt,3] zero-based) as
  * Wavefront OBJ with per-vertex colours, replacing o3d.io.write_triangle_mesh (flow_matching_trainer.py:1297, 1311).
  * GA_ERR_LAUNCH reports an I/O failure. */

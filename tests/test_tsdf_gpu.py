@@ -69,6 +69,36 @@ def test_mesh_matches_the_oracle_vertex_by_vertex_and_triangle_by_triangle(gpu_d
     assert len(ot2) < len(t2)
 
 
+def test_cluster_labels_union_find_against_scipy(gpu_device):
+    """ga_mesh_cluster_labels (round 5: one lock-free union-find pass instead of seven rounds of device-wide torch operations): random pair
+    lists -- long chains, many small clusters, isolated triangles, duplicate and self pairs -- give exactly the labels scipy's connected
+    components give when every cluster is named by its smallest member, run to run (the labels do not depend on the service order)."""
+    import ctypes
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import connected_components
+    from gaussiananything_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    for n, m, chain in ((1000, 700, False), (200_000, 150_000, False), (50_000, 49_999, True), (10, 0, False)):
+        if chain:
+            perm = rng.permutation(n)
+            a, b = perm[:-1].copy(), perm[1:].copy()          # one cluster, a chain in random index order
+        else:
+            a, b = rng.integers(0, n, m), rng.integers(0, n, m)
+        g = sp.coo_matrix((np.ones(len(a)), (a, b)), shape=(n, n))
+        _, comp = connected_components(g, directed=False)
+        smallest = np.full(comp.max() + 1, n, np.int64)
+        np.minimum.at(smallest, comp, np.arange(n))
+        want = smallest[comp]
+        ta, tb = torch.from_numpy(a.astype(np.int64)).to(gpu_device), torch.from_numpy(b.astype(np.int64)).to(gpu_device)
+        for _ in range(2):
+            lab = torch.empty(n, dtype=torch.int32, device=gpu_device)
+            rc = L.ga_mesh_cluster_labels(ta.data_ptr() if len(a) else None, tb.data_ptr() if len(a) else None, len(a), lab.data_ptr(), n,
+                                          ctypes.c_void_p(torch.cuda.current_stream(gpu_device).cuda_stream))
+            assert rc == 0
+            assert np.array_equal(lab.cpu().numpy().astype(np.int64), want)
+
+
 def test_partially_observed_volume_and_empty_volume(gpu_device):
     frames = sphere_frames(1, 64)
     ovol, hvol = _fuse_both(gpu_device, frames, (3, 4, 5), (-1, -2, -3), 0.0125, 0.075)
