@@ -632,6 +632,8 @@ def summary_of(out):
                        "traffic_MB": None if not out["roofline"].get("traffic") else round(out["roofline"]["traffic"] / 1e6, 1)}
     if out.get("stress_scene"):
         sm["stress_ms"] = out["stress_scene"]["ms_per_step"]
+    if out.get("two_streams"):
+        sm["two_streams_Msplats_s"] = out["two_streams"]["Msplats_per_s"]
     if out.get("parity"):
         pr = out["parity"]
         sm["parity"] = {"pass": pr.get("pass"), "bins_exact": pr.get("bins_bit_identical"), "mse": pr.get("max_channel_mse"),
@@ -866,6 +868,30 @@ def main():
             out["stage_ms"]["device_total"] = round(total_dev, 5)
             if a.scene == "surface" and not a.no_extras:
                 out["stress_scene"] = stress_scene_line(cams, a.points, H, W, dev)
+                # untimed, beside the headline (which stays ONE forward at a time on one stream): two INDEPENDENT surfel sets rendered
+                # concurrently on two streams -- the latency-bound front-end of one hides under the issue-bound blend of the other
+                # (tools/overlap_probe.py)
+                g2 = synthetic.surface_surfels(a.points, seed=101 + rank)[0]
+                m2, o2, s2_, r2, c2 = [t.to(dev) for t in synthetic.split_gaussians(g2)]
+                plan2 = SurfelForwardPlan(m2, o2, c2, s2_, r2, cams["cam_view"].to(dev), cams["cam_view_proj"].to(dev), torch.ones(3, device=dev), H, W)
+                plan2.run(); plan2.ensure_capacity()
+                sA, sB = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+                def pair():
+                    with torch.cuda.stream(sA):
+                        plan.run()
+                    with torch.cuda.stream(sB):
+                        plan2.run()
+                for _ in range(5):
+                    pair()
+                torch.cuda.synchronize()
+                tp0 = time.perf_counter()
+                for _ in range(30):
+                    pair()
+                torch.cuda.synchronize()
+                pms = (time.perf_counter() - tp0) / 30 * 1e3
+                out["two_streams"] = {"ms_per_pair_of_forwards": round(pms, 4), "Msplats_per_s": round(2 * n * v / pms / 1e3, 1),
+                                      "note": "two independent 100k-surfel sets x 8 views on two streams, NOT the headline (one forward at a time)"}
+                del plan2
         if not a.no_parity:
             out["parity"] = parity_check(g, cams, H, W, dev)
         if world == 1 and not a.no_cpu_baseline:
