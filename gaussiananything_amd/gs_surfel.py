@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import torch
 
+from . import io_formats
 from .diff_surfel_rasterization import postprocess_views, rasterize_views
 
 
@@ -66,3 +67,11 @@ class GaussianRenderer2DGS:
         # alpha / dist are channels 1 / 6 of allmap (:121,142): views for one batch item, one stack otherwise
         am = allmaps[0].unsqueeze(0) if B == 1 else torch.stack(allmaps, dim=0)
         return {"image": image, "alpha": am[:, :, 1:2], "depth": depth, "rend_normal": rend_normal, "dist": am[:, :, 6:7]}
+
+    def save_2dgs_ply(self, path, gaussians, compatible=True):
+        """nsr/gs_surfel.py:206-265; the upstream body references undefined names -- ``io_formats.save_2dgs_ply`` writes the
+        file it describes (host I/O)."""
+        io_formats.save_2dgs_ply(path, gaussians, compatible=compatible)
+
+    def load_2dgs_ply(self, path, compatible=True):
+        return torch.from_numpy(io_formats.load_2dgs_ply(path, compatible=compatible))
