@@ -322,17 +322,21 @@ __device__ __forceinline__ void final_layer_row(const FinalArgs &a, int row, int
             sc[c] = make_float4(s4.x + t4.x, s4.y + t4.y, s4.z + t4.z, s4.w + t4.w);
         }
     }
-    // LayerNorm statistics in ONE pass (round 5: sum and sum of squares reduced together -- two dependent wave reductions before)
+    // LayerNorm statistics in ONE reduction round (round 5), about a pivot (round 6): sum and sum of squares of (x - x[0]) are reduced
+    // together -- the plain E[x^2] - mean^2 cancels when a row carries a common offset much larger than its spread; shifted by an
+    // element of the row the two terms are of the size of the spread itself (T2IFinalLayer's LayerNorm is two-pass upstream)
+    const float pivot = __shfl(v[0].x, 0, 64);
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c)
         if (c * 256 + lane * 4 < D) {
+            v[c].x -= pivot; v[c].y -= pivot; v[c].z -= pivot; v[c].w -= pivot;
             s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
             q += (v[c].x * v[c].x + v[c].y * v[c].y) + (v[c].z * v[c].z + v[c].w * v[c].w);
         }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-    const float mean = s / (float)D;
+    const float mean = s / (float)D;                       // of the shifted row
     const float rs = rsqrtf(fmaxf(q / (float)D - mean * mean, 0.f) + 1e-6f);
 #pragma unroll
     for (int c = 0; c < 8; ++c)

@@ -186,6 +186,7 @@ int ga_ode_dopri5_finish(const GaOdeDopri5 *o, void *stream)
     using namespace gaode;
     if (!o || !o->y || !o->ystage || !o->ctl || !o->t_grid || !o->out) return GA_DIT_ERR_NULL_ARG;
     if (o->n <= 0 || o->grid_len <= 0) return GA_DIT_ERR_BAD_SHAPE;
+    if (o->ctl_words < (int64_t)GA_ODE_CTL_WORDS + grid_for(o->n)) return GA_DIT_ERR_BAD_SHAPE;   // the partials would land outside `ctl`
     KPtrs kp;
     for (int j = 0; j < 7; ++j) { if (!o->k[j]) return GA_DIT_ERR_NULL_ARG; kp.k[j] = o->k[j]; }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -21,6 +21,8 @@
 // and the launch count is 4 instead of ~18.
 #include "surfel_common.h"
 
+#include <atomic>
+
 namespace ga {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1071,22 +1073,35 @@ void launch_binning(const GaSurfelForwardArgs &a, const Dims &d, const Workspace
     const unsigned nbx = (unsigned)std::max(1, (d.N + kFT * kFillSplats - 1) / (kFT * kFillSplats));
     const int nsched = (int)std::min<unsigned>(nbx, (unsigned)((nt + kFT - 1) / kFT));   // one schedule slot per thread of a row-0 workgroup
     // (16-bit halves in the schedule's class bins; the schedule workgroups' notes of the long lists fit point_list)
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) {   // 2 * kLdsTiles words of dynamic LDS (64 KiB at 8192 tiles) beside the kernels' static LDS: opted into once
-        (void)hipFuncSetAttribute((const void *)surfel_fill_sched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kLdsTiles * (int)sizeof(uint32_t));
-        (void)hipFuncSetAttribute((const void *)surfel_fill_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kLdsTiles * (int)sizeof(uint32_t));
-        lds_attr_set = true;
+    // 2 * kLdsTiles words of dynamic LDS (64 KiB at 8192 tiles) beside the kernels' static LDS must be opted into: the attribute belongs
+    // to the function ON ONE DEVICE, so it is set once per device (0 = not yet, 1 = granted, 2 = refused; racing threads both set it:
+    // idempotent), and a refusal keeps the launches that would need it on the paths that fit the default 64 KiB
+    static std::atomic<uint8_t> lds_optin[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int di = dev >= 0 && dev < 64 ? dev : 63;
+    uint8_t st = dev == di ? lds_optin[di].load(std::memory_order_acquire) : (uint8_t)0;
+    if (st == 0) {
+        const int want = 2 * kLdsTiles * (int)sizeof(uint32_t);
+        const bool ok = hipFuncSetAttribute((const void *)surfel_fill_sched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess &&
+                        hipFuncSetAttribute((const void *)surfel_fill_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        st = ok ? 1 : 2;
+        lds_optin[di].store(st, std::memory_order_release);
     }
-    if (d.tiles <= kLdsTiles && nt <= 0xFFFF && (int64_t)nsched * 2 * (a.capacity / kSortCap + 1) <= a.capacity) {
-        hipLaunchKernelGGL(surfel_fill_sched_kernel, dim3(nbx, (unsigned)d.V + 1u), dim3(kFT), 2 * d.tiles * sizeof(uint32_t), s, sa,
+    // without the opt-in a launch may use 64 KiB of LDS in all; the fused kernel's static part is below 12 KiB (histl: 8.25), the plain fill's below 1 KiB
+    const size_t dyn = 2 * (size_t)d.tiles * sizeof(uint32_t);
+    const bool fused_fits = st == 1 || dyn + 12288 <= 65536, fill_fits = st == 1 || dyn + 1024 <= 65536;
+    if (fused_fits && d.tiles <= kLdsTiles && nt <= 0xFFFF && (int64_t)nsched * 2 * (a.capacity / kSortCap + 1) <= a.capacity) {
+        hipLaunchKernelGGL(surfel_fill_sched_kernel, dim3(nbx, (unsigned)d.V + 1u), dim3(kFT), dyn, s, sa,
                            ws.rect, ws.depth, d, ws.view_total, ws.keys, nsched, ws.point_list, ws.seg_scratch);
         return;
     }
     // larger problems: the single-workgroup scan in front of the fill
     hipLaunchKernelGGL(surfel_tile_scan_kernel, dim3(1), dim3(1024), 0, s, sa);
     const dim3 grid((unsigned)((d.N + 256 * kBinSplats - 1) / (256 * kBinSplats)), (unsigned)d.V);
-    if (d.tiles <= kLdsTiles)
-        hipLaunchKernelGGL(surfel_fill_kernel<true>, grid, dim3(256), 2 * d.tiles * sizeof(uint32_t), s, ws.rect, ws.depth, d, ws.tile_cursor,
+    if (d.tiles <= kLdsTiles && fill_fits)
+        hipLaunchKernelGGL(surfel_fill_kernel<true>, grid, dim3(256), dyn, s, ws.rect, ws.depth, d, ws.tile_cursor,
                            ws.keys, ws.status);
     else
         hipLaunchKernelGGL(surfel_fill_kernel<false>, grid, dim3(256), 0, s, ws.rect, ws.depth, d, ws.tile_cursor, ws.keys, ws.status);

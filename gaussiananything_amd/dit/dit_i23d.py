@@ -255,6 +255,15 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         self._pooled_cache = None
         return self._pack
 
+    def invalidate_conditioning_cache(self):
+        """Drop what the module derived from the conditioning tensors (K / V of ``img_crossattn``, the pooled-vector branch of
+        ``img_vector``).  Both are keyed on (address, autograd version, shape): a write that does not move the version counter --
+        ``.data.copy_``, a custom kernel, DLPack / another framework writing into the same storage -- must be followed by this call
+        (INTEGRATION.md section 3).  The sampling entry points copy their conditioning into module-owned buffers with ``copy_``
+        every call, so they never serve a stale projection."""
+        self._ctx_cache = None
+        self._pooled_cache = None
+
     ca_skip = True  # skip the cross-attention of batch items whose image tokens are all zero (exact; tests switch it off)
     # fold the (un-modulated) cross-attention pre-norm into the neighbouring GEMMs (include/ga_dit.h); GA_DIT_FOLD=0: A/B aid
     fold_prenorm = os.environ.get("GA_DIT_FOLD", "1") != "0"
@@ -533,7 +542,7 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         if ng > 1:
             if st["graph"] is None:
                 ode = ops.GaOdeDopri5(n, B, ng, y.data_ptr(), (ops.c_p * 7)(*[t.data_ptr() for t in k]), ystage.data_ptr(), tvec.data_ptr(),
-                                      ctl.data_ptr(), tg.data_ptr(), out.data_ptr())
+                                      ctl.data_ptr(), tg.data_ptr(), out.data_ptr(), ctl.numel())
 
                 def attempt():
                     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

@@ -70,7 +70,7 @@ class GaDitSamplerStep(ctypes.Structure):
 class GaOdeDopri5(ctypes.Structure):
     """include/ga_dit.h: GaOdeDopri5"""
     _fields_ = [("n", ctypes.c_int64), ("batch", i32), ("grid_len", i32), ("y", c_p), ("k", c_p * 7), ("ystage", c_p), ("timesteps", c_p),
-                ("ctl", c_p), ("t_grid", c_p), ("out", c_p)]
+                ("ctl", c_p), ("t_grid", c_p), ("out", c_p), ("ctl_words", ctypes.c_int64)]
 
 
 # indices into GaOdeDopri5.ctl (include/ga_dit.h)

@@ -339,6 +339,9 @@ typedef struct GaOdeDopri5 {
     double *ctl;            /* [GA_ODE_CTL_ALLOC] device scalars (head of GA_ODE_CTL_WORDS) + the error-norm partials */
     const double *t_grid;   /* [grid_len] requested times, increasing                     */
     float *out;             /* [grid_len, n] dense output (slice 0 is the caller's)        */
+    int64_t ctl_words;      /* doubles allocated behind `ctl`: at least GA_ODE_CTL_WORDS + min(ceil(n / 256), GA_ODE_MAX_PARTIALS);
+                             * GA_ODE_CTL_ALLOC always suffices.  ga_ode_dopri5_finish returns GA_DIT_ERR_BAD_SHAPE below that
+                             * (the error launch writes one partial per workgroup behind the head).                          */
 } GaOdeDopri5;
 
 int ga_ode_dopri5_stage(const GaOdeDopri5 *ode, int32_t stage, void *stream);

@@ -539,6 +539,38 @@ def test_model_release_shape_against_oracle(gpu_device):
     assert torch.equal(y[1], y_full[1]) and rel_l2(y[0], y_full[0]) < 1e-2
 
 
+def test_final_layer_statistics_on_rows_with_a_large_common_offset(gpu_device):
+    """T2IFinalLayer's LayerNorm (dit_models_xformers.py:62-85) is two-pass upstream; the kernel reduces sum and sum of squares in one
+    round.  Rows whose common offset is ~2000 x their spread: E[x^2] - mean^2 in fp32 loses the variance there (a quarter of it at
+    this ratio), the pivoted form does not.  The blocks are switched off exactly (zero gates, zero cross-attention output), so the
+    final layer sees the token embedding + offset and the fp32 oracle is the yardstick for that kernel alone."""
+    from gaussiananything_amd.dit import DiT_I23D_PCD_PixelArt_noclip
+    from oracle import dit as od
+    torch.manual_seed(0)
+    model = DiT_I23D_PCD_PixelArt_noclip(input_size=16, patch_size=1, in_channels=3, hidden_size=768, depth=1,
+                                         num_heads=12, num_classes=0, learn_sigma=False, context_dim=1024,
+                                         pooling_ctx_dim=768, roll_out=True, use_clay_ca=True)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if float(p.abs().max()) == 0.0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+        for k, p in model.named_parameters():
+            if k.startswith("adaLN_modulation") or k.endswith("scale_shift_table") and k.startswith("blocks") \
+                    or "cross_attn_dino.to_out" in k:
+                p.zero_()
+        model.x_embedder.fc2.bias.add_(100.0)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = torch.randn(2, 768, 3, generator=g)
+    t = torch.tensor([0.3, 0.3])
+    ctx = {"img_crossattn": torch.randn(2, 1369, 1024, generator=g), "img_vector": torch.randn(2, 1024, generator=g)}
+    ref = od.dit_forward(sd, x, t, ctx)
+    model.to(gpu_device)
+    with torch.no_grad():
+        y = model(x.to(gpu_device), t.to(gpu_device), {k: v.to(gpu_device) for k, v in ctx.items()})
+    assert rel_l2(y.cpu(), ref) < 1e-2, rel_l2(y.cpu(), ref)
+
+
 @pytest.mark.parametrize("arch,C", [("DiT-PixArt-PCD-CLAY-L", 3), ("DiT-PixArt-PCD-CLAY-stage2-L", 10)])
 def test_release_models_full_depth_against_oracle(gpu_device, arch, C):
     """The two released denoisers at FULL size (DiT-L: depth 24, width 1024, 16 heads; stage 2 with the xyz positional
