@@ -21,6 +21,7 @@
 // ds_read_b128 lane groups).
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "dit_common.h"
@@ -58,6 +59,11 @@ struct GemmP {  // by-value kernel parameters (kept flat: no pointer into the ar
     const float *emit_w, *emit_scale;
     long long emit_scale_stride, bias_stride;
     int k_rows;
+    // deterministic split-K (round 6, include/ga_dit.h: GaGemmArgs.splitk_ws): blockIdx.z takes K / splits of the reduction; the partial
+    // tiles meet in sk_part, the last workgroup of a tile to arrive (sk_count) adds them in split order and runs the epilogue
+    int splits;
+    float *sk_part;
+    unsigned *sk_count;
 };
 
 // Element offset of chunk c (8 bf16) of weight row n at K-tile 0, and the stride from one K-tile to the next: row-major
@@ -561,7 +567,12 @@ __device__ __forceinline__ void static_for(F &&f)
 
 #define GA_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
-template <int EPI, int WM, int WN, int FM, int FN, int NST, int PIPE>
+// SK > 0: split-K over SK workgroups per tile (blockIdx.z).  Every workgroup writes its fp32 accumulator fragments lane-contiguously
+// (1 KiB per store instruction) with agent-scope stores, waits for them, and counts itself on the tile's word; the workgroup that
+// finds SK - 1 there reads the partials back with agent-scope loads and adds them IN SPLIT ORDER ((p0 + p1) + p2) + p3 -- its own
+// from registers, the same bits it stored -- so the result does not depend on who arrives last.  No fence (an agent-scope fence
+// writes back / invalidates the whole L2 of the XCD, see surfel_bin.hip: merge_runs); nobody waits for anybody: no residency assumption.
+template <int EPI, int WM, int WN, int FM, int FN, int NST, int PIPE, int SK = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
 {
     constexpr int NW = WM * WN, BM = WM * FM * 16, BNT = WN * FN * 16;
@@ -579,7 +590,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
     const int wn = wave / WM, wm = wave % WM;
     const int n0 = blockIdx.x * BNT, m0 = blockIdx.y * BM;
     const int M = p.M, N = p.N, K = p.K;
-    const int nk = K / BK;
+    const int nk = K / BK / (SK > 0 ? SK : 1);                 // K-tiles of THIS workgroup
+    const int kt0 = SK > 0 ? (int)blockIdx.z * nk : 0;         // its first one
 
     // DMA sources: instruction i of this wave fills rows q*8 .. q*8+7 of the slot image [W rows | A rows], q = i*NW + wave;
     // slot (row, s) of the 128-byte row receives global chunk s ^ (row & 7)
@@ -591,8 +603,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
 #pragma unroll
     for (int i = 0; i < DPT; ++i) {
         const int row = (i * NW + wave) * 8 + (lane >> 3);
-        if (i * NW * 8 < BNT) src[i] = p.W + w_offset(p, min(n0 + row, N - 1), (lane & 7) ^ (row & 7));
-        else src[i] = p.A + (size_t)min(m0 + row - BNT, arows - 1) * p.lda + ((lane & 7) ^ ((row - BNT) & 7)) * 8;
+        if (i * NW * 8 < BNT) src[i] = p.W + w_offset(p, min(n0 + row, N - 1), (lane & 7) ^ (row & 7)) + (size_t)kt0 * wks;
+        else src[i] = p.A + (size_t)min(m0 + row - BNT, arows - 1) * p.lda + ((lane & 7) ^ ((row - BNT) & 7)) * 8 + (size_t)kt0 * BK;
     }
     f32x4 acc[FN][FM];
 #pragma unroll
@@ -662,7 +674,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
             }
         }
     }
-    constexpr bool PRE = EPI == GA_GEMM_EPI_RESIDUAL && NW == 4;      // 8-wave tile: 256-register budget, no room
+    constexpr bool PRE = EPI == GA_GEMM_EPI_RESIDUAL && NW == 4 && SK == 0;      // 8-wave tile: 256-register budget, no room; split-K: only
+                                                                                 // one of SK workgroups runs the epilogue
     ResidualPrefetch<PRE ? FM : 1> pre;
     if (PRE) residual_prefetch<FM, FN / 2>(p, reinterpret_cast<ResidualPrefetch<FM> &>(pre), mrow0, ncol0, lane);
     constexpr bool RSS = EPI == GA_GEMM_EPI_STORE_BF16 || EPI == GA_GEMM_EPI_GELU_BF16;
@@ -778,6 +791,99 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
     }
     }   // product
 
+    if constexpr (SK > 0) {
+        const int split = __builtin_amdgcn_readfirstlane((int)blockIdx.z);
+        const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x;
+        constexpr size_t FRAG = 64 * 16, WAVE_BYTES = (size_t)FN * FM * FRAG, WG_BYTES = (size_t)NW * WAVE_BYTES;
+        char *tile_base = reinterpret_cast<char *>(p.sk_part) + (size_t)tile * SK * WG_BYTES + (size_t)wave * WAVE_BYTES + (size_t)lane * 16;
+        {
+            char *mine = tile_base + (size_t)split * WG_BYTES;
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(mine + (size_t)(i * FM + j) * FRAG), "v"(acc[i][j]) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my part of the partial tile has been written ...
+        __syncthreads();                                      // ... and everybody's; the ring is idle: its first word carries the rank
+        unsigned *rank_word = reinterpret_cast<unsigned *>(smem);
+        if (tid == 0) *rank_word = __hip_atomic_fetch_add(p.sk_count + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned rank = *rank_word;
+        if (rank != (unsigned)(SK - 1)) return;               // workgroup-uniform
+        __syncthreads();                                      // (the epilogues of the 32-column waves reuse the ring's first words)
+        if (tid == 0) __hip_atomic_store(p.sk_count + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left clean for the next launch
+        // last arriver: the other partials in split order, two of them in flight at a time
+        auto fetch = [&](int s_, f32x4(&dst)[FN][FM]) __attribute__((always_inline)) {
+            const char *src_ = tile_base + (size_t)s_ * WG_BYTES;
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst[i][j]) : "v"(src_ + (size_t)(i * FM + j) * FRAG) : "memory");
+        };
+        auto landed = [&](auto newerc, f32x4(&v)[FN][FM]) __attribute__((always_inline)) {   // all loads but the newest `newer` fragments
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(newerc)::value) : "memory");
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j) asm volatile("" : "+v"(v[i][j]));
+        };
+        auto add_to = [&](f32x4(&sum)[FN][FM], const f32x4(&t)[FN][FM]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j) sum[i][j] += t[i][j];
+        };
+        constexpr int NF = FN * FM;
+        static_for<0, SK>([&](auto myc) __attribute__((always_inline)) {
+            constexpr int MY = decltype(myc)::value;
+            if (split != MY) return;
+            // the others, in split order: o[0 .. SK-2]
+            f32x4 buf[2][FN][FM], sum[FN][FM];
+            constexpr int first_other = MY == 0 ? 1 : 0;
+            fetch(first_other, buf[0]);
+            if constexpr (SK > 2) fetch(first_other + 1 + (first_other + 1 == MY ? 1 : 0), buf[1]);
+            // walk s = 0 .. SK-1; `slot` = which buffer holds the next other partial, `next_other` = the next one to request
+            int dummy = 0; (void)dummy;
+            static_for<0, SK>([&](auto sc) __attribute__((always_inline)) {
+                constexpr int S_ = decltype(sc)::value;
+                constexpr int others_before = S_ - (S_ > MY ? 1 : 0);           // other partials consumed before step S_
+                if constexpr (S_ == MY) {
+                    if constexpr (S_ == 0) {
+#pragma unroll
+                        for (int i = 0; i < FN; ++i)
+#pragma unroll
+                            for (int j = 0; j < FM; ++j) sum[i][j] = acc[i][j];
+                    } else add_to(sum, acc);
+                } else {
+                    constexpr int slot = others_before & 1;
+                    constexpr int requested = (SK - 1) < 2 ? (SK - 1) : 2;      // in flight after the prologue
+                    // loads still allowed in flight when this one must have landed: the one requested after it, if any
+                    constexpr int total_requested_by_now = others_before + requested > SK - 1 ? SK - 1 : others_before + requested;
+                    constexpr int newer = (total_requested_by_now - others_before - 1) * NF;
+                    landed(std::integral_constant<int, newer>{}, buf[slot]);
+                    if constexpr (S_ == 0) {
+#pragma unroll
+                        for (int i = 0; i < FN; ++i)
+#pragma unroll
+                            for (int j = 0; j < FM; ++j) sum[i][j] = buf[slot][i][j];
+                    } else add_to(sum, buf[slot]);
+                    // request the other partial two ahead into the buffer just consumed
+                    constexpr int nxt_idx = others_before + 2;                  // index among the others
+                    if constexpr (nxt_idx < SK - 1) {
+                        constexpr int nxt_split = nxt_idx + (nxt_idx >= MY ? 1 : 0);
+                        fetch(nxt_split, buf[slot]);
+                    }
+                }
+            });
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j) acc[i][j] = sum[i][j];
+        });
+    }
+
     if constexpr (FN == 4) {
         gemm_epilogue<EPI, FM, 4, PRE, RSS, true>(p, acc, reinterpret_cast<const ResidualPrefetch<FM> *>(&pre),
                                                   reinterpret_cast<const RowSsPrefetch<FM> *>(&rss), mrow0, ncol0, lane, nullptr, bias_pre, qkw_pre, nullptr, nullptr, emul);
@@ -808,6 +914,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
 // depth, caps these tiles, so only more reuse per byte (larger workgroup tiles on grids that still fill the chip) helps.
 
 }  // namespace gadit
+
+namespace gadit {
+static std::atomic<int> &splitk_mode()
+{
+    static std::atomic<int> mode{[] { const char *e = getenv("GA_GEMM_SPLITK"); return e ? atoi(e) : -1; }()};
+    return mode;
+}
+}  // namespace gadit
+
+extern "C" int ga_gemm_splitk_mode(int mode)
+{
+    return gadit::splitk_mode().exchange(mode < -1 || mode > 3 ? -1 : mode);
+}
+
+extern "C" size_t ga_gemm_splitk_workspace_bytes(int32_t M, int32_t N)
+{
+    if (M <= 0 || N <= 0) return 0;
+    const size_t tiles = (size_t)((N + 127) / 128) * ((M + 191) / 192);
+    return GA_GEMM_SPLITK_COUNTER_BYTES + tiles * 4 * 192 * 128 * 4;   // (two 96-row tiles x 4 splits fit the same bytes)
+}
 
 extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
 {
@@ -840,7 +966,8 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
                   a->vt, a->vt_col0, a->vt ? (a->N - a->vt_col0) / 64 : 0, a->vt_ld, a->qk_w0, a->qk_w1, a->qk_cols0,
                   a->qk_cols1, a->emit_x, a->emit_ss, a->emit_ld, a->row_ss, a->row_ss_tiles,
                   a->row_ss_dim > 0 ? 1.0f / (float)a->row_ss_dim : 0.f, a->row_ss_eps, a->w_tiled ? 1 : 0,
-                  a->emit_w, a->emit_scale, a->emit_scale_stride, a->bias_stride, a->k_rows == a->M ? 0 : a->k_rows};
+                  a->emit_w, a->emit_scale, a->emit_scale_stride, a->bias_stride, a->k_rows == a->M ? 0 : a->k_rows,
+                  0, nullptr, nullptr};
     // Tile / ring choice (256 CUs).  A workgroup tile is 128 weight rows x 32 MT activation rows (MT = 4, 3, 2, 1); its work is
     // proportional to MT plus a tile-independent share (prologue, weight tile, epilogue: about one MT unit, tools/gemm_sweep.py) and
     // the launch ends with the busiest CU, so the cost of a choice is ceil(workgroups / 256) * (MT + 1)
@@ -855,6 +982,47 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
     // (fc1, qkv, everything at M >= 6144), else 96 x 64 (proj, fc2: 256 workgroups at M = 1536), else 64 x 64 (the M = 768
     // cross-attention projections).  The 96 x 64 tile has 32-column waves: for the per-head q/k norm its two waves exchange
     // their halves of the row sums of squares through LDS.
+    // Round 6: deterministic split-K for the residual GEMMs whose reduction is long and whose output is small (FusedMLP's second
+    // linear: K = 4 D).  At M <= 1536 rows the chip is only filled by 96 x 64 / 64 x 64 tiles, which pull 1.3 MB of operands through
+    // every CU's L1 miss path (the bound of these kernels); 192 x 128 tiles over a quarter of K each halve
+    // that, the partial tiles cost a quarter of what they save.  GA_GEMM_SPLITK (read once): 0 off, 1 / 2 / 3 force a configuration.
+    if (a->splitk_ws && a->epilogue == GA_GEMM_EPI_RESIDUAL && p.k_rows == 0) {
+        const int sk_env = splitk_mode().load(std::memory_order_relaxed);
+        const int nk = a->K / BK;
+        const bool per_batch = a->bias_stride != 0 || a->emit_scale != nullptr;
+        const bool rows48 = !per_batch || a->rows_per_batch % 48 == 0;
+        const long long t192 = (long long)((a->N + 127) / 128) * ((a->M + 191) / 192), t96 = (long long)((a->N + 127) / 128) * ((a->M + 95) / 96);
+        int cfg = 0;   // 1: 192 x 128 x 4 splits (8 waves), 2: 96 x 128 x 2 splits, 3: 96 x 128 x 4 splits (4 waves)
+        const bool ok4 = nk % 16 == 0 && nk >= 32, ok2 = nk % 8 == 0 && nk >= 16;
+        if (rows48 && ok4 && t192 * 4 >= 160 && t192 * 4 <= 256) cfg = 1;
+        else if (rows48 && ok4 && t96 * 4 >= 160 && t96 * 4 <= 256) cfg = 3;
+        if (sk_env == 0) cfg = 0;
+        else if (sk_env == 1 && rows48 && ok4) cfg = 1;
+        else if (sk_env == 2 && rows48 && ok2) cfg = 2;
+        else if (sk_env == 3 && rows48 && ok4) cfg = 3;
+        const long long tiles = cfg == 1 ? t192 : t96;
+        const int splits = cfg == 2 ? 2 : 4;
+        const size_t tile_bytes = (size_t)(cfg == 1 ? 192 : 96) * 128 * 4;
+        if (cfg && tiles <= GA_GEMM_SPLITK_MAX_TILES &&
+            (size_t)a->splitk_ws_bytes >= GA_GEMM_SPLITK_COUNTER_BYTES + (size_t)tiles * splits * tile_bytes && ((uintptr_t)a->splitk_ws & 255) == 0) {
+            GemmP q = p;
+            q.splits = splits;
+            q.sk_count = static_cast<unsigned *>(a->splitk_ws);
+            q.sk_part = reinterpret_cast<float *>(static_cast<char *>(a->splitk_ws) + GA_GEMM_SPLITK_COUNTER_BYTES);
+            // (the attribute is per device; setting it is cheap and idempotent)
+            if (cfg == 1) {
+                if (hipFuncSetAttribute((const void *)gemm_ring_kernel<2, 4, 2, 3, 4, 4, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 320 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH;
+                hipLaunchKernelGGL((gemm_ring_kernel<2, 4, 2, 3, 4, 4, 2, 4>), dim3((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 191) / 192), 4), dim3(512), 4 * 320 * BK * 2, s, q);
+            } else if (cfg == 2) {
+                if (hipFuncSetAttribute((const void *)gemm_ring_kernel<2, 2, 2, 3, 4, 4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 224 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH;
+                hipLaunchKernelGGL((gemm_ring_kernel<2, 2, 2, 3, 4, 4, 2, 2>), dim3((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 95) / 96), 2), dim3(256), 4 * 224 * BK * 2, s, q);
+            } else {
+                if (hipFuncSetAttribute((const void *)gemm_ring_kernel<2, 2, 2, 3, 4, 4, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 224 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH;
+                hipLaunchKernelGGL((gemm_ring_kernel<2, 2, 2, 3, 4, 4, 2, 4>), dim3((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 95) / 96), 4), dim3(256), 4 * 224 * BK * 2, s, q);
+            }
+            return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
+        }
+    }
     {
         const int nk = a->K / BK;
         const long long wg_big = (long long)((a->N + 127) / 128) * ((a->M + 191) / 192);

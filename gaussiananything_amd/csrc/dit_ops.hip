@@ -478,6 +478,8 @@ struct Ws {
     float *xres, *tfreq, *t1, *pln, *pvec, *tvec, *t0, *mod, *rowss, *sbias;
     uint16_t *xn, *qkv, *att, *hmid, *vt;
     size_t vt_bytes;
+    void *splitk;          // scratch of the deterministic split-K of fc2 (GaGemmArgs.splitk_ws); nullptr above 3072 rows
+    size_t splitk_bytes;
     size_t total;
 };
 
@@ -500,6 +502,10 @@ static Ws carve(const GaDitModel *m, int B, int L, void *base)
     const size_t o_mod = take((size_t)m->depth * B * 6 * D * 4);
     const size_t o_rowss = take(M * (D / 64) * 4);   // per-row partial sums of squares of the residual stream (folded pre-norm)
     const size_t o_sbias = take((size_t)m->depth * B * 7 * D * 4);   // shift_b W^T + bias of the qkv and fc1 projections (folded modulated pre-norms)
+    // (round 6) split-K scratch of the MLP's second linear: counters + partial tiles; only where a 4-way split can fill the chip
+    w.splitk_bytes = M <= 3072 ? ga_gemm_splitk_workspace_bytes((int32_t)M, (int32_t)D) : 0;
+    const size_t o_sk = take(w.splitk_bytes);
+    w.splitk = w.splitk_bytes && base ? p + o_sk : nullptr;
     w.total = off;
     w.xres = reinterpret_cast<float *>(p + o_xres); w.xn = reinterpret_cast<uint16_t *>(p + o_xn);
     w.qkv = reinterpret_cast<uint16_t *>(p + o_qkv); w.att = reinterpret_cast<uint16_t *>(p + o_att);
@@ -625,6 +631,9 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     if (a->workspace_bytes < w.total || ((uintptr_t)a->workspace & 255)) return GA_DIT_ERR_BAD_SHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     (void)hipGetLastError();
+    // the tile counters of the split-K GEMMs are left zero by every launch; cleared once per evaluation all the same, so that a
+    // workspace needs no initialisation and an aborted launch cannot poison the next evaluation (a 16 KiB memset node)
+    if (w.splitk && hipMemsetAsync(w.splitk, 0, GA_GEMM_SPLITK_COUNTER_BYTES, s) != hipSuccess) return GA_DIT_ERR_LAUNCH;
 
     // ---- conditioning path: t = t_embedder(timesteps) + pooled_vec_embedder(img_vector); t0 = adaLN(SiLU(t))
     // (round 5: the sinusoidal features are formed inside the first linear -- one launch less -- and the pooled-vector branch, which
@@ -851,6 +860,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         g2.W = bw.fc2_w; g2.w_tiled = m->gemm_weights_tiled; g2.bias = bw.fc2_b; g2.out = w.xres; g2.ldo = D; g2.gate = mod + 5 * D;
         g2.gate_stride = 6 * (int64_t)D; g2.rows_per_batch = L;
         if (i + 1 < m->depth && can_fold(m, i + 1)) { g2.emit_x = w.xn; g2.emit_ld = D; g2.emit_ss = w.rowss; }
+        g2.splitk_ws = w.splitk; g2.splitk_ws_bytes = (int64_t)w.splitk_bytes;
         GA_UNLESS(8, ga_gemm_bf16(&g2, stream));
     }
     {

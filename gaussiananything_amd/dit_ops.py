@@ -20,7 +20,8 @@ class GaGemmArgs(ctypes.Structure):
                 ("vt", c_p), ("vt_col0", i32), ("vt_ld", i64), ("qk_w0", c_p), ("qk_w1", c_p), ("qk_cols0", i32),
                 ("qk_cols1", i32), ("emit_x", c_p), ("emit_ss", c_p), ("emit_ld", i64), ("row_ss", c_p),
                 ("row_ss_tiles", i32), ("row_ss_dim", i32), ("row_ss_eps", ctypes.c_float), ("w_tiled", i32),
-                ("emit_w", c_p), ("emit_scale", c_p), ("emit_scale_stride", i64), ("bias_stride", i64), ("k_rows", i32)]
+                ("emit_w", c_p), ("emit_scale", c_p), ("emit_scale_stride", i64), ("bias_stride", i64), ("k_rows", i32),
+                ("splitk_ws", c_p), ("splitk_ws_bytes", i64)]
 
 
 class GaAttentionArgs(ctypes.Structure):
@@ -89,7 +90,7 @@ class GaDitForwardArgs(ctypes.Structure):
 
 DIT_EXPORTS = ("ga_gemm_bf16", "ga_attention_bf16", "ga_attention_hd_bf16", "ga_head_rmsnorm_bf16", "ga_rmsnorm_modulate", "ga_small_linear", "ga_dit_workspace_bytes",
                "ga_dit_cache_context", "ga_dit_forward", "ga_dit_pooled_vector", "ga_dit_shift_bias", "ga_dit_sampler_advance", "ga_ode_dopri5_stage", "ga_ode_dopri5_finish",
-               "ga_dit_version")
+               "ga_dit_version", "ga_gemm_splitk_workspace_bytes", "ga_gemm_splitk_mode")
 _ERR = {-1: "GA_DIT_ERR_NULL_ARG", -2: "GA_DIT_ERR_BAD_SHAPE", -4: "GA_DIT_ERR_LAUNCH"}
 _bound = False
 
@@ -122,6 +123,10 @@ def lib():
         L.ga_ode_dopri5_stage.argtypes = [ctypes.POINTER(GaOdeDopri5), i32, c_p]
         L.ga_ode_dopri5_finish.restype = ctypes.c_int
         L.ga_ode_dopri5_finish.argtypes = [ctypes.POINTER(GaOdeDopri5), c_p]
+        L.ga_gemm_splitk_workspace_bytes.restype = ctypes.c_size_t
+        L.ga_gemm_splitk_workspace_bytes.argtypes = [i32, i32]
+        L.ga_gemm_splitk_mode.restype = ctypes.c_int
+        L.ga_gemm_splitk_mode.argtypes = [ctypes.c_int]
         _bound = True
     return L
 
@@ -147,13 +152,14 @@ def _need_cuda(*ts):
 
 def gemm(A, W, bias=None, epilogue=EPI_STORE_BF16, out=None, gate=None, rows_per_batch=1, vt=None, vt_col0=0,
          qk_w0=None, qk_cols0=0, qk_w1=None, qk_cols1=0, emit_x=None, emit_ss=None, row_ss=None, row_ss_dim=0,
-         row_ss_eps=1e-5, w_tiled=False, N=None, emit_w=None, emit_scale=None, k_rows=0):
+         row_ss_eps=1e-5, w_tiled=False, N=None, emit_w=None, emit_scale=None, k_rows=0, splitk_ws=None):
     """A [M,K] bf16, W [N,K] bf16 -> see ga_dit.h.  EPI_RESIDUAL accumulates into ``out`` (fp32 [M,N]).
     ``vt`` [B*heads*64, Lpad] bf16 (zero-initialised): columns >= vt_col0 are stored transposed there (V projection).
     ``qk_w0/qk_w1``: per-head RMSNorm weights for the column groups [0, qk_cols0) / [qk_cols0, qk_cols1).
     ``emit_*`` (EPI_RESIDUAL) / ``row_ss`` (EPI_STORE_BF16, EPI_GELU_BF16): the folded RMSNorm of ga_dit.h; ``emit_w`` [N] and
     ``emit_scale`` [B, N] fp32 make it the modulated one; a 2-d ``bias`` [B, N] is one bias row per batch item (``rows_per_batch``).
-    ``k_rows``: EPI_RESIDUAL rows >= k_rows get the epilogue with a zero product."""
+    ``k_rows``: EPI_RESIDUAL rows >= k_rows get the epilogue with a zero product.
+    ``splitk_ws``: uint8 scratch of ``splitk_workspace(M, N)`` (zero-initialised counters) = GaGemmArgs.splitk_ws."""
     _need_cuda(A, W, bias, out, gate, vt)
     assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and A.stride(-1) == 1 and W.is_contiguous()
     M, K = A.shape
@@ -168,9 +174,20 @@ def gemm(A, W, bias=None, epilogue=EPI_STORE_BF16, out=None, gate=None, rows_per
                    _ptr(emit_x), _ptr(emit_ss), emit_x.stride(0) if emit_x is not None else 0,
                    _ptr(row_ss), row_ss.shape[1] if row_ss is not None else 0, row_ss_dim, row_ss_eps, 1 if w_tiled else 0,
                    _ptr(emit_w), _ptr(emit_scale), emit_scale.stride(0) if emit_scale is not None else 0,
-                   bias.stride(0) if (bias is not None and bias.dim() == 2) else 0, k_rows)
+                   bias.stride(0) if (bias is not None and bias.dim() == 2) else 0, k_rows,
+                   _ptr(splitk_ws), splitk_ws.numel() if splitk_ws is not None else 0)
     check(lib().ga_gemm_bf16(ctypes.byref(a), _stream(A)), "ga_gemm_bf16")
     return out
+
+
+def splitk_workspace(M, N, device):
+    """zeroed scratch for the deterministic split-K of ``gemm`` (include/ga_dit.h: GaGemmArgs.splitk_ws)"""
+    return torch.zeros(int(lib().ga_gemm_splitk_workspace_bytes(M, N)), dtype=torch.uint8, device=device)
+
+
+def splitk_mode(mode):
+    """ga_gemm_splitk_mode: -1 by shape (default), 0 off, 1 / 2 / 3 force a configuration; returns the previous mode"""
+    return int(lib().ga_gemm_splitk_mode(int(mode)))
 
 
 def tile_weight(W):

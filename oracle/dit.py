@@ -17,7 +17,7 @@ reference-format ``state_dict`` (same keys as the reference classes produce).
 
 PARITY PINNED: tests/golden/dit_ref_*.pt hold inputs, state dicts and outputs produced by the REFERENCE'S OWN model code
 imported from /root/reference (tests/golden/make_dit_golden.py; third-party xformers/timm pieces replaced by the
-stand-ins documented in tests/golden/ref_dit_loader.py); tests/test_dit_oracle.py checks this file against them.
+stand-ins documented in tests/golden/ref_dit_loader.py); tests/test_cpu_oracle_and_host.py (test_dit_oracle_matches_reference_golden) checks this file against them.
 """
 from __future__ import annotations
 

@@ -148,6 +148,52 @@ def test_gemm_tiled_weight_image_gives_the_same_bits(gpu_device, M, N, K, epi):
                                                               else A.float() @ W.float().T + (0 if epi == "f32" else bias))) < 1e-2
 
 
+@pytest.mark.parametrize("mode,M,N,K", [(1, 1536, 1024, 4096), (2, 1536, 1024, 4096), (3, 768, 1024, 4096), (3, 1536, 768, 3072),
+                                        (1, 1488, 1024, 4096), (2, 100, 264, 1024), (-1, 1536, 1024, 4096), (-1, 768, 1024, 4096)])
+def test_gemm_deterministic_split_k(gpu_device, mode, M, N, K):
+    """GaGemmArgs.splitk_ws (round 6): 2 / 4 workgroups share the reduction of an output tile, the partial tiles are added in split
+    order by whichever arrives last.  Against the fp32 product at the per-op bar and against the unsplit kernel (another summation
+    order: close, not equal); BIT-identical from launch to launch whatever the arrival order (20 launches, a cold and a warm scratch);
+    the tile counters are left zero; with the gated residual, a per-batch emit (folded modulated pre-norm) and ragged edges."""
+    from gaussiananything_amd import dit_ops as ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K + mode)
+    A = torch.randn(M, K, generator=g).to(gpu_device).bfloat16()
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(gpu_device).bfloat16()
+    bias = torch.randn(N, generator=g).to(gpu_device)
+    rpb = M // 2 if M % 96 == 0 else M
+    gate = torch.randn(M // rpb, N, generator=g).to(gpu_device)
+    x0 = torch.randn(M, N, generator=g).to(gpu_device)
+    emit = N % 64 == 0
+    ew = torch.rand(N, generator=g).to(gpu_device) + 0.5 if emit else None
+    es = (torch.randn(M // rpb, N, generator=g) * 0.1).to(gpu_device) if emit else None
+
+    def run(ws):
+        x = x0.clone()
+        ex = torch.empty(M, N, device=gpu_device, dtype=torch.bfloat16) if emit else None
+        ss = torch.empty(M, N // 64, device=gpu_device) if emit else None
+        ops.gemm(A, W, bias, ops.EPI_RESIDUAL, out=x, gate=gate, rows_per_batch=rpb, emit_x=ex, emit_ss=ss, emit_w=ew, emit_scale=es, splitk_ws=ws)
+        return x, ex, ss
+    ref = x0.double() + gate.double().repeat_interleave(rpb, 0) * (A.double() @ W.double().T + bias.double())
+    base = run(None)
+    prev = ops.splitk_mode(mode)
+    try:
+        ws = ops.splitk_workspace(M, N, gpu_device)
+        first = run(ws)
+        for _ in range(20):
+            again = run(ws)
+            assert all(torch.equal(a, b) for a, b in zip(first, again) if a is not None)
+        assert int(ws[:16384].view(torch.int32).abs().max()) == 0          # counters left clean
+        if mode > 0:   # the forced configuration really is another kernel: another summation order somewhere
+            assert not torch.equal(first[0], base[0])
+    finally:
+        ops.splitk_mode(prev)
+    assert rel_l2(first[0], ref) < 1e-2 and rel_l2(first[0], base[0].double()) < 1e-5
+    if emit:
+        assert rel_l2(first[1].float(), base[1].float()) < 5e-3 and rel_l2(first[2], base[2]) < 1e-5
+        want = (ref * (ew.double() * (1 + es.double().repeat_interleave(rpb, 0)))).float()
+        assert rel_l2(first[1].float(), want) < 1e-2
+
+
 # norm: "qk" = q and k RMS-normalised in the kernel (register-staged variant), "q" = only q (k arrives normalised from the
 # projection GEMM, as in the DiT forward), "" = neither: the last two run the LDS-DMA variants -- 128-query workgroups when
 # they fill half the chip, else 64-query workgroups with two key groups (ragged last tiles, 1-tile and 1-key inputs included)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Exactly the kernels the bench line quotes, each alone, for counter passes (tools/pmc_r3.sh):
+"""Exactly the kernels the bench line quotes, each alone, for counter passes (tools/collect_r5.sh):
   attn : the two attention launches of a DiT-L evaluation (self 2x16x768x768, cross 1x16x768x1369), 20 launches each
   gemm : the GEMM launches of a DiT-L block at M = 1536 (qkv, fc1, fc2, proj) and M = 768 (cross-attention q), 20 each,
          weights rotated through 40 copies (cold, as in an evaluation)
