@@ -225,9 +225,14 @@ class SurfelDecoder(nn.Module):
             import random
             keys = [random.choice(keys[:-1])] + [keys[-1]]
         out = {}
-        for key in keys:
-            res = self.gs.render(ret_after_gaussian_forward[key], c["cam_view"], c["cam_view_proj"], c["cam_pos"],
-                                 tanfov=c["tanfov"], bg_color=bg_color, output_size=self.output_size[key])
+        sets = [ret_after_gaussian_forward[key] for key in keys]
+        if torch.is_grad_enabled() and any(g.requires_grad for g in sets):
+            rendered = [self.gs.render(g, c["cam_view"], c["cam_view_proj"], c["cam_pos"], tanfov=c["tanfov"], bg_color=bg_color,
+                                       output_size=self.output_size[key]) for g, key in zip(sets, keys)]
+        else:   # the levels are independent surfel sets: overlapped on two streams, one overflow read-back for all of them
+            rendered = self.gs.render_levels(sets, [self.output_size[key] for key in keys], c["cam_view"], c["cam_view_proj"],
+                                             c["cam_pos"], c["tanfov"], bg_color=bg_color)
+        for key, res in zip(keys, rendered):
             res["image_raw"] = res["image"] * 2 - 1  # [0,1] -> [-1,1]
             res["image_depth"] = res["depth"]
             res["image_mask"] = res["alpha"]

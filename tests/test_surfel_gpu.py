@@ -442,6 +442,37 @@ def test_renderer_2dgs_dict(gpu_device):
         assert float(np.mean((out["dist"][0, v, 0].cpu().numpy() - o["allmap"][6]) ** 2)) <= MSE_TOL
 
 
+def test_render_levels_overlapped_on_two_streams_equals_one_render_per_set(gpu_device):
+    """GaussianRenderer2DGS.render_levels (the four levels of triplane_decode, vit/vit_triplane.py:1550-1591): independent surfel
+    sets on two side streams with ONE overflow read-back -- every tensor bit-identical to render() set by set; a set whose
+    workspace overflows (splats much larger than the default capacity expects) is rendered again the ordinary way; repeated
+    calls (workspaces now 'clean') and two sets of one shape (one shared workspace, one stream) included."""
+    from gaussiananything_amd import diff_surfel_rasterization as dsr
+    from gaussiananything_amd.gs_surfel import GaussianRenderer2DGS
+    cams = synthetic.eval_cameras(6)
+    cv, cvp, cp = (cams[k][None].to(gpu_device) for k in ("cam_view", "cam_view_proj", "cam_pos"))
+    big = synthetic.random_surfels(2500, seed=9)
+    big[0, :, 4:6] *= 12.0                                   # hundreds of tiles per splat: far beyond 2 N V entries
+    sets = [synthetic.random_surfels(700, seed=5), synthetic.surface_surfels(9000, seed=6), big, synthetic.random_surfels(700, seed=7),
+            synthetic.surface_surfels(30000, seed=8)]
+    sets = [g.to(gpu_device) for g in sets]
+    sizes = [64, 128, 96, 64, 256]
+    r = GaussianRenderer2DGS(512, 3, {})
+    dsr._ws_cache.clear()
+    for rep in range(3):
+        if rep == 1:
+            dsr._ws_cache.clear()                            # the overflow is found again on fresh workspaces
+        got = r.render_levels(sets, sizes, cv, cvp, cp, cams["tanfov"])
+        torch.cuda.synchronize()
+        for g, S, res in zip(sets, sizes, got):
+            want = r.render(g, cv, cvp, cp, cams["tanfov"], output_size=S)
+            assert set(res) == set(want)
+            for k in want:
+                assert res[k].shape == want[k].shape and torch.equal(res[k], want[k]), (rep, S, k)
+    key = (str(gpu_device), 2500, 6, 96, 96)
+    assert key in dsr._ws_cache and dsr._ws_cache[key].capacity > dsr.default_capacity(2500, 6)     # it did overflow and grow
+
+
 def test_postprocess_kernel_exact(gpu_device):
     """ga_surfel_postprocess against the torch formulation of nsr/gs_surfel.py:121-163, NaN / inf / out-of-range included,
     image sizes with and without the 16-byte path; batch of two through the renderer."""

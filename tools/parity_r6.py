@@ -181,6 +181,19 @@ def cascade(points):
     print(f"raster on the oracle's surfels: D oracle {o_D}, HIP {s_D} ({'bins agree in size' if s_D == o_D else 'DIFFERENT'})")
     show_pixels("raster on the oracle's surfels, HIP vs oracle:", s_img, o_img)
     show_pixels("raster of the HIP decode of the ORACLE's latent (decode + raster only) vs oracle:", hip_render(s_surf)[0], o_img)
+    # ---------------- the same question from the other side: the ORACLE's stages on the HIP cascade's inputs -----------------------
+    # (if the free-running divergence is the models' sensitivity to their inputs and not an error of a HIP stage, every HIP stage
+    #  must agree with the oracle stage evaluated on the SAME input)
+    t5 = time.perf_counter()
+    c_lat = oracle_stage2(h_fps.cpu())
+    c_surf = odec.decode(sdd, h_lat.cpu(), h_fps.cpu())["gaussians_upsampled_3"]
+    c_img, c_D = oracle_render(h_surf.cpu())
+    print(f"\n== ON THE HIP CASCADE'S OWN INTERMEDIATES (oracle stage on the HIP stage's input; {time.perf_counter() - t5:.0f} s) ==")
+    print(f"stage 2: oracle(HIP fps_xyz) vs HIP latent            rel_l2 {rel(h_lat.cpu().numpy(), c_lat.numpy()):.3e}"
+          f"      [oracle(HIP fps_xyz) vs oracle(oracle fps_xyz): {rel(c_lat.numpy(), o_lat.numpy()):.3e} = the fp32 MODEL's own response to the 1e-2 hand-off difference]")
+    show_surfels("decode: oracle(HIP latent, HIP fps_xyz) vs HIP surfels  rel_l2", h_surf, c_surf)
+    print(f"raster: oracle(HIP surfels) vs HIP renders: D oracle {c_D}, HIP {h_D}")
+    show_pixels("raster: oracle(HIP surfels) vs HIP renders:", h_img, c_img)
 
 
 if __name__ == "__main__":
