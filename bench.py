@@ -883,7 +883,7 @@ def main():
                                  "peak_fp32_valu_tflops": FP32_VALU_PEAK_TFLOPS,
                                  "note": "lanes = pixels of an 8x8 quadrant cannot exceed 0.53 lane use on this scene (tools/blend_sim.py); the "
                                          "split walk (lanes = pairs, then lanes = pixels) was built and measured in round 4: 175 us against "
-                                         "140 us (DESIGN.md section 3, GA_SURFEL_FLAG_SPLIT_WALK)"}
+                                         "140 us (DESIGN_HISTORY.md section 3, GA_SURFEL_FLAG_SPLIT_WALK)"}
             del splan
             out["stage_ms"] = {k: round(x, 5) for k, x in stage.items()}
             out["stage_ms"]["device_total"] = round(total_dev, 5)
@@ -891,7 +891,7 @@ def main():
                 out["stress_scene"] = stress_scene_line(cams, a.points, H, W, dev)
                 # untimed, beside the headline (which stays ONE forward at a time on one stream): two INDEPENDENT surfel sets rendered
                 # concurrently on two streams -- the latency-bound front-end of one hides under the issue-bound blend of the other
-                # (tools/overlap_probe.py)
+                # (tools/overlap_probe.py, DESIGN_HISTORY.md section 3)
                 g2 = synthetic.surface_surfels(a.points, seed=101 + rank)[0]
                 m2, o2, s2_, r2, c2 = [t.to(dev) for t in synthetic.split_gaussians(g2)]
                 plan2 = SurfelForwardPlan(m2, o2, c2, s2_, r2, cams["cam_view"].to(dev), cams["cam_view_proj"].to(dev), torch.ones(3, device=dev), H, W)
