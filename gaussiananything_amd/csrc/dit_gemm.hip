@@ -925,7 +925,7 @@ static std::atomic<int> &splitk_mode()
 
 extern "C" int ga_gemm_splitk_mode(int mode)
 {
-    return gadit::splitk_mode().exchange(mode < -1 || mode > 3 ? -1 : mode);
+    return gadit::splitk_mode().exchange(mode < -1 || mode > 5 ? -1 : mode);
 }
 
 extern "C" size_t ga_gemm_splitk_workspace_bytes(int32_t M, int32_t N)
@@ -986,40 +986,55 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
     // linear: K = 4 D).  At M <= 1536 rows the chip is only filled by 96 x 64 / 64 x 64 tiles, which pull 1.3 MB of operands through
     // every CU's L1 miss path (the bound of these kernels); 192 x 128 tiles over a quarter of K each halve
     // that, the partial tiles cost a quarter of what they save.  GA_GEMM_SPLITK (read once): 0 off, 1 / 2 / 3 force a configuration.
-    if (a->splitk_ws && a->epilogue == GA_GEMM_EPI_RESIDUAL && p.k_rows == 0) {
+    if (a->splitk_ws && p.k_rows == 0 && a->epilogue != GA_GEMM_EPI_STORE_F32) {
         const int sk_env = splitk_mode().load(std::memory_order_relaxed);
         const int nk = a->K / BK;
         const bool per_batch = a->bias_stride != 0 || a->emit_scale != nullptr;
         const bool rows48 = !per_batch || a->rows_per_batch % 48 == 0;
+        const bool res = a->epilogue == GA_GEMM_EPI_RESIDUAL;
         const long long t192 = (long long)((a->N + 127) / 128) * ((a->M + 191) / 192), t96 = (long long)((a->N + 127) / 128) * ((a->M + 95) / 96);
-        int cfg = 0;   // 1: 192 x 128 x 4 splits (8 waves), 2: 96 x 128 x 2 splits, 3: 96 x 128 x 4 splits (4 waves)
+        // 1: 192 x 128 x 4 splits (8 waves) | 2: 96 x 128 x 2 (4 waves) | 3: 96 x 128 x 4 | 4: 192 x 128 x 2.  The bf16-store epilogues
+        // (qkv with its head norm / V^T, fc1 with GELU) only exist for configuration 4 -- what their shapes need at 768 rows.
         const bool ok4 = nk % 16 == 0 && nk >= 32, ok2 = nk % 8 == 0 && nk >= 16;
-        if (rows48 && ok4 && t192 * 4 >= 160 && t192 * 4 <= 256) cfg = 1;
-        else if (rows48 && ok4 && t96 * 4 >= 160 && t96 * 4 <= 256) cfg = 3;
+        auto fills = [](long long wgs) { return wgs >= 160 && wgs <= 256; };
+        int cfg = 0;
+        if (rows48 && t192 < 160) {          // (a 192 x 128 grid that fills the chip on its own needs no split)
+            if (ok2 && fills(t192 * 2)) cfg = 4;
+            else if (res && ok4 && fills(t192 * 4)) cfg = 1;
+            else if (res && ok4 && fills(t96 * 4)) cfg = 3;
+            else if (res && ok2 && fills(t96 * 2)) cfg = 2;
+        }
         if (sk_env == 0) cfg = 0;
-        else if (sk_env == 1 && rows48 && ok4) cfg = 1;
-        else if (sk_env == 2 && rows48 && ok2) cfg = 2;
-        else if (sk_env == 3 && rows48 && ok4) cfg = 3;
-        const long long tiles = cfg == 1 ? t192 : t96;
-        const int splits = cfg == 2 ? 2 : 4;
-        const size_t tile_bytes = (size_t)(cfg == 1 ? 192 : 96) * 128 * 4;
+        else if (sk_env == 1) cfg = res && rows48 && ok4 ? 1 : 0;
+        else if (sk_env == 2) cfg = res && rows48 && ok2 ? 2 : 0;
+        else if (sk_env == 3) cfg = res && rows48 && ok4 ? 3 : 0;
+        else if (sk_env == 4) cfg = rows48 && ok2 ? 4 : 0;
+        else if (sk_env == 5) cfg = res ? cfg : 0;          // by shape, residual GEMMs only (A/B aid)
+        const bool big = cfg == 1 || cfg == 4;
+        const long long tiles = big ? t192 : t96;
+        const int splits = (cfg == 2 || cfg == 4) ? 2 : 4;
+        const size_t tile_bytes = (size_t)(big ? 192 : 96) * 128 * 4;
         if (cfg && tiles <= GA_GEMM_SPLITK_MAX_TILES &&
             (size_t)a->splitk_ws_bytes >= GA_GEMM_SPLITK_COUNTER_BYTES + (size_t)tiles * splits * tile_bytes && ((uintptr_t)a->splitk_ws & 255) == 0) {
             GemmP q = p;
             q.splits = splits;
             q.sk_count = static_cast<unsigned *>(a->splitk_ws);
             q.sk_part = reinterpret_cast<float *>(static_cast<char *>(a->splitk_ws) + GA_GEMM_SPLITK_COUNTER_BYTES);
-            // (the attribute is per device; setting it is cheap and idempotent)
-            if (cfg == 1) {
-                if (hipFuncSetAttribute((const void *)gemm_ring_kernel<2, 4, 2, 3, 4, 4, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 320 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH;
-                hipLaunchKernelGGL((gemm_ring_kernel<2, 4, 2, 3, 4, 4, 2, 4>), dim3((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 191) / 192), 4), dim3(512), 4 * 320 * BK * 2, s, q);
-            } else if (cfg == 2) {
-                if (hipFuncSetAttribute((const void *)gemm_ring_kernel<2, 2, 2, 3, 4, 4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 224 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH;
-                hipLaunchKernelGGL((gemm_ring_kernel<2, 2, 2, 3, 4, 4, 2, 2>), dim3((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 95) / 96), 2), dim3(256), 4 * 224 * BK * 2, s, q);
-            } else {
-                if (hipFuncSetAttribute((const void *)gemm_ring_kernel<2, 2, 2, 3, 4, 4, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 224 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH;
-                hipLaunchKernelGGL((gemm_ring_kernel<2, 2, 2, 3, 4, 4, 2, 4>), dim3((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 95) / 96), 4), dim3(256), 4 * 224 * BK * 2, s, q);
-            }
+            const dim3 gbig((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 191) / 192), (unsigned)splits);
+            const dim3 gmid((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 95) / 96), (unsigned)splits);
+            // (the LDS opt-in belongs to the function on one device; setting it is cheap and idempotent)
+#define GA_SK_LAUNCH(KERNEL, GRID, THREADS, LDS)                                                                                   \
+            do {                                                                                                                  \
+                if (hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
+                hipLaunchKernelGGL(KERNEL, GRID, dim3(THREADS), LDS, s, q);                                                       \
+            } while (0)
+            if (cfg == 1) GA_SK_LAUNCH((gemm_ring_kernel<2, 4, 2, 3, 4, 4, 2, 4>), gbig, 512, 4 * 320 * BK * 2);
+            else if (cfg == 2) GA_SK_LAUNCH((gemm_ring_kernel<2, 2, 2, 3, 4, 4, 2, 2>), gmid, 256, 4 * 224 * BK * 2);
+            else if (cfg == 3) GA_SK_LAUNCH((gemm_ring_kernel<2, 2, 2, 3, 4, 4, 2, 4>), gmid, 256, 4 * 224 * BK * 2);
+            else if (a->epilogue == GA_GEMM_EPI_RESIDUAL) GA_SK_LAUNCH((gemm_ring_kernel<2, 4, 2, 3, 4, 4, 2, 2>), gbig, 512, 4 * 320 * BK * 2);
+            else if (a->epilogue == GA_GEMM_EPI_STORE_BF16) GA_SK_LAUNCH((gemm_ring_kernel<0, 4, 2, 3, 4, 4, 2, 2>), gbig, 512, 4 * 320 * BK * 2);
+            else GA_SK_LAUNCH((gemm_ring_kernel<1, 4, 2, 3, 4, 4, 2, 2>), gbig, 512, 4 * 320 * BK * 2);
+#undef GA_SK_LAUNCH
             return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
         }
     }

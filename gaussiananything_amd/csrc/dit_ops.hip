@@ -12,6 +12,8 @@
 // All are one-wave-per-row with 16-byte accesses where the layout allows.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "dit_common.h"
 
 namespace gadit {
@@ -503,7 +505,9 @@ static Ws carve(const GaDitModel *m, int B, int L, void *base)
     const size_t o_rowss = take(M * (D / 64) * 4);   // per-row partial sums of squares of the residual stream (folded pre-norm)
     const size_t o_sbias = take((size_t)m->depth * B * 7 * D * 4);   // shift_b W^T + bias of the qkv and fc1 projections (folded modulated pre-norms)
     // (round 6) split-K scratch of the MLP's second linear: counters + partial tiles; only where a 4-way split can fill the chip
-    w.splitk_bytes = M <= 3072 ? ga_gemm_splitk_workspace_bytes((int32_t)M, (int32_t)D) : 0;
+    // (fc2: up to 4 splits of [M, D]; qkv / fc1 at 768 rows: 2 splits of [M, 4 D] -- half of the 4-split bound)
+    w.splitk_bytes = M <= 3072 ? std::max(ga_gemm_splitk_workspace_bytes((int32_t)M, (int32_t)D),
+                                          GA_GEMM_SPLITK_COUNTER_BYTES + (ga_gemm_splitk_workspace_bytes((int32_t)M, (int32_t)(4 * D)) - GA_GEMM_SPLITK_COUNTER_BYTES) / 2) : 0;
     const size_t o_sk = take(w.splitk_bytes);
     w.splitk = w.splitk_bytes && base ? p + o_sk : nullptr;
     w.total = off;
@@ -826,6 +830,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
             gqkv.row_ss = w.rowss; gqkv.row_ss_tiles = D / 64; gqkv.row_ss_dim = D; gqkv.row_ss_eps = 1e-5f;
             gqkv.bias = sbias; gqkv.bias_stride = 3 * (int64_t)D;
         }
+        gqkv.splitk_ws = w.splitk; gqkv.splitk_ws_bytes = (int64_t)w.splitk_bytes;
         GA_UNLESS(16, ga_gemm_bf16(&gqkv, stream));
         GaAttentionArgs sa{B, m->heads, L, L, w.qkv, w.qkv + D, w.vt, 2 * D, 2 * D, Lp, nullptr, nullptr, w.att, D};
         if (fold_mod && sb_tail && i + 1 < m->depth) {
@@ -854,6 +859,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
             g1.row_ss = w.rowss; g1.row_ss_tiles = D / 64; g1.row_ss_dim = D; g1.row_ss_eps = 1e-5f;
             g1.bias = sbias + (size_t)B * 3 * D; g1.bias_stride = 4 * (int64_t)D; g1.rows_per_batch = L;
         }
+        g1.splitk_ws = w.splitk; g1.splitk_ws_bytes = (int64_t)w.splitk_bytes;
         GA_UNLESS(8, ga_gemm_bf16(&g1, stream));
         GaGemmArgs g2{};
         g2.M = Mrows; g2.N = D; g2.K = 4 * D; g2.epilogue = GA_GEMM_EPI_RESIDUAL; g2.A = w.hmid; g2.lda = 4 * D;

@@ -98,8 +98,8 @@ typedef struct GaGemmArgs {
     int64_t emit_scale_stride;
     int64_t bias_stride;
     int32_t k_rows;
-    /* Round 6: optional scratch for a DETERMINISTIC split-K (EPI 2 without k_rows, long reductions with a small output: FusedMLP's
-     * second linear at M <= 1536 rows).  2 or 4 workgroups share the reduction of one 192 x 128 / 96 x 128 output tile; the partial
+    /* Round 6: optional scratch for a DETERMINISTIC split-K (EPI 0 / 1 / 2 without k_rows: reductions whose output tiles cannot fill the
+     * chip -- FusedMLP's second linear up to 3072 rows, every wide projection at 768).  2 or 4 workgroups share the reduction of one 192 x 128 / 96 x 128 output tile; the partial
      * tiles meet in the scratch and are added in split order by whichever workgroup arrives last -- results do not depend on the
      * arrival order (bit-reproducible), nobody waits for anybody.  Layout: GA_GEMM_SPLITK_COUNTER_BYTES of tile counters, which must
      * be ZERO before the call and are left zero by it, then the partial tiles.  ga_gemm_splitk_workspace_bytes(M, N) bytes always
@@ -113,8 +113,9 @@ typedef struct GaGemmArgs {
 #define GA_GEMM_SPLITK_MAX_TILES (GA_GEMM_SPLITK_COUNTER_BYTES / 4)
 size_t ga_gemm_splitk_workspace_bytes(int32_t M, int32_t N);
 /* tuning / test hook: which split-K configuration calls with a scratch take.  -1 (default; or the value of the environment variable
- * GA_GEMM_SPLITK at first use): chosen by shape; 0: none; 1: 192 x 128 tiles x 4 splits; 2: 96 x 128 x 2; 3: 96 x 128 x 4 (a forced
- * configuration still needs K / 64 divisible by 4 x splits and >= 8 x splits).  Returns the previous mode.  Process-wide. */
+ * GA_GEMM_SPLITK at first use): chosen by shape; 0: none; 1: 192 x 128 tiles x 4 splits; 2: 96 x 128 x 2; 3: 96 x 128 x 4; 4: 192 x 128
+ * x 2 (the only one the bf16-store epilogues have); 5: by shape for EPI 2 only (a forced configuration still needs K / 64 divisible
+ * by 4 x splits and >= 8 x splits).  Returns the previous mode.  Process-wide. */
 int ga_gemm_splitk_mode(int mode);
 
 int ga_gemm_bf16(const GaGemmArgs *args, void *stream);

@@ -662,9 +662,14 @@ def test_committed_bench_line_follows_the_contract():
     # round 5: the absolute pixel bars and the full-depth trajectory on `parity`; the compact summary is the LAST key of the line
     p = d["parity"]
     assert p["pass"] is True and p["bins_bit_identical"] is True and p["max_abs"] <= 0.25 and p["pixels_beyond_1e-4_fraction"] <= 3e-4
-    assert 0 < p["trajectory_rel_l2"] < 3e-2 and p["trajectory"]["pass"] is True
+    # round 6: the CPU trajectory oracle left the default run (it doubled the driver's run time); the line quotes the committed
+    # full-length run instead, or carries the 25-point measurement when --trajectory-parity was given
+    if "trajectory" in p:
+        assert 0 < p["trajectory_rel_l2"] < 3e-2 and p["trajectory"]["pass"] is True
+    elif "trajectory_250_points" in p:
+        assert 0 < p["trajectory_250_points"]["end_state_rel_l2"] < 3e-2 and os.path.exists(os.path.join(ROOT, "profiles", "r6_traj250.txt"))
     assert list(d)[-1] == "summary" and len(json.dumps(d["summary"])) <= 1500
-    assert d["summary"]["sec_per_sample"] == d["sec_per_sample"] and d["summary"]["parity"]["traj_rel_l2"] == p["trajectory_rel_l2"]
+    assert d["summary"]["sec_per_sample"] == d["sec_per_sample"] and d["summary"]["parity"]["traj_rel_l2"] == p.get("trajectory_rel_l2")
 
 
 def test_dopri5_refuses_non_finite_models_and_step_underflow():

@@ -194,6 +194,48 @@ def test_gemm_deterministic_split_k(gpu_device, mode, M, N, K):
         assert rel_l2(first[1].float(), want) < 1e-2
 
 
+@pytest.mark.parametrize("epi,M,N,K,mode", [("qkv", 768, 3072, 1024, -1), ("gelu", 768, 4096, 1024, -1), ("qkv", 1536, 3072, 1024, 4), ("gelu", 400, 520, 1024, 4),
+                                            ("res", 3072, 1024, 4096, -1), ("res", 1536, 1024, 4096, 4)])
+def test_gemm_split_k_of_two_on_the_wide_tiles(gpu_device, epi, M, N, K, mode):
+    """192 x 128 tiles x 2 splits (configuration 4): the only split the bf16-store epilogues have -- qkv with the per-head q/k RMSNorm,
+    the V^T store and a folded row scale + per-batch bias, fc1 with GELU -- chosen by shape at 768 rows (and for fc2 at 3072).  Close to
+    the unsplit kernels (another summation order), launch-to-launch bit-identical, counters left zero."""
+    from gaussiananything_amd import dit_ops as ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(gpu_device).bfloat16()
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(gpu_device).bfloat16()
+    L = 768 if M % 768 == 0 else M
+    bias = torch.randn(M // L, N, generator=g).to(gpu_device)                # one bias row per batch item (folded shift)
+    rss = (torch.rand(M, K // 64, generator=g) * 64).to(gpu_device)          # row sums of squares per 64-column group
+
+    def run(ws):
+        if epi == "qkv":
+            H = N // 192
+            vt = torch.zeros((M // L) * H * 64, (L + 63) // 64 * 64, device=gpu_device, dtype=torch.bfloat16)
+            qw, kw = torch.rand(64, generator=torch.Generator().manual_seed(1)).to(gpu_device) + 0.5, torch.rand(64, generator=torch.Generator().manual_seed(2)).to(gpu_device) + 0.5
+            out = ops.gemm(A, W, bias, ops.EPI_STORE_BF16, rows_per_batch=L, vt=vt, vt_col0=2 * H * 64, qk_w0=qw, qk_cols0=H * 64, qk_w1=kw,
+                           qk_cols1=2 * H * 64, row_ss=rss, row_ss_dim=K, splitk_ws=ws)
+            return out, vt
+        if epi == "gelu":
+            return (ops.gemm(A, W, bias, ops.EPI_GELU_BF16, rows_per_batch=L, row_ss=rss, row_ss_dim=K, splitk_ws=ws),)
+        x = torch.ones(M, N, device=gpu_device)
+        ops.gemm(A, W, bias[0].contiguous(), ops.EPI_RESIDUAL, out=x, rows_per_batch=L, splitk_ws=ws)
+        return (x,)
+    base = run(None)
+    prev = ops.splitk_mode(mode)
+    try:
+        ws = ops.splitk_workspace(M, N, gpu_device)
+        first = run(ws)
+        for _ in range(10):
+            assert all(torch.equal(a, b) for a, b in zip(first, run(ws)))
+        assert int(ws[:16384].view(torch.int32).abs().max()) == 0
+    finally:
+        ops.splitk_mode(prev)
+    assert any(not torch.equal(a, b) for a, b in zip(first, base))             # the split kernel did run
+    for a, b in zip(first, base):
+        assert rel_l2(a.float(), b.float()) < 4e-3, rel_l2(a.float(), b.float())
+
+
 # norm: "qk" = q and k RMS-normalised in the kernel (register-staged variant), "q" = only q (k arrives normalised from the
 # projection GEMM, as in the DiT forward), "" = neither: the last two run the LDS-DMA variants -- 128-query workgroups when
 # they fill half the chip, else 64-query workgroups with two key groups (ragged last tiles, 1-tile and 1-key inputs included)
