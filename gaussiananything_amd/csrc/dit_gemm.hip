@@ -796,13 +796,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
         const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x;
         constexpr size_t FRAG = 64 * 16, WAVE_BYTES = (size_t)FN * FM * FRAG, WG_BYTES = (size_t)NW * WAVE_BYTES;
         char *tile_base = reinterpret_cast<char *>(p.sk_part) + (size_t)tile * SK * WG_BYTES + (size_t)wave * WAVE_BYTES + (size_t)lane * 16;
+        // 8-byte agent-scope atomics (global_store / global_load_dwordx2 sc1): COMPILER-VISIBLE memory operations -- the first version
+        // used 16-byte inline-asm loads with hand-counted vmcnt and was not launch-to-launch reproducible on the 252-register
+        // instantiation (the register allocator may copy an asm output before the wait the compiler knows nothing about)
+        auto put = [&](char *dst, const f32x4 &v) __attribute__((always_inline)) {
+            unsigned long long *d = reinterpret_cast<unsigned long long *>(dst);
+            __hip_atomic_store(d, ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d + 1, ((unsigned long long)__float_as_uint(v[3]) << 32) | __float_as_uint(v[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto get = [&](const char *src_) __attribute__((always_inline)) {
+            const unsigned long long *q = reinterpret_cast<const unsigned long long *>(src_);
+            const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return f32x4{__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)), __uint_as_float((uint32_t)hi), __uint_as_float((uint32_t)(hi >> 32))};
+        };
         {
             char *mine = tile_base + (size_t)split * WG_BYTES;
 #pragma unroll
             for (int i = 0; i < FN; ++i)
 #pragma unroll
-                for (int j = 0; j < FM; ++j)
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(mine + (size_t)(i * FM + j) * FRAG), "v"(acc[i][j]) : "memory");
+                for (int j = 0; j < FM; ++j) put(mine + (size_t)(i * FM + j) * FRAG, acc[i][j]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my part of the partial tile has been written ...
         __syncthreads();                                      // ... and everybody's; the ring is idle: its first word carries the rank
@@ -813,69 +826,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
         if (rank != (unsigned)(SK - 1)) return;               // workgroup-uniform
         __syncthreads();                                      // (the epilogues of the 32-column waves reuse the ring's first words)
         if (tid == 0) __hip_atomic_store(p.sk_count + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left clean for the next launch
-        // last arriver: the other partials in split order, two of them in flight at a time
-        auto fetch = [&](int s_, f32x4(&dst)[FN][FM]) __attribute__((always_inline)) {
-            const char *src_ = tile_base + (size_t)s_ * WG_BYTES;
-#pragma unroll
-            for (int i = 0; i < FN; ++i)
-#pragma unroll
-                for (int j = 0; j < FM; ++j)
-                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst[i][j]) : "v"(src_ + (size_t)(i * FM + j) * FRAG) : "memory");
-        };
-        auto landed = [&](auto newerc, f32x4(&v)[FN][FM]) __attribute__((always_inline)) {   // all loads but the newest `newer` fragments
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(newerc)::value) : "memory");
-#pragma unroll
-            for (int i = 0; i < FN; ++i)
-#pragma unroll
-                for (int j = 0; j < FM; ++j) asm volatile("" : "+v"(v[i][j]));
-        };
-        auto add_to = [&](f32x4(&sum)[FN][FM], const f32x4(&t)[FN][FM]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < FN; ++i)
-#pragma unroll
-                for (int j = 0; j < FM; ++j) sum[i][j] += t[i][j];
-        };
-        constexpr int NF = FN * FM;
+        // last arriver: the partials in split order, its own from registers (the very bits it stored)
         static_for<0, SK>([&](auto myc) __attribute__((always_inline)) {
             constexpr int MY = decltype(myc)::value;
             if (split != MY) return;
-            // the others, in split order: o[0 .. SK-2]
-            f32x4 buf[2][FN][FM], sum[FN][FM];
-            constexpr int first_other = MY == 0 ? 1 : 0;
-            fetch(first_other, buf[0]);
-            if constexpr (SK > 2) fetch(first_other + 1 + (first_other + 1 == MY ? 1 : 0), buf[1]);
-            // walk s = 0 .. SK-1; `slot` = which buffer holds the next other partial, `next_other` = the next one to request
-            int dummy = 0; (void)dummy;
+            f32x4 sum[FN][FM];
             static_for<0, SK>([&](auto sc) __attribute__((always_inline)) {
                 constexpr int S_ = decltype(sc)::value;
-                constexpr int others_before = S_ - (S_ > MY ? 1 : 0);           // other partials consumed before step S_
-                if constexpr (S_ == MY) {
-                    if constexpr (S_ == 0) {
+                const char *src_ = tile_base + (size_t)S_ * WG_BYTES;
 #pragma unroll
-                        for (int i = 0; i < FN; ++i)
+                for (int i = 0; i < FN; ++i)
 #pragma unroll
-                            for (int j = 0; j < FM; ++j) sum[i][j] = acc[i][j];
-                    } else add_to(sum, acc);
-                } else {
-                    constexpr int slot = others_before & 1;
-                    constexpr int requested = (SK - 1) < 2 ? (SK - 1) : 2;      // in flight after the prologue
-                    // loads still allowed in flight when this one must have landed: the one requested after it, if any
-                    constexpr int total_requested_by_now = others_before + requested > SK - 1 ? SK - 1 : others_before + requested;
-                    constexpr int newer = (total_requested_by_now - others_before - 1) * NF;
-                    landed(std::integral_constant<int, newer>{}, buf[slot]);
-                    if constexpr (S_ == 0) {
-#pragma unroll
-                        for (int i = 0; i < FN; ++i)
-#pragma unroll
-                            for (int j = 0; j < FM; ++j) sum[i][j] = buf[slot][i][j];
-                    } else add_to(sum, buf[slot]);
-                    // request the other partial two ahead into the buffer just consumed
-                    constexpr int nxt_idx = others_before + 2;                  // index among the others
-                    if constexpr (nxt_idx < SK - 1) {
-                        constexpr int nxt_split = nxt_idx + (nxt_idx >= MY ? 1 : 0);
-                        fetch(nxt_split, buf[slot]);
+                    for (int j = 0; j < FM; ++j) {
+                        const f32x4 t = S_ == MY ? acc[i][j] : get(src_ + (size_t)(i * FM + j) * FRAG);
+                        if constexpr (S_ == 0) sum[i][j] = t;
+                        else sum[i][j] += t;
                     }
-                }
             });
 #pragma unroll
             for (int i = 0; i < FN; ++i)
@@ -925,7 +891,7 @@ static std::atomic<int> &splitk_mode()
 
 extern "C" int ga_gemm_splitk_mode(int mode)
 {
-    return gadit::splitk_mode().exchange(mode < -1 || mode > 5 ? -1 : mode);
+    return gadit::splitk_mode().exchange(mode < -1 || mode > 6 ? -1 : mode);
 }
 
 extern "C" size_t ga_gemm_splitk_workspace_bytes(int32_t M, int32_t N)
@@ -982,10 +948,9 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
     // (fc1, qkv, everything at M >= 6144), else 96 x 64 (proj, fc2: 256 workgroups at M = 1536), else 64 x 64 (the M = 768
     // cross-attention projections).  The 96 x 64 tile has 32-column waves: for the per-head q/k norm its two waves exchange
     // their halves of the row sums of squares through LDS.
-    // Round 6: deterministic split-K for the residual GEMMs whose reduction is long and whose output is small (FusedMLP's second
-    // linear: K = 4 D).  At M <= 1536 rows the chip is only filled by 96 x 64 / 64 x 64 tiles, which pull 1.3 MB of operands through
-    // every CU's L1 miss path (the bound of these kernels); 192 x 128 tiles over a quarter of K each halve
-    // that, the partial tiles cost a quarter of what they save.  GA_GEMM_SPLITK (read once): 0 off, 1 / 2 / 3 force a configuration.
+    // Round 6: deterministic split-K for the GEMMs whose output tiles cannot fill the chip (FusedMLP's second linear: K = 4 D; the wide
+    // projections at 768 rows).  At M <= 1536 rows the chip is only filled by 96 x 64 / 64 x 64 tiles, which pull 1.3 MB of operands through
+    // every CU's L1 miss path (the bound of these kernels); 192 x 128 tiles over a quarter of K each halve that.
     if (a->splitk_ws && p.k_rows == 0 && a->epilogue != GA_GEMM_EPI_STORE_F32) {
         const int sk_env = splitk_mode().load(std::memory_order_relaxed);
         const int nk = a->K / BK;
@@ -997,19 +962,21 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
         // (qkv with its head norm / V^T, fc1 with GELU) only exist for configuration 4 -- what their shapes need at 768 rows.
         const bool ok4 = nk % 16 == 0 && nk >= 32, ok2 = nk % 8 == 0 && nk >= 16;
         auto fills = [](long long wgs) { return wgs >= 160 && wgs <= 256; };
+        // MEASURED SLOWER on every DiT shape (profiles/r6_splitk.txt: fc2 at 1536 rows 25.5 -> 29.5 ... 35.0 us, at 768 rows 19.9 -> 22.8 ... 27.8,
+        // DiT-L 3.11 -> 3.30 ms per evaluation): the memory-side hand-over costs more than the smaller K loop saves.  OFF unless asked for:
+        // mode 6 = the shape rule below, 5 = the same for EPI 2 only, 1 ... 4 = one configuration.
         int cfg = 0;
-        if (rows48 && t192 < 160) {          // (a 192 x 128 grid that fills the chip on its own needs no split)
+        if ((sk_env == 5 || sk_env == 6) && rows48 && t192 < 160) {          // (a 192 x 128 grid that fills the chip on its own needs no split)
             if (ok2 && fills(t192 * 2)) cfg = 4;
             else if (res && ok4 && fills(t192 * 4)) cfg = 1;
             else if (res && ok4 && fills(t96 * 4)) cfg = 3;
             else if (res && ok2 && fills(t96 * 2)) cfg = 2;
         }
-        if (sk_env == 0) cfg = 0;
-        else if (sk_env == 1) cfg = res && rows48 && ok4 ? 1 : 0;
+        if (sk_env == 1) cfg = res && rows48 && ok4 ? 1 : 0;
         else if (sk_env == 2) cfg = res && rows48 && ok2 ? 2 : 0;
         else if (sk_env == 3) cfg = res && rows48 && ok4 ? 3 : 0;
         else if (sk_env == 4) cfg = rows48 && ok2 ? 4 : 0;
-        else if (sk_env == 5) cfg = res ? cfg : 0;          // by shape, residual GEMMs only (A/B aid)
+        else if (sk_env == 5) cfg = res ? cfg : 0;          // by shape, residual GEMMs only
         const bool big = cfg == 1 || cfg == 4;
         const long long tiles = big ? t192 : t96;
         const int splits = (cfg == 2 || cfg == 4) ? 2 : 4;

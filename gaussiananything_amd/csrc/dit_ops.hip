@@ -506,7 +506,9 @@ static Ws carve(const GaDitModel *m, int B, int L, void *base)
     const size_t o_sbias = take((size_t)m->depth * B * 7 * D * 4);   // shift_b W^T + bias of the qkv and fc1 projections (folded modulated pre-norms)
     // (round 6) split-K scratch of the MLP's second linear: counters + partial tiles; only where a 4-way split can fill the chip
     // (fc2: up to 4 splits of [M, D]; qkv / fc1 at 768 rows: 2 splits of [M, 4 D] -- half of the 4-split bound)
-    w.splitk_bytes = M <= 3072 ? std::max(ga_gemm_splitk_workspace_bytes((int32_t)M, (int32_t)D),
+    // Measured slower (include/ga_dit.h: ga_gemm_splitk_mode) -- the scratch only exists when GA_GEMM_SPLITK asks for a split at process start
+    static const bool sk_on = [] { const char *e = getenv("GA_GEMM_SPLITK"); return e && atoi(e) > 0; }();
+    w.splitk_bytes = sk_on && M <= 3072 ? std::max(ga_gemm_splitk_workspace_bytes((int32_t)M, (int32_t)D),
                                           GA_GEMM_SPLITK_COUNTER_BYTES + (ga_gemm_splitk_workspace_bytes((int32_t)M, (int32_t)(4 * D)) - GA_GEMM_SPLITK_COUNTER_BYTES) / 2) : 0;
     const size_t o_sk = take(w.splitk_bytes);
     w.splitk = w.splitk_bytes && base ? p + o_sk : nullptr;

@@ -112,10 +112,11 @@ typedef struct GaGemmArgs {
 #define GA_GEMM_SPLITK_COUNTER_BYTES 16384
 #define GA_GEMM_SPLITK_MAX_TILES (GA_GEMM_SPLITK_COUNTER_BYTES / 4)
 size_t ga_gemm_splitk_workspace_bytes(int32_t M, int32_t N);
-/* tuning / test hook: which split-K configuration calls with a scratch take.  -1 (default; or the value of the environment variable
- * GA_GEMM_SPLITK at first use): chosen by shape; 0: none; 1: 192 x 128 tiles x 4 splits; 2: 96 x 128 x 2; 3: 96 x 128 x 4; 4: 192 x 128
- * x 2 (the only one the bf16-store epilogues have); 5: by shape for EPI 2 only (a forced configuration still needs K / 64 divisible
- * by 4 x splits and >= 8 x splits).  Returns the previous mode.  Process-wide. */
+/* Which split-K configuration calls with a scratch take.  MEASURED SLOWER than the unsplit kernels on every shape of the denoiser
+ * (profiles/r6_splitk.txt), therefore OFF by default: -1 (default; or the value of the environment variable GA_GEMM_SPLITK at first use)
+ * and 0: none; 1: 192 x 128 tiles x 4 splits; 2: 96 x 128 x 2; 3: 96 x 128 x 4; 4: 192 x 128 x 2 (the only one the bf16-store epilogues
+ * have); 6: chosen by shape (splits x tiles must fill 160 ... 256 workgroups); 5: the same for EPI 2 only.  A configuration still needs
+ * K / 64 divisible by 4 x splits and >= 8 x splits.  Returns the previous mode.  Process-wide. */
 int ga_gemm_splitk_mode(int mode);
 
 int ga_gemm_bf16(const GaGemmArgs *args, void *stream);
