@@ -539,7 +539,7 @@ static bool model_ok(const GaDitModel *m)
 
 }  // namespace gadit
 
-extern "C" const char *ga_dit_version(void) { return "ga_mi355 dit gfx950 r5"; }
+extern "C" const char *ga_dit_version(void) { return "ga_mi355 dit gfx950 r6"; }
 
 extern "C" size_t ga_dit_workspace_bytes(const GaDitModel *m, int32_t batch, int32_t tokens, int32_t ctx_tokens)
 {

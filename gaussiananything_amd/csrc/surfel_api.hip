@@ -26,7 +26,7 @@ bool make_dims(int32_t N, int32_t V, int32_t H, int32_t W, ga::Dims *d)
 
 extern "C" {
 
-const char *ga_surfel_version(void) { return "ga_mi355 surfel gfx950 r5"; }
+const char *ga_surfel_version(void) { return "ga_mi355 surfel gfx950 r6"; }
 
 int ga_surfel_workspace_layout(int32_t num_points, int32_t num_views, int32_t image_height, int32_t image_width,
                                int64_t capacity, GaSurfelWorkspaceLayout *out)
