@@ -61,18 +61,22 @@ class HipEvents:
 
 
 def committed_pmc(name):
-    """profiles/<name> (tools/pmc_to_json.py) if the kernel source it was measured on is still the source in the tree, else None:
-    counters cannot be collected inside this run, and a quotation of a stale pass would drift from the code silently."""
+    """profiles/<round>_<name> (tools/pmc_to_json.py), newest round first, if the kernel source it was measured on is still the source in
+    the tree, else None: counters cannot be collected inside this run, and a quotation of a stale pass would drift from the code silently."""
     import hashlib
-    path = os.path.join(ROOT, "profiles", name)
-    if not os.path.exists(path):
-        return None
-    pj = json.load(open(path))
-    for rel, want in pj.get("source_sha256", {}).items():
-        src = os.path.join(ROOT, rel)
-        if not os.path.exists(src) or hashlib.sha256(open(src, "rb").read()).hexdigest() != want:
-            return None
-    return pj
+    for rnd in ("r6", "r5"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
+        if not os.path.exists(path):
+            continue
+        pj = json.load(open(path))
+        ok = True
+        for rel, want in pj.get("source_sha256", {}).items():
+            src = os.path.join(ROOT, rel)
+            if not os.path.exists(src) or hashlib.sha256(open(src, "rb").read()).hexdigest() != want:
+                ok = False
+        if ok:
+            return pj
+    return None
 
 
 def host_threads():
@@ -179,7 +183,7 @@ def bench_attention(dev, reps=50):
         fl = 4.0 * B * H * Lq * Lk * 64
         out[name] = {"us": round(us, 2), "tflops": round(fl / (us * 1e-6) / 1e12, 1),
                      "frac_of_bf16_mfma_peak": round(fl / (us * 1e-6) / 1e12 / 2500.0, 4)}
-    pj = committed_pmc("r5_attention_pmc.json")
+    pj = committed_pmc("attention_pmc.json")
     out["mfma_busy_from_counters"] = ({"kernels": pj["kernels"], "source": pj["source"] + " (committed rocprofv3 PMC pass of exactly these two "
                                         "launches: SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs; dit_attention.hip unchanged "
                                         "since), not measured in this run"} if pj else None)
@@ -865,7 +869,7 @@ def main():
             blend_bytes = 76.0 * int(st[0]) + 40.0 * P * v      # per launch (all V views), SURVEY.md 8d
             achieved = blend_bytes / (stage["blend"] * 1e-3) / 1e9
             traffic, tsrc, valu_frac, valu_insts = None, None, None, None  # PMC counters cannot be collected live: committed rocprofv3 passes
-            pj = committed_pmc("r5_blend_pmc.json") if (a.scene == "surface" and n == 100_000 and v == 8 and H == 512) else None
+            pj = committed_pmc("blend_pmc.json") if (a.scene == "surface" and n == 100_000 and v == 8 and H == 512) else None
             if pj:
                 traffic, valu_frac, valu_insts = pj["traffic_bytes_per_launch"], pj["valu_issue_frac"], pj["SQ_INSTS_VALU"]
                 tsrc = f"committed PMC ({pj['source']}; surfel_blend.hip unchanged since), not measured in this run"
@@ -955,7 +959,7 @@ def main():
             out["attention"] = bench_attention(dev)
             from tools.gemm_yardstick import yardstick   # same-run, same-node: torch.matmul beside ga_gemm_bf16 (tools only)
             out["gemm_yardstick"] = yardstick(dev)
-            gj = committed_pmc("r5_gemm_pmc.json")   # MFMA busy of the GEMM kernels (committed counter pass, hash-keyed like the blend's)
+            gj = committed_pmc("gemm_pmc.json")   # MFMA busy of the GEMM kernels (committed counter pass, hash-keyed like the blend's)
             out["gemm_yardstick"]["mfma_busy_from_counters"] = ({"kernels": {k: v["mfma_busy"] for k, v in gj["kernels"].items()},
                                                                  "source": gj["source"] + " (committed rocprofv3 PMC pass; dit_gemm.hip unchanged since)"}
                                                                 if gj else None)
