@@ -28,6 +28,8 @@
 //     fragments; the softmax scale and log2(e) are folded into Q so the exponentials are bare v_exp_f32.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include <type_traits>
 
 #include "dit_common.h"
@@ -86,6 +88,8 @@ __device__ __forceinline__ float group_max(float t)
 struct AttnTail {
     ShiftBiasJob job;
     int y0;
+    PrefetchJob pf;      // pf.ptr[0] == nullptr: none; every tail workgroup takes its share (after its shift-bias part, if it has one)
+    int nwgs;            // tail workgroups in all
 };
 
 template <int NW, int KS, bool KNORM>
@@ -100,14 +104,15 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
     __shared__ __attribute__((aligned(16))) uint16_t smem[KS * 6 * TPS * TILE];  // per key group: K[3][TPS][key][d], V^T[3][TPS][d][key]
     constexpr int kTailPairs = sizeof(smem) / (kSbLdsFloats * sizeof(float)) >= 4 ? 4 : (int)(sizeof(smem) / (kSbLdsFloats * sizeof(float)));
     static_assert(kTailPairs >= 1, "the tail's partial sums");
-    if (tail.job.W[0] != nullptr) {   // kernel-uniform
+    if (tail.job.W[0] != nullptr || tail.pf.ptr[0] != nullptr) {   // kernel-uniform
 #if GA_ATTN_HEAD_MAJOR
         const int slice = (int)blockIdx.y - tail.y0, in_slice = blockIdx.x, per_slice = gridDim.x;
 #else
         const int slice = (int)blockIdx.z - tail.y0, in_slice = blockIdx.y * gridDim.x + blockIdx.x, per_slice = gridDim.x * gridDim.y;
 #endif
         if (slice >= 0) {             // workgroup-uniform
-            shift_bias_block<kTailPairs>(tail.job, slice * per_slice + in_slice, reinterpret_cast<float *>(smem));
+            if (tail.job.W[0] != nullptr) shift_bias_block<kTailPairs>(tail.job, slice * per_slice + in_slice, reinterpret_cast<float *>(smem));
+            if (tail.pf.ptr[0] != nullptr) prefetch_block(tail.pf, slice * per_slice + in_slice, tail.nwgs);
             return;
         }
     }
@@ -561,7 +566,7 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
 }
 
 template <int NW, int KS>
-static void launch_attention(const GaAttentionArgs &a, hipStream_t s, const ShiftBiasJob *job)
+static void launch_attention(const GaAttentionArgs &a, hipStream_t s, const ShiftBiasJob *job, const PrefetchJob *pf = nullptr, int pf_wgs = 0)
 {
     // K normalised while it is staged (not on the DiT path, which normalises K once per conditioning tensor): ONE instantiation, eight
     // query waves and a single key group -- <8,2,true> / <4,3,true> spilt registers and <4,1,true> carried a private segment (round-3 review)
@@ -574,15 +579,18 @@ static void launch_attention(const GaAttentionArgs &a, hipStream_t s, const Shif
     dim3 grid((a.Lq + rows - 1) / rows, a.heads, a.batch);
 #endif
     AttnTail tail{};
-    if (job) {
-        tail.job = *job;
-        const int needed = shift_bias_wgs(job->N0, job->N1);
+    if (pf && pf->ptr[0] && pf_wgs > 0) tail.pf = *pf; else pf_wgs = 0;
+    if (job || pf_wgs) {
+        if (job) tail.job = *job;
+        const int needed = std::max(job ? shift_bias_wgs(job->N0, job->N1) : 0, pf_wgs);
 #if GA_ATTN_HEAD_MAJOR
         const int per_slice = (int)grid.x;
         tail.y0 = grid.y; grid.y += (needed + per_slice - 1) / per_slice;
+        tail.nwgs = (int)(grid.y - tail.y0) * per_slice;
 #else
         const int per_slice = (int)(grid.x * grid.y);
         tail.y0 = grid.z; grid.z += (needed + per_slice - 1) / per_slice;
+        tail.nwgs = (int)(grid.z - tail.y0) * per_slice;
 #endif
     }
     if (knorm) hipLaunchKernelGGL((attention_fwd_kernel<QW, 1, true>), grid, dim3(QW * 64), 0, s, a, tail);
@@ -599,7 +607,7 @@ extern "C" int ga_attn_debug_stamps(unsigned long long *out)
 #endif
 
 namespace gadit {
-static int dispatch_attention(const GaAttentionArgs *a, const ShiftBiasJob *job, void *stream);
+static int dispatch_attention(const GaAttentionArgs *a, const ShiftBiasJob *job, void *stream, const PrefetchJob *pf = nullptr, int pf_wgs = 0);
 // workgroups of the launch dispatch_attention picks for this shape (no k-norm): a tail only pays while they leave CUs idle
 int attention_workgroups(const GaAttentionArgs *a)
 {
@@ -611,17 +619,20 @@ bool attention_fuses_q(const GaAttentionArgs *a)
 {
     return (int64_t)((a->Lq + 127) / 128) * a->heads * a->batch <= 128;
 }
-int attention_with_tail(const GaAttentionArgs *a, const ShiftBiasJob *job, void *stream)
+int attention_with_tail(const GaAttentionArgs *a, const ShiftBiasJob *job, void *stream, const PrefetchJob *pf, int pf_wgs)
 {
-    if (!job || !job->W[0] || !job->W[1] || !job->shift || !job->out) return GA_DIT_ERR_NULL_ARG;
-    if (job->N0 % 8 != 0 || job->N1 % 8 != 0 || job->K % 64 != 0 || job->K > 2048 || job->B <= 0) return GA_DIT_ERR_BAD_SHAPE;   // (K / 64 <= 4 x 8 waves)
-    return dispatch_attention(a, job, stream);
+    if (job) {
+        if (!job->W[0] || !job->W[1] || !job->shift || !job->out) return GA_DIT_ERR_NULL_ARG;
+        if (job->N0 % 8 != 0 || job->N1 % 8 != 0 || job->K % 64 != 0 || job->K > 2048 || job->B <= 0) return GA_DIT_ERR_BAD_SHAPE;   // (K / 64 <= 4 x 8 waves)
+    }
+    if (pf && (pf->bytes[0] % 1024 || pf->bytes[1] % 1024)) return GA_DIT_ERR_BAD_SHAPE;
+    return dispatch_attention(a, job, stream, pf, pf_wgs);
 }
 }  // namespace gadit
 
 extern "C" int ga_attention_bf16(const GaAttentionArgs *a, void *stream) { return gadit::dispatch_attention(a, nullptr, stream); }
 
-static int gadit::dispatch_attention(const GaAttentionArgs *a, const ShiftBiasJob *job, void *stream)
+static int gadit::dispatch_attention(const GaAttentionArgs *a, const ShiftBiasJob *job, void *stream, const PrefetchJob *pf, int pf_wgs)
 {
     using namespace gadit;
     if (!a || (!a->q && !a->qp_a) || !a->k || !a->vt || !a->out) return GA_DIT_ERR_NULL_ARG;
@@ -648,20 +659,20 @@ static int gadit::dispatch_attention(const GaAttentionArgs *a, const ShiftBiasJo
     const int64_t wgs128 = (int64_t)((a->Lq + 127) / 128) * a->heads * a->batch;
     if (a->qp_a && (cfg != 0 || wgs128 > 128)) return GA_DIT_ERR_BAD_SHAPE;   // only the 64-query configuration projects q itself (attention_fuses_q)
 #ifdef GA_TUNING
-    if (cfg == 23) { launch_attention<2, 3>(*a, s, job); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
-    if (cfg == 43) { launch_attention<4, 3>(*a, s, job); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
-    if (cfg == 22) { launch_attention<2, 2>(*a, s, job); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
-    if (cfg == 41) { launch_attention<4, 1>(*a, s, job); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
-    if (cfg == 82) { launch_attention<8, 2>(*a, s, job); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
-    if (cfg == 21) { launch_attention<2, 1>(*a, s, job); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
+    if (cfg == 23) { launch_attention<2, 3>(*a, s, job, pf, pf_wgs); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
+    if (cfg == 43) { launch_attention<4, 3>(*a, s, job, pf, pf_wgs); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
+    if (cfg == 22) { launch_attention<2, 2>(*a, s, job, pf, pf_wgs); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
+    if (cfg == 41) { launch_attention<4, 1>(*a, s, job, pf, pf_wgs); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
+    if (cfg == 82) { launch_attention<8, 2>(*a, s, job, pf, pf_wgs); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
+    if (cfg == 21) { launch_attention<2, 1>(*a, s, job, pf, pf_wgs); return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH; }
 #endif
     // Round 3 (tools/attn_cfg_sweep.py): three key groups on the small grids (1 x 16 x 768 x 1369: 15.9 -> 14.2 us, x 768 keys
     // 10.1 -> 9.6 us), and two key groups beside eight query waves while 128-query workgroups are fewer than two per CU
     // (2 x 16 x 768 x 768: 13.7 -> 12.8 us; 4 x 16 x 768 x 1369: 39.5 -> 37.1 us); one group on the grids beyond that.
-    if (cfg == 42) launch_attention<4, 2>(*a, s, job);
-    else if (cfg == 81) launch_attention<8, 1>(*a, s, job);
-    else if (wgs128 <= 128) launch_attention<4, 3>(*a, s, job);
-    else if (wgs128 <= 512) launch_attention<8, 2>(*a, s, job);
-    else launch_attention<8, 1>(*a, s, job);
+    if (cfg == 42) launch_attention<4, 2>(*a, s, job, pf, pf_wgs);
+    else if (cfg == 81) launch_attention<8, 1>(*a, s, job, pf, pf_wgs);
+    else if (wgs128 <= 128) launch_attention<4, 3>(*a, s, job, pf, pf_wgs);
+    else if (wgs128 <= 512) launch_attention<8, 2>(*a, s, job, pf, pf_wgs);
+    else launch_attention<8, 1>(*a, s, job, pf, pf_wgs);
     return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
 }

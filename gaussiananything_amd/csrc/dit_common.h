@@ -132,9 +132,38 @@ __device__ __forceinline__ void shift_bias_block(const ShiftBiasJob &j, int wg, 
     }
 }
 
+// Round 6: weight ranges the idle workgroups of an attention launch pull towards the Infinity Cache for a GEMM that runs a few launches
+// later (fc2's 8 MB: 24.0 -> 21.1 us at 1536 rows, 19.3 -> 15.7 us at 768 when its weights are there instead of in HBM,
+// tools/warm_vs_cold.py).  Plain loads whose values are folded into a word nobody reads: nothing depends on them.
+struct PrefetchJob {
+    const char *ptr[2];
+    unsigned bytes[2];       // multiples of 1024
+};
+__device__ __forceinline__ void prefetch_block(const PrefetchJob &j, int wg, int nwgs)
+{
+    const int nw = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned acc = 0;
+#pragma unroll 1
+    for (int r = 0; r < 2; ++r) {
+        if (!j.ptr[r]) continue;
+        const unsigned pieces = j.bytes[r] >> 10, per = (pieces + nwgs - 1) / nwgs;     // 1-KiB pieces: one wave load each
+        const unsigned p0 = (unsigned)wg * per, p1 = min(p0 + per, pieces);
+        const char *base = j.ptr[r] + (size_t)lane * 16;
+#pragma unroll 1
+        for (unsigned p = p0 + w; p < p1; p += 8 * nw) {                              // eight loads in flight per lane
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint4 *>(base + (size_t)min(p + (unsigned)u * nw, p1 - 1) * 1024);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+        }
+    }
+    asm volatile("" ::"v"(acc));   // (keeps the loads)
+}
+
 // dit_attention.hip: the attention launch with `tail` workgroups behind its grid that compute one ShiftBiasJob (the self-attention of a
 // CFG pair fills 192 of the 256 CUs with one 96-KiB-LDS workgroup each: the job's weight stream runs on the idle ones)
-int attention_with_tail(const GaAttentionArgs *a, const ShiftBiasJob *job, void *stream);
+int attention_with_tail(const GaAttentionArgs *a, const ShiftBiasJob *job, void *stream, const PrefetchJob *pf = nullptr, int pf_wgs = 0);
 int attention_workgroups(const GaAttentionArgs *a);
 bool attention_fuses_q(const GaAttentionArgs *a);
 

@@ -695,6 +695,19 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         static const bool sb_tail0_env = [] { const char *e = getenv("GA_DIT_SBTAIL0"); return !e || atoi(e) != 0; }();   // A/B aid
         sb_tail0 = sb_tail0_env && sb_tail && attention_workgroups(&probe_ca) + shift_bias_wgs(3 * D, 4 * D) <= 256;
     }
+    // Round 6: a block's fc2 weights (8 MB at D = 1024: the one GEMM whose time depends on where its weights are, tools/warm_vs_cold.py)
+    // are pulled towards the Infinity Cache by the CUs an attention grid of the same block leaves idle.  GA_DIT_PREFETCH: 0 off,
+    // 1 behind the cross-attention grid (default), 2 behind the self-attention grid, 3 fc2 + the two output projections behind the CA grid
+    static const int pf_mode = [] { const char *e = getenv("GA_DIT_PREFETCH"); return e ? atoi(e) : 1; }();
+    int pf_ca = 0, pf_sa = 0;        // tail workgroups available for it
+    if (hd == 64 && pf_mode > 0) {
+        const GaAttentionArgs probe_sa{B, m->heads, L, L, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0};
+        const GaAttentionArgs probe_ca{ca_batch, m->heads, L, a->ctx_tokens, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0};
+        pf_ca = std::max(0, 256 - attention_workgroups(&probe_ca));
+        pf_sa = std::max(0, 256 - attention_workgroups(&probe_sa));
+        if (pf_ca < 16 || pf_mode == 2) pf_ca = 0;
+        if (pf_sa < 16 || pf_mode != 2) pf_sa = 0;
+    }
     if (fold_mod && !sb_tail0) {
         ShiftBiasArgs sb{};
         for (int i = 0; i < m->depth; ++i) {
@@ -800,11 +813,17 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
             GA_UNLESS(32, ga_gemm_bf16(&gq, stream));
         }
         if (i == 0 && !join()) return GA_DIT_ERR_LAUNCH;     // the conditioning chain's results from here on (mod, tvec, block 0's shift rows)
+        PrefetchJob pf{{reinterpret_cast<const char *>(bw.fc2_w), nullptr}, {(unsigned)(8u * (unsigned)D * (unsigned)D), 0u}};
+        if (pf_mode == 3) {   // (+ the output projections of the self-attention and of the NEXT block's cross-attention: adjacent? no -- two ranges only)
+            pf.ptr[1] = reinterpret_cast<const char *>(bw.proj_w); pf.bytes[1] = (unsigned)(2u * (unsigned)D * (unsigned)D);
+        }
         if (i == 0 && sb_tail0) {
             ShiftBiasJob job{{bw.qkv_w, bw.fc1_w}, {bw.qkv_b, bw.fc1_b}, w.mod, w.sbias,
                              6 * (long long)D, 3 * (long long)D, 3 * D, 4 * D, D, B, m->gemm_weights_tiled};
-            GA_UNLESS(2, attention_with_tail(&ca, &job, stream));
-        } else
+            GA_UNLESS(2, attention_with_tail(&ca, &job, stream, pf_ca ? &pf : nullptr, pf_ca));
+        } else if (pf_ca)
+            GA_UNLESS(2, attention_with_tail(&ca, nullptr, stream, &pf, pf_ca));
+        else
             GA_UNLESS(2, ga_attention_bf16(&ca, stream));
         GaGemmArgs go{};
         go.M = Mca; go.N = D; go.K = D; go.epilogue = GA_GEMM_EPI_RESIDUAL; go.A = w.att; go.lda = D; go.W = bw.ca_out_w; go.w_tiled = m->gemm_weights_tiled;
@@ -839,8 +858,10 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
             const GaDitBlockWeights &nb = m->blocks[i + 1];
             ShiftBiasJob job{{nb.qkv_w, nb.fc1_w}, {nb.qkv_b, nb.fc1_b}, w.mod + (size_t)(i + 1) * B * 6 * D, w.sbias + (size_t)(i + 1) * B * 7 * D,
                              6 * (long long)D, 3 * (long long)D, 3 * D, 4 * D, D, B, m->gemm_weights_tiled};
-            GA_UNLESS(1, attention_with_tail(&sa, &job, stream));
-        } else
+            GA_UNLESS(1, attention_with_tail(&sa, &job, stream, pf_sa ? &pf : nullptr, pf_sa));
+        } else if (pf_sa)
+            GA_UNLESS(1, attention_with_tail(&sa, nullptr, stream, &pf, pf_sa));
+        else
             GA_UNLESS(1, ga_attention_bf16(&sa, stream));
         GaGemmArgs gp{};
         gp.M = Mrows; gp.N = D; gp.K = D; gp.epilogue = GA_GEMM_EPI_RESIDUAL; gp.A = w.att; gp.lda = D; gp.W = bw.proj_w; gp.w_tiled = m->gemm_weights_tiled;
