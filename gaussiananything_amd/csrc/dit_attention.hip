@@ -88,8 +88,9 @@ __device__ __forceinline__ float group_max(float t)
 struct AttnTail {
     ShiftBiasJob job;
     int y0;
-    PrefetchJob pf;      // pf.ptr[0] == nullptr: none; every tail workgroup takes its share (after its shift-bias part, if it has one)
+    PrefetchJob pf;      // every tail workgroup takes its share (after its shift-bias part, if it has one)
     int nwgs;            // tail workgroups in all
+    int pf_on;
 };
 
 template <int NW, int KS, bool KNORM>
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
     __shared__ __attribute__((aligned(16))) uint16_t smem[KS * 6 * TPS * TILE];  // per key group: K[3][TPS][key][d], V^T[3][TPS][d][key]
     constexpr int kTailPairs = sizeof(smem) / (kSbLdsFloats * sizeof(float)) >= 4 ? 4 : (int)(sizeof(smem) / (kSbLdsFloats * sizeof(float)));
     static_assert(kTailPairs >= 1, "the tail's partial sums");
-    if (tail.job.W[0] != nullptr || tail.pf.ptr[0] != nullptr) {   // kernel-uniform
+    if (tail.job.W[0] != nullptr || tail.nwgs > 0) {   // kernel-uniform
 #if GA_ATTN_HEAD_MAJOR
         const int slice = (int)blockIdx.y - tail.y0, in_slice = blockIdx.x, per_slice = gridDim.x;
 #else
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
 #endif
         if (slice >= 0) {             // workgroup-uniform
             if (tail.job.W[0] != nullptr) shift_bias_block<kTailPairs>(tail.job, slice * per_slice + in_slice, reinterpret_cast<float *>(smem));
-            if (tail.pf.ptr[0] != nullptr) prefetch_block(tail.pf, slice * per_slice + in_slice, tail.nwgs);
+            if (tail.pf_on) prefetch_block(tail.pf, slice * per_slice + in_slice, tail.nwgs);
             return;
         }
     }
@@ -579,7 +580,7 @@ static void launch_attention(const GaAttentionArgs &a, hipStream_t s, const Shif
     dim3 grid((a.Lq + rows - 1) / rows, a.heads, a.batch);
 #endif
     AttnTail tail{};
-    if (pf && pf->ptr[0] && pf_wgs > 0) tail.pf = *pf; else pf_wgs = 0;
+    if (pf && pf_wgs > 0) { tail.pf = *pf; tail.pf_on = 1; } else pf_wgs = 0;
     if (job || pf_wgs) {
         if (job) tail.job = *job;
         const int needed = std::max(job ? shift_bias_wgs(job->N0, job->N1) : 0, pf_wgs);
@@ -625,7 +626,9 @@ int attention_with_tail(const GaAttentionArgs *a, const ShiftBiasJob *job, void 
         if (!job->W[0] || !job->W[1] || !job->shift || !job->out) return GA_DIT_ERR_NULL_ARG;
         if (job->N0 % 8 != 0 || job->N1 % 8 != 0 || job->K % 64 != 0 || job->K > 2048 || job->B <= 0) return GA_DIT_ERR_BAD_SHAPE;   // (K / 64 <= 4 x 8 waves)
     }
-    if (pf && (pf->bytes[0] % 1024 || pf->bytes[1] % 1024)) return GA_DIT_ERR_BAD_SHAPE;
+    if (pf)
+        for (int r = 0; r < kPfRanges; ++r)
+            if (pf->ptr[r] && pf->bytes[r] % 1024) return GA_DIT_ERR_BAD_SHAPE;
     return dispatch_attention(a, job, stream, pf, pf_wgs);
 }
 }  // namespace gadit

@@ -135,16 +135,17 @@ __device__ __forceinline__ void shift_bias_block(const ShiftBiasJob &j, int wg, 
 // Round 6: weight ranges the idle workgroups of an attention launch pull towards the Infinity Cache for a GEMM that runs a few launches
 // later (fc2's 8 MB: 24.0 -> 21.1 us at 1536 rows, 19.3 -> 15.7 us at 768 when its weights are there instead of in HBM,
 // tools/warm_vs_cold.py).  Plain loads whose values are folded into a word nobody reads: nothing depends on them.
+constexpr int kPfRanges = 6;
 struct PrefetchJob {
-    const char *ptr[2];
-    unsigned bytes[2];       // multiples of 1024
+    const char *ptr[kPfRanges];      // nullptr: unused slot
+    unsigned bytes[kPfRanges];       // multiples of 1024
 };
 __device__ __forceinline__ void prefetch_block(const PrefetchJob &j, int wg, int nwgs)
 {
     const int nw = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned acc = 0;
 #pragma unroll 1
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < kPfRanges; ++r) {
         if (!j.ptr[r]) continue;
         const unsigned pieces = j.bytes[r] >> 10, per = (pieces + nwgs - 1) / nwgs;     // 1-KiB pieces: one wave load each
         const unsigned p0 = (unsigned)wg * per, p1 = min(p0 + per, pieces);

@@ -697,8 +697,9 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     }
     // Round 6: a block's fc2 weights (8 MB at D = 1024: the one GEMM whose time depends on where its weights are, tools/warm_vs_cold.py)
     // are pulled towards the Infinity Cache by the CUs an attention grid of the same block leaves idle.  GA_DIT_PREFETCH: 0 off,
-    // 1 behind the cross-attention grid (default), 2 behind the self-attention grid, 3 fc2 + the two output projections behind the CA grid
-    static const int pf_mode = [] { const char *e = getenv("GA_DIT_PREFETCH"); return e ? atoi(e) : 1; }();
+    // 1 fc2 behind the cross-attention grid, 2 fc2 behind the self-attention grid, 3 (default) fc2 + the self-attention's output projection behind the CA
+    // grid, 4: 3 + the next block's cross-attention projections (q, out), 5: 4 + the next block's cached K / V^T of the image tokens
+    static const int pf_mode = [] { const char *e = getenv("GA_DIT_PREFETCH"); return e ? atoi(e) : 3; }();
     int pf_ca = 0, pf_sa = 0;        // tail workgroups available for it
     if (hd == 64 && pf_mode > 0) {
         const GaAttentionArgs probe_sa{B, m->heads, L, L, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0};
@@ -813,9 +814,24 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
             GA_UNLESS(32, ga_gemm_bf16(&gq, stream));
         }
         if (i == 0 && !join()) return GA_DIT_ERR_LAUNCH;     // the conditioning chain's results from here on (mod, tvec, block 0's shift rows)
-        PrefetchJob pf{{reinterpret_cast<const char *>(bw.fc2_w), nullptr}, {(unsigned)(8u * (unsigned)D * (unsigned)D), 0u}};
-        if (pf_mode == 3) {   // (+ the output projections of the self-attention and of the NEXT block's cross-attention: adjacent? no -- two ranges only)
-            pf.ptr[1] = reinterpret_cast<const char *>(bw.proj_w); pf.bytes[1] = (unsigned)(2u * (unsigned)D * (unsigned)D);
+        PrefetchJob pf{};
+        {
+            const unsigned DD = (unsigned)D * (unsigned)D;
+            pf.ptr[0] = reinterpret_cast<const char *>(bw.fc2_w); pf.bytes[0] = 8u * DD;
+            if (pf_mode >= 3) { pf.ptr[1] = reinterpret_cast<const char *>(bw.proj_w); pf.bytes[1] = 2u * DD; }
+            if (pf_mode >= 4 && i + 1 < m->depth) {   // what the NEXT block's cross-attention and its output projection start on
+                const GaDitBlockWeights &nb = m->blocks[i + 1];
+                pf.ptr[2] = reinterpret_cast<const char *>(nb.ca_out_w); pf.bytes[2] = 2u * DD;
+                const uint16_t *qw = (can_fold(m, i + 1) && nb.ca_q_w_prenorm) ? nb.ca_q_w_prenorm : nb.ca_q_w;
+                pf.ptr[3] = reinterpret_cast<const char *>(qw); pf.bytes[3] = 2u * DD;
+                if (pf_mode >= 5) {                   // ... and its cached K / V^T of the image tokens (the items that take part)
+                    const size_t Mp_ = ((size_t)a->ctx_tokens + 63) / 64 * 64;
+                    pf.ptr[4] = reinterpret_cast<const char *>(a->ca_k + (size_t)(i + 1) * B * a->ctx_tokens * D);
+                    pf.bytes[4] = (unsigned)((size_t)ca_batch * a->ctx_tokens * D * 2 / 1024 * 1024);
+                    pf.ptr[5] = reinterpret_cast<const char *>(a->ca_vt + (size_t)(i + 1) * B * D * Mp_);
+                    pf.bytes[5] = (unsigned)((size_t)ca_batch * D * Mp_ * 2 / 1024 * 1024);
+                }
+            }
         }
         if (i == 0 && sb_tail0) {
             ShiftBiasJob job{{bw.qkv_w, bw.fc1_w}, {bw.qkv_b, bw.fc1_b}, w.mod, w.sbias,
