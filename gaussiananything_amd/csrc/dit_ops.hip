@@ -824,13 +824,17 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
                 pf.ptr[2] = reinterpret_cast<const char *>(nb.ca_out_w); pf.bytes[2] = 2u * DD;
                 const uint16_t *qw = (can_fold(m, i + 1) && nb.ca_q_w_prenorm) ? nb.ca_q_w_prenorm : nb.ca_q_w;
                 pf.ptr[3] = reinterpret_cast<const char *>(qw); pf.bytes[3] = 2u * DD;
-                if (pf_mode >= 5) {                   // ... and its cached K / V^T of the image tokens (the items that take part)
+                if (pf_mode == 5) {                   // ... and its cached K / V^T of the image tokens (the items that take part)
                     const size_t Mp_ = ((size_t)a->ctx_tokens + 63) / 64 * 64;
                     pf.ptr[4] = reinterpret_cast<const char *>(a->ca_k + (size_t)(i + 1) * B * a->ctx_tokens * D);
                     pf.bytes[4] = (unsigned)((size_t)ca_batch * a->ctx_tokens * D * 2 / 1024 * 1024);
                     pf.ptr[5] = reinterpret_cast<const char *>(a->ca_vt + (size_t)(i + 1) * B * D * Mp_);
                     pf.bytes[5] = (unsigned)((size_t)ca_batch * D * Mp_ * 2 / 1024 * 1024);
                 }
+            }
+            if (pf_mode >= 6) {   // this block's qkv and fc1 weights once more (the shift rows' pass over them was a block ago)
+                pf.ptr[4] = reinterpret_cast<const char *>(bw.qkv_w); pf.bytes[4] = 6u * DD;
+                pf.ptr[5] = reinterpret_cast<const char *>(bw.fc1_w); pf.bytes[5] = 8u * DD;
             }
         }
         if (i == 0 && sb_tail0) {
