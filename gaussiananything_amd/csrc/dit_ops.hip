@@ -695,11 +695,15 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         static const bool sb_tail0_env = [] { const char *e = getenv("GA_DIT_SBTAIL0"); return !e || atoi(e) != 0; }();   // A/B aid
         sb_tail0 = sb_tail0_env && sb_tail && attention_workgroups(&probe_ca) + shift_bias_wgs(3 * D, 4 * D) <= 256;
     }
-    // Round 6: a block's fc2 weights (8 MB at D = 1024: the one GEMM whose time depends on where its weights are, tools/warm_vs_cold.py)
-    // are pulled towards the Infinity Cache by the CUs an attention grid of the same block leaves idle.  GA_DIT_PREFETCH: 0 off,
-    // 1 fc2 behind the cross-attention grid, 2 fc2 behind the self-attention grid, 3 (default) fc2 + the self-attention's output projection behind the CA
-    // grid, 4: 3 + the next block's cross-attention projections (q, out), 5: 4 + the next block's cached K / V^T of the image tokens
-    static const int pf_mode = [] { const char *e = getenv("GA_DIT_PREFETCH"); return e ? atoi(e) : 3; }();
+    // Round 6: WEIGHT PREFETCH.  A GEMM whose weights sit in the Infinity Cache instead of HBM starts and streams faster (fc2 at 1536
+    // rows 24.0 -> 21.1 us, at 768 rows 19.3 -> 15.7; fc1 18.0 -> 17.1; tools/warm_vs_cold.py), and every attention grid of a CFG pair
+    // leaves 64 of the 256 CUs idle.  The tail workgroups behind block i's CROSS-attention grid (dit_attention.hip: PrefetchJob) read
+    // block i's fc2 and self-attention output weights and block i + 1's cross-attention q / output weights -- plain loads nobody
+    // waits for; the qkv and fc1 weights are already passed over by the shift rows' tail a block earlier.  Same-box A/B
+    // (profiles/r6_prefetch_ab.txt): DiT-L 2.91 -> 2.73 ms per evaluation (-6 %), batch 1 2.53 -> 2.38, CFG batch 4 4.79 -> 4.67, DiT-B
+    // 1.29 -> 1.27.  GA_DIT_PREFETCH: 0 off | 1 fc2 only | 2 fc2 behind the self-attention grid instead | 3 fc2 + proj | 4 (default) 3 + the
+    // next block's cross-attention q / out | 5: 4 + its cached K / V^T (no gain) | 6: 4 + this block's qkv / fc1 once more (no gain)
+    static const int pf_mode = [] { const char *e = getenv("GA_DIT_PREFETCH"); return e ? atoi(e) : 4; }();
     int pf_ca = 0, pf_sa = 0;        // tail workgroups available for it
     if (hd == 64 && pf_mode > 0) {
         const GaAttentionArgs probe_sa{B, m->heads, L, L, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0};
