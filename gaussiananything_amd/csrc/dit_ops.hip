@@ -823,12 +823,14 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
             const unsigned DD = (unsigned)D * (unsigned)D;
             pf.ptr[0] = reinterpret_cast<const char *>(bw.fc2_w); pf.bytes[0] = 8u * DD;
             if (pf_mode >= 3) { pf.ptr[1] = reinterpret_cast<const char *>(bw.proj_w); pf.bytes[1] = 2u * DD; }
-            if (pf_mode >= 4 && i + 1 < m->depth) {   // what the NEXT block's cross-attention and its output projection start on
-                const GaDitBlockWeights &nb = m->blocks[i + 1];
+            if (pf_mode >= 4) {   // what the NEXT block's cross-attention and its output projection start on (after the last block: block 0 of
+                                  // the next evaluation -- a sampling loop comes straight back)
+                const int ni = i + 1 < m->depth ? i + 1 : 0;
+                const GaDitBlockWeights &nb = m->blocks[ni];
                 pf.ptr[2] = reinterpret_cast<const char *>(nb.ca_out_w); pf.bytes[2] = 2u * DD;
-                const uint16_t *qw = (can_fold(m, i + 1) && nb.ca_q_w_prenorm) ? nb.ca_q_w_prenorm : nb.ca_q_w;
+                const uint16_t *qw = (ni > 0 && can_fold(m, ni) && nb.ca_q_w_prenorm) ? nb.ca_q_w_prenorm : nb.ca_q_w;
                 pf.ptr[3] = reinterpret_cast<const char *>(qw); pf.bytes[3] = 2u * DD;
-                if (pf_mode == 5) {                   // ... and its cached K / V^T of the image tokens (the items that take part)
+                if (pf_mode == 5 && ni > 0) {         // ... and its cached K / V^T of the image tokens (the items that take part)
                     const size_t Mp_ = ((size_t)a->ctx_tokens + 63) / 64 * 64;
                     pf.ptr[4] = reinterpret_cast<const char *>(a->ca_k + (size_t)(i + 1) * B * a->ctx_tokens * D);
                     pf.bytes[4] = (unsigned)((size_t)ca_batch * a->ctx_tokens * D * 2 / 1024 * 1024);
