@@ -1026,16 +1026,9 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
 #ifdef GA_TUNING  // tuning builds only: GA_GEMM_RING = 0 old kernel, 1 / 2 / 3 force a ring tile
         if (const char *e = getenv("GA_GEMM_RING")) { const int c = atoi(e); if (c == 0 || (nk % 4 == 0 && nk >= 8 && c >= 1 && c <= 3)) ring = c; }
 #endif
-        // Round 6 experiment: 96 (rows) x 192 (columns), six waves (2 x 3 of 48 x 64): for the shapes whose 192 x 128 grid leaves a quarter of
-        // the CUs empty while this one fills them exactly (DiT-L's qkv at 1536 rows: 24 x 8 = 192 workgroups -> 16 x 16 = 256, 36 KB per
-        // K-tile instead of 40).  EPI 0 only.  GA_GEMM_WIDE96 = 1 switches it on (read once).
-        static const bool wide96_env = [] { const char *e = getenv("GA_GEMM_WIDE96"); return e && atoi(e) != 0; }();
-        if (wide96_env && ring == 1 && a->epilogue == GA_GEMM_EPI_STORE_BF16 && wg_big < 224 && a->N % 192 == 0 &&
-            (long long)(a->N / 192) * ((a->M + 95) / 96) >= 224 && (long long)(a->N / 192) * ((a->M + 95) / 96) <= 256) {
-            if (hipFuncSetAttribute((const void *)gemm_ring_kernel<0, 2, 3, 3, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 288 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH;
-            hipLaunchKernelGGL((gemm_ring_kernel<0, 2, 3, 3, 4, 4, 2>), dim3((unsigned)(a->N / 192), (unsigned)((a->M + 95) / 96)), dim3(384), 4 * 288 * BK * 2, s, p);
-            return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
-        }
+        // (round 6: a 96-row x 192-column six-wave tile that fills all 256 CUs for DiT-L's qkv -- 16 x 16 workgroups instead of the 24 x 8
+        //  = 192 of the 192 x 128 tile, 36 KB per K-tile instead of 40 -- measured the same to the microsecond, same-box A/B
+        //  2.72 / 2.72 ms per evaluation: not kept)
         if (ring) {
             static bool ring_attr_set = false;
             if (!ring_attr_set) {
