@@ -64,6 +64,10 @@ struct GemmP {  // by-value kernel parameters (kept flat: no pointer into the ar
     int splits;
     float *sk_part;
     unsigned *sk_count;
+    // round 6: tile -> XCD blocking (ring kernels).  Workgroup ids are dealt to the 8 XCDs round-robin; with xmap the XCD c = id % 8 owns a
+    // (gridDim.x / 2) x (gridDim.y / 4) block of output tiles instead of every 8th column of tiles: for the N = 1024 GEMMs, whose
+    // activation operand is larger than the weight, an XCD's L2 then serves 7 of 8 reads of an activation tile instead of 1 of 2
+    int xmap;
 };
 
 // Element offset of chunk c (8 bf16) of weight row n at K-tile 0, and the stride from one K-tile to the next: row-major
@@ -588,7 +592,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave / WM, wm = wave % WM;
-    const int n0 = blockIdx.x * BNT, m0 = blockIdx.y * BM;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xmap) {   // kernel-uniform (host: gridDim.x % 2 == 0, gridDim.y % 4 == 0)
+        const int lin = by * (int)gridDim.x + bx, c = lin & 7, k = lin >> 3, bw = (int)gridDim.x >> 1, bh = (int)gridDim.y >> 2;
+        bx = (c & 1) * bw + k % bw;
+        by = (c >> 1) * bh + k / bw;
+    }
+    const int n0 = bx * BNT, m0 = by * BM;
     const int M = p.M, N = p.N, K = p.K;
     const int nk = K / BK / (SK > 0 ? SK : 1);                 // K-tiles of THIS workgroup
     const int kt0 = SK > 0 ? (int)blockIdx.z * nk : 0;         // its first one
@@ -793,7 +803,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
 
     if constexpr (SK > 0) {
         const int split = __builtin_amdgcn_readfirstlane((int)blockIdx.z);
-        const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned tile = (unsigned)by * gridDim.x + (unsigned)bx;
         constexpr size_t FRAG = 64 * 16, WAVE_BYTES = (size_t)FN * FM * FRAG, WG_BYTES = (size_t)NW * WAVE_BYTES;
         char *tile_base = reinterpret_cast<char *>(p.sk_part) + (size_t)tile * SK * WG_BYTES + (size_t)wave * WAVE_BYTES + (size_t)lane * 16;
         // 8-byte agent-scope atomics (global_store / global_load_dwordx2 sc1): COMPILER-VISIBLE memory operations -- the first version
@@ -933,7 +943,7 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
                   a->qk_cols1, a->emit_x, a->emit_ss, a->emit_ld, a->row_ss, a->row_ss_tiles,
                   a->row_ss_dim > 0 ? 1.0f / (float)a->row_ss_dim : 0.f, a->row_ss_eps, a->w_tiled ? 1 : 0,
                   a->emit_w, a->emit_scale, a->emit_scale_stride, a->bias_stride, a->k_rows == a->M ? 0 : a->k_rows,
-                  0, nullptr, nullptr};
+                  0, nullptr, nullptr, 0};
     // Tile / ring choice (256 CUs).  A workgroup tile is 128 weight rows x 32 MT activation rows (MT = 4, 3, 2, 1); its work is
     // proportional to MT plus a tile-independent share (prologue, weight tile, epilogue: about one MT unit, tools/gemm_sweep.py) and
     // the launch ends with the busiest CU, so the cost of a choice is ceil(workgroups / 256) * (MT + 1)
@@ -1040,16 +1050,24 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
 #undef GA_RATTR
                 ring_attr_set = true;
             }
+            // tile -> XCD blocking for the residual GEMMs on the 96 x 64 / 64 x 64 tiles (GemmP.xmap); GA_GEMM_XMAP: 0 off, 1 (default) on
+            static const int xmap_env = [] { const char *e = getenv("GA_GEMM_XMAP"); return e ? atoi(e) : 0; }();
+            GemmP pr = p;
+            {
+                const unsigned gx = ring == 2 ? (unsigned)((a->N + 63) / 64) : (ring == 3 ? (unsigned)((a->N + 63) / 64) : 1u);
+                const unsigned gy = ring == 2 ? (unsigned)((a->M + 95) / 96) : (ring == 3 ? (unsigned)((a->M + 63) / 64) : 1u);
+                if (xmap_env && ring != 1 && a->epilogue == GA_GEMM_EPI_RESIDUAL && gx % 2 == 0 && gy % 4 == 0 && (gx * gy) % 8 == 0) pr.xmap = 1;
+            }
 #define GA_RLAUNCH(E)                                                                                                     \
             if (ring == 1)                                                                                                \
                 hipLaunchKernelGGL((gemm_ring_kernel<E, 4, 2, 3, 4, 4, 2>), dim3((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 191) / 192)), \
                                    dim3(512), 4 * 320 * BK * 2, s, p);                                                    \
             else if (ring == 2)                                                                                           \
                 hipLaunchKernelGGL((gemm_ring_kernel<E, 2, 2, 3, 2, 4, 0>), dim3((unsigned)((a->N + 63) / 64), (unsigned)((a->M + 95) / 96)), \
-                                   dim3(256), 4 * 160 * BK * 2, s, p);                                                    \
+                                   dim3(256), 4 * 160 * BK * 2, s, pr);                                                   \
             else                                                                                                          \
                 hipLaunchKernelGGL((gemm_ring_kernel<E, 4, 1, 1, 4, 4, 0>), dim3((unsigned)((a->N + 63) / 64), (unsigned)((a->M + 63) / 64)), \
-                                   dim3(256), 4 * 128 * BK * 2, s, p);
+                                   dim3(256), 4 * 128 * BK * 2, s, pr);
             switch (a->epilogue) {
             case GA_GEMM_EPI_STORE_BF16: GA_RLAUNCH(0) break;
             case GA_GEMM_EPI_GELU_BF16: GA_RLAUNCH(1) break;
