@@ -1050,13 +1050,18 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
 #undef GA_RATTR
                 ring_attr_set = true;
             }
-            // tile -> XCD blocking for the residual GEMMs on the 96 x 64 / 64 x 64 tiles (GemmP.xmap); GA_GEMM_XMAP: 0 off, 1 (default) on
-            static const int xmap_env = [] { const char *e = getenv("GA_GEMM_XMAP"); return e ? atoi(e) : 0; }();
+            // tile -> XCD blocking for the residual GEMMs on the 96 x 64 / 64 x 64 tiles (GemmP.xmap).  Same-box A/B (profiles/r6_xmap_ab.txt):
+            // it pays where the natural dealing is ragged or the grid is more than one round -- DiT-B (12 tile columns: an XCD's
+            // workgroups share neither weights nor activations systematically) 1.267 -> 1.229 ms per evaluation, DiT-L at CFG batch 4
+            // (512 workgroups) 5.21 -> 5.10 -- and costs 1 % where every XCD already owns two whole tile columns of a one-round grid
+            // (DiT-L at CFG batch 2: 2.930 -> 2.960; batch 1: 2.409 -> 2.422).  GA_GEMM_XMAP: 0 off, 1 always (where the grid divides), 2 (default) by that rule
+            static const int xmap_env = [] { const char *e = getenv("GA_GEMM_XMAP"); return e ? atoi(e) : 2; }();
             GemmP pr = p;
             {
                 const unsigned gx = ring == 2 ? (unsigned)((a->N + 63) / 64) : (ring == 3 ? (unsigned)((a->N + 63) / 64) : 1u);
                 const unsigned gy = ring == 2 ? (unsigned)((a->M + 95) / 96) : (ring == 3 ? (unsigned)((a->M + 63) / 64) : 1u);
-                if (xmap_env && ring != 1 && a->epilogue == GA_GEMM_EPI_RESIDUAL && gx % 2 == 0 && gy % 4 == 0 && (gx * gy) % 8 == 0) pr.xmap = 1;
+                const bool pays = xmap_env == 1 || (xmap_env == 2 && (gx % 8 != 0 || gx * gy > 256));
+                if (pays && ring != 1 && a->epilogue == GA_GEMM_EPI_RESIDUAL && gx % 2 == 0 && gy % 4 == 0 && (gx * gy) % 8 == 0) pr.xmap = 1;
             }
 #define GA_RLAUNCH(E)                                                                                                     \
             if (ring == 1)                                                                                                \
