@@ -1025,8 +1025,13 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
         // lie in one batch item
         const bool per_batch = a->bias_stride != 0 || a->emit_scale != nullptr;
         const bool rows48 = !per_batch || a->rows_per_batch % 48 == 0, rows16 = !per_batch || a->rows_per_batch % 16 == 0;
+        // round 6: 96 x 128, four waves of 48 x 64 (the wave tile of the 192 x 128 kernel): for the wide projections at 768 rows, whose 96 x 64
+        // grid is 1.5 - 2 workgroups per CU (qkv 384, fc1 512) while this one is 192 / 256 with 30 % fewer operand bytes on the busiest CU
+        static const int ring4_env = [] { const char *e = getenv("GA_GEMM_RING4"); return e ? atoi(e) : 0; }();
+        const long long wg_96x128 = (long long)((a->N + 127) / 128) * ((a->M + 95) / 96);
         if (nk % 4 == 0 && nk >= 8) {
             if (wg_big >= 160 && rows48) ring = 1;
+            else if (ring4_env && a->epilogue != GA_GEMM_EPI_STORE_F32 && wg_96x128 >= 160 && wg_96x128 <= 256 && rows48) ring = 4;
             // (per-head norm on the 96 x 64 tile: its two 32-column waves exchange their sums through LDS, a barrier more than the
             //  64-column waves of the other tiles need -- worth it while the grid is one residency round, 2 x 256 workgroups:
             //  DiT-L's qkv at M = 768 13.4 -> 12.1 us; DiT-B's at M = 1536, 576 workgroups, is faster on 64 x 64, same-box A/B)
@@ -1064,7 +1069,11 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
                 if (pays && ring != 1 && a->epilogue == GA_GEMM_EPI_RESIDUAL && gx % 2 == 0 && gy % 4 == 0 && (gx * gy) % 8 == 0) pr.xmap = 1;
             }
 #define GA_RLAUNCH(E)                                                                                                     \
-            if (ring == 1)                                                                                                \
+            if (ring == 4) {                                                                                              \
+                if (hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 2, 2, 3, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 224 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
+                hipLaunchKernelGGL((gemm_ring_kernel<E, 2, 2, 3, 4, 4, 2>), dim3((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 95) / 96)), \
+                                   dim3(256), 4 * 224 * BK * 2, s, p);                                                    \
+            } else if (ring == 1)                                                                                                \
                 hipLaunchKernelGGL((gemm_ring_kernel<E, 4, 2, 3, 4, 4, 2>), dim3((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 191) / 192)), \
                                    dim3(512), 4 * 320 * BK * 2, s, p);                                                    \
             else if (ring == 2)                                                                                           \
