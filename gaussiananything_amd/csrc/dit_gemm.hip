@@ -1017,9 +1017,13 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
     }
     {
         const int nk = a->K / BK;
-        const long long wg_big = (long long)((a->N + 127) / 128) * ((a->M + 191) / 192);
-        const long long wg_mid = (long long)((a->N + 63) / 64) * ((a->M + 95) / 96);
-        const long long wg_small = (long long)((a->N + 63) / 64) * ((a->M + 63) / 64);
+        // (k_rows: only the first k_rows rows carry a product -- the tile is chosen for THOSE workgroups; the rows behind them are quick.
+        //  GA_GEMM_KROWS_TILE=0: by all M rows as before, A/B aid)
+        static const bool krows_tile = [] { const char *e = getenv("GA_GEMM_KROWS_TILE"); return !e || atoi(e) != 0; }();
+        const int Mw = (p.k_rows && krows_tile) ? p.k_rows : a->M;
+        const long long wg_big = (long long)((a->N + 127) / 128) * ((Mw + 191) / 192);
+        const long long wg_mid = (long long)((a->N + 63) / 64) * ((Mw + 95) / 96);
+        const long long wg_small = (long long)((a->N + 63) / 64) * ((Mw + 63) / 64);
         int ring = 0;
         // per-batch operands (bias rows, emit multipliers) are requested once per wave in the ring kernels: a wave's 48 (16) rows must
         // lie in one batch item
@@ -1027,7 +1031,8 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
         const bool rows48 = !per_batch || a->rows_per_batch % 48 == 0, rows16 = !per_batch || a->rows_per_batch % 16 == 0;
         // round 6: 96 x 128, four waves of 48 x 64 (the wave tile of the 192 x 128 kernel): for the wide projections at 768 rows, whose 96 x 64
         // grid is 1.5 - 2 workgroups per CU (qkv 384, fc1 512) while this one is 192 / 256 with 30 % fewer operand bytes on the busiest CU
-        static const int ring4_env = [] { const char *e = getenv("GA_GEMM_RING4"); return e ? atoi(e) : 0; }();
+        // same-box A/B (profiles/r6_ring4_ab.txt): DiT-L on the conditional sequence alone 2.376 -> 2.315 ms per evaluation, nothing else moves.  GA_GEMM_RING4=0: off
+        static const int ring4_env = [] { const char *e = getenv("GA_GEMM_RING4"); return e ? atoi(e) : 1; }();
         const long long wg_96x128 = (long long)((a->N + 127) / 128) * ((a->M + 95) / 96);
         if (nk % 4 == 0 && nk >= 8) {
             if (wg_big >= 160 && rows48) ring = 1;
