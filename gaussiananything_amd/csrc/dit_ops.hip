@@ -843,8 +843,10 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
                 pf.ptr[5] = reinterpret_cast<const char *>(bw.fc1_w); pf.bytes[5] = 8u * DD;
             }
         }
-        if (i == 0 && sb_tail0) {
-            ShiftBiasJob job{{bw.qkv_w, bw.fc1_w}, {bw.qkv_b, bw.fc1_b}, w.mod, w.sbias,
+        // GA_DIT_SB_ON_CA=1 (experiment): EVERY block's shift rows behind its own cross-attention grid (as block 0's), none behind the self-attention
+        static const bool sb_on_ca = [] { const char *e = getenv("GA_DIT_SB_ON_CA"); return e && atoi(e) != 0; }();
+        if ((i == 0 || sb_on_ca) && sb_tail0) {
+            ShiftBiasJob job{{bw.qkv_w, bw.fc1_w}, {bw.qkv_b, bw.fc1_b}, w.mod + (size_t)i * B * 6 * D, w.sbias + (size_t)i * B * 7 * D,
                              6 * (long long)D, 3 * (long long)D, 3 * D, 4 * D, D, B, m->gemm_weights_tiled};
             GA_UNLESS(2, attention_with_tail(&ca, &job, stream, pf_ca ? &pf : nullptr, pf_ca));
         } else if (pf_ca)
@@ -880,7 +882,8 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         gqkv.splitk_ws = w.splitk; gqkv.splitk_ws_bytes = (int64_t)w.splitk_bytes;
         GA_UNLESS(16, ga_gemm_bf16(&gqkv, stream));
         GaAttentionArgs sa{B, m->heads, L, L, w.qkv, w.qkv + D, w.vt, 2 * D, 2 * D, Lp, nullptr, nullptr, w.att, D};
-        if (fold_mod && sb_tail && i + 1 < m->depth) {
+        static const bool sb_on_ca2 = [] { const char *e = getenv("GA_DIT_SB_ON_CA"); return e && atoi(e) != 0; }();
+        if (fold_mod && sb_tail && i + 1 < m->depth && !(sb_on_ca2 && sb_tail0)) {
             const GaDitBlockWeights &nb = m->blocks[i + 1];
             ShiftBiasJob job{{nb.qkv_w, nb.fc1_w}, {nb.qkv_b, nb.fc1_b}, w.mod + (size_t)(i + 1) * B * 6 * D, w.sbias + (size_t)(i + 1) * B * 7 * D,
                              6 * (long long)D, 3 * (long long)D, 3 * D, 4 * D, D, B, m->gemm_weights_tiled};
