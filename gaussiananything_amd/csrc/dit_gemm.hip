@@ -1071,7 +1071,7 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
                 const bool pays = xmap_env == 1 || (xmap_env == 2 && (gx % 8 != 0 || gx * gy > 256));
                 if (pays && ring != 1 && a->epilogue == GA_GEMM_EPI_RESIDUAL && gx % 2 == 0 && gy % 4 == 0 && (gx * gy) % 8 == 0) pr.xmap = 1;
             }
-            static const bool pipe2_env = [] { const char *e = getenv("GA_GEMM_PIPE2"); return e && atoi(e) != 0; }();   // experiment: k-step pipeline on the 96 x 64 tile
+            // (round 6: the k-step software pipeline of the 192 x 128 kernel on the 96 x 64 tile measured 1.5 - 2 % slower per evaluation: not kept)
 #define GA_RLAUNCH(E)                                                                                                     \
             if (ring == 4) {                                                                                              \
                 if (hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 2, 2, 3, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 224 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
@@ -1080,11 +1080,7 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
             } else if (ring == 1)                                                                                                \
                 hipLaunchKernelGGL((gemm_ring_kernel<E, 4, 2, 3, 4, 4, 2>), dim3((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 191) / 192)), \
                                    dim3(512), 4 * 320 * BK * 2, s, p);                                                    \
-            else if (ring == 2 && pipe2_env) {                                                                            \
-                if (hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 2, 2, 3, 2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 160 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
-                hipLaunchKernelGGL((gemm_ring_kernel<E, 2, 2, 3, 2, 4, 2>), dim3((unsigned)((a->N + 63) / 64), (unsigned)((a->M + 95) / 96)), \
-                                   dim3(256), 4 * 160 * BK * 2, s, pr);                                                   \
-            } else if (ring == 2)                                                                                         \
+            else if (ring == 2)                                                                                           \
                 hipLaunchKernelGGL((gemm_ring_kernel<E, 2, 2, 3, 2, 4, 0>), dim3((unsigned)((a->N + 63) / 64), (unsigned)((a->M + 95) / 96)), \
                                    dim3(256), 4 * 160 * BK * 2, s, pr);                                                   \
             else                                                                                                          \

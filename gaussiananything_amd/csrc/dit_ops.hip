@@ -838,13 +838,20 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
                     pf.bytes[5] = (unsigned)((size_t)ca_batch * D * Mp_ * 2 / 1024 * 1024);
                 }
             }
+            if (pf_mode == 4 && i + 1 == m->depth) {   // the next evaluation's conditioning chain: adaLN (12 MB at D = 1024) and the timestep MLP
+                pf.ptr[4] = reinterpret_cast<const char *>(m->adaln_w); pf.bytes[4] = 12u * DD;
+                pf.ptr[5] = reinterpret_cast<const char *>(m->t_mlp2_w); pf.bytes[5] = 2u * DD;
+            }
             if (pf_mode >= 6) {   // this block's qkv and fc1 weights once more (the shift rows' pass over them was a block ago)
                 pf.ptr[4] = reinterpret_cast<const char *>(bw.qkv_w); pf.bytes[4] = 6u * DD;
                 pf.ptr[5] = reinterpret_cast<const char *>(bw.fc1_w); pf.bytes[5] = 8u * DD;
             }
         }
-        // GA_DIT_SB_ON_CA=1 (experiment): EVERY block's shift rows behind its own cross-attention grid (as block 0's), none behind the self-attention
-        static const bool sb_on_ca = [] { const char *e = getenv("GA_DIT_SB_ON_CA"); return e && atoi(e) != 0; }();
+        // round 6: EVERY block's shift rows ride behind its own cross-attention grid (as block 0's since round 5), none behind the self-attention
+        // grid of the block before: the CA grid idles the same 64 CUs for 21 us instead of 13, and the weights the rows' pass pulls in are
+        // used two and five launches later.  Same-box A/B (profiles/r6_sb_on_ca_ab.txt): batch 1 2.332 -> 2.272 ms per evaluation, CFG batch 2
+        // 2.879 -> 2.864; GA_DIT_SB_ON_CA=0: the round-4 placement
+        static const bool sb_on_ca = [] { const char *e = getenv("GA_DIT_SB_ON_CA"); return !e || atoi(e) != 0; }();
         if ((i == 0 || sb_on_ca) && sb_tail0) {
             ShiftBiasJob job{{bw.qkv_w, bw.fc1_w}, {bw.qkv_b, bw.fc1_b}, w.mod + (size_t)i * B * 6 * D, w.sbias + (size_t)i * B * 7 * D,
                              6 * (long long)D, 3 * (long long)D, 3 * D, 4 * D, D, B, m->gemm_weights_tiled};
@@ -882,7 +889,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         gqkv.splitk_ws = w.splitk; gqkv.splitk_ws_bytes = (int64_t)w.splitk_bytes;
         GA_UNLESS(16, ga_gemm_bf16(&gqkv, stream));
         GaAttentionArgs sa{B, m->heads, L, L, w.qkv, w.qkv + D, w.vt, 2 * D, 2 * D, Lp, nullptr, nullptr, w.att, D};
-        static const bool sb_on_ca2 = [] { const char *e = getenv("GA_DIT_SB_ON_CA"); return e && atoi(e) != 0; }();
+        static const bool sb_on_ca2 = [] { const char *e = getenv("GA_DIT_SB_ON_CA"); return !e || atoi(e) != 0; }();
         if (fold_mod && sb_tail && i + 1 < m->depth && !(sb_on_ca2 && sb_tail0)) {
             const GaDitBlockWeights &nb = m->blocks[i + 1];
             ShiftBiasJob job{{nb.qkv_w, nb.fc1_w}, {nb.qkv_b, nb.fc1_b}, w.mod + (size_t)(i + 1) * B * 6 * D, w.sbias + (size_t)(i + 1) * B * 7 * D,
