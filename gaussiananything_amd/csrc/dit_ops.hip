@@ -838,11 +838,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
                     pf.bytes[5] = (unsigned)((size_t)ca_batch * D * Mp_ * 2 / 1024 * 1024);
                 }
             }
-            static const bool pf_head = [] { const char *e = getenv("GA_DIT_PF_HEAD"); return !e || atoi(e) != 0; }();   // (A/B aid)
-            if (pf_mode == 4 && pf_head && i + 1 == m->depth) {   // the next evaluation's conditioning chain: adaLN (12 MB at D = 1024) and the timestep MLP
-                pf.ptr[4] = reinterpret_cast<const char *>(m->adaln_w); pf.bytes[4] = 12u * DD;
-                pf.ptr[5] = reinterpret_cast<const char *>(m->t_mlp2_w); pf.bytes[5] = 2u * DD;
-            }
+            // (the next evaluation's conditioning-chain weights -- adaLN 12 MB, timestep MLP -- behind the last block's grid: measured, no gain)
             if (pf_mode >= 6) {   // this block's qkv and fc1 weights once more (the shift rows' pass over them was a block ago)
                 pf.ptr[4] = reinterpret_cast<const char *>(bw.qkv_w); pf.bytes[4] = 6u * DD;
                 pf.ptr[5] = reinterpret_cast<const char *>(bw.fc1_w); pf.bytes[5] = 8u * DD;
