@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libga_mi355.so")
 GA_OK = 0
 GA_STATUS_NUM_RENDERED, GA_STATUS_OVERFLOW, GA_STATUS_MAX_TILE, GA_STATUS_WORDS = 0, 1, 2, 16
 GA_STATUS_SEG_WORK = 9
-GA_SURFEL_FLAG_STATS, GA_SURFEL_FLAG_WORKSPACE_CLEAN, GA_SURFEL_FLAG_SPLIT_WALK = 1, 2, 4
+GA_SURFEL_FLAG_STATS, GA_SURFEL_FLAG_WORKSPACE_CLEAN, GA_SURFEL_FLAG_SPLIT_WALK, GA_SURFEL_FLAG_BG_IN_BLEND = 1, 2, 4, 8
 GA_SEG_EPOCH_WORD = 96   # csrc/surfel_common.h: kSegEpochWord
 GA_SURFEL_RECORD_FLOATS = 24
 GA_SURFEL_STAGE_EVENTS = 5

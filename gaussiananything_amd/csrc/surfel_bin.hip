@@ -992,7 +992,9 @@ __global__ __launch_bounds__(256) void surfel_run_sort_kernel(const uint4 *__res
                                                               const int64_t *__restrict__ status,
                                                               uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_cursor,
                                                               unsigned long long *__restrict__ view_total, int nviews,
-                                                              uint32_t *__restrict__ seg_sync, unsigned long long *__restrict__ dbg)
+                                                              uint32_t *__restrict__ seg_sync, unsigned long long *__restrict__ dbg,
+                                                              Dims dm, const float *__restrict__ bg, float *__restrict__ out_color,
+                                                              float *__restrict__ out_others)
 {
     __shared__ __attribute__((aligned(16))) double s[kSortCap];  // raw key bits (see bitonic_sort_blocked)
     const int tid = threadIdx.x;
@@ -1034,6 +1036,31 @@ __global__ __launch_bounds__(256) void surfel_run_sort_kernel(const uint4 *__res
         const uint32_t beg = rec.y;
         const int n = (int)rec.z;
         GA_STAMP_N(n < kWaveSort ? n : -2);
+        if (!overflow && n == 0 && out_color != nullptr) {
+            // Round 6: an EMPTY tile has no list to sort -- its wave writes the tile's background pixels (colour = bg, the seven allmap
+            // channels 0: what the blend's fresh pixel gives, bit for bit) here, where the launch is latency-bound and the memory
+            // system idle, instead of a blend workgroup doing it at the end of the blend.  Lane -> row lane >> 2, pixels 4 (lane & 3) ..
+            const int v = (int)(rec.x / (uint32_t)dm.tiles), tile = (int)(rec.x - (uint32_t)v * dm.tiles);
+            const int px = (tile % dm.gx) * kTile + 4 * (lane & 3), py = (tile / dm.gx) * kTile + (lane >> 2);
+            if (py < dm.H && px < dm.W) {
+                const size_t HW = (size_t)dm.H * dm.W, pid = (size_t)py * dm.W + px;
+                float *oc = out_color + (size_t)v * 3 * HW + pid, *oo = out_others + (size_t)v * 7 * HW + pid;
+                const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+                if (px + 3 < dm.W && (dm.W & 3) == 0 && (HW & 3) == 0) {   // 16-byte stores: whole 64-byte tile rows per four lanes
+                    *reinterpret_cast<float4 *>(oc) = make_float4(b0, b0, b0, b0);
+                    *reinterpret_cast<float4 *>(oc + HW) = make_float4(b1, b1, b1, b1);
+                    *reinterpret_cast<float4 *>(oc + 2 * HW) = make_float4(b2, b2, b2, b2);
+#pragma unroll
+                    for (int c = 0; c < 7; ++c) *reinterpret_cast<float4 *>(oo + (size_t)c * HW) = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    for (int e = 0; e < 4 && px + e < dm.W; ++e) {
+                        oc[e] = b0; oc[HW + e] = b1; oc[2 * HW + e] = b2;
+                        for (int c = 0; c < 7; ++c) oo[(size_t)c * HW + e] = 0.f;
+                    }
+                }
+            }
+            return;
+        }
         if (overflow || n <= 0 || n >= kWaveSort) return;
         if (n == 1) { if (lane == 0) point_list[beg] = (uint32_t)keys[beg]; return; }
         if (n <= 64) wave_sort_list<1>(keys, point_list, beg, n, lane);
@@ -1116,7 +1143,8 @@ void launch_tile_sort(const GaSurfelForwardArgs &a, const Dims &d, const Workspa
     const uint32_t max_big = (uint32_t)std::min<int64_t>(nt, a.capacity / kSortCap);
     hipLaunchKernelGGL(surfel_run_sort_kernel, dim3(max_extra + nbig + (nt + 3) / 4 + (max_big + max_extra) * kMergeParts), dim3(256), 0, s,
                        ws.tile_order, ws.run_table, max_extra, nbig, nt, ws.keys, ws.point_list, ws.status, ws.tile_count, ws.tile_cursor,
-                       ws.view_total, d.V, ws.seg_sync, reinterpret_cast<unsigned long long *>(ws.depth));
+                       ws.view_total, d.V, ws.seg_sync, reinterpret_cast<unsigned long long *>(ws.depth), d, a.bg,
+                       (a.flags & GA_SURFEL_FLAG_BG_IN_BLEND) ? nullptr : a.out_color, a.out_others);
 }
 
 }  // namespace ga

@@ -1129,6 +1129,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
         const uint32_t pos = tslot;
         if (pos < nlong) return;
         if (my_sched.z == 0) {   // empty list (more than half of the tiles at BASELINE configs[1]): background pixels, nothing else
+            if (!(k.flags & GA_SURFEL_FLAG_BG_IN_BLEND)) return;   // (round 6: written by the sort launch's waves, surfel_bin.hip)
             const int v = (int)(my_sched.x / (uint32_t)dm.tiles), tile = (int)(my_sched.x - (uint32_t)v * dm.tiles);
             const int pxi = (tile % dm.gx) * kTile + (wave & 1) * 8 + (lane & 7), pyi = (tile / dm.gx) * kTile + (wave >> 1) * 8 + (lane >> 3);
             if (pxi < dm.W && pyi < dm.H) write_pixel(fresh_pixel(1.0f), k.bg, dm, v, pxi, pyi, k.out_color, k.out_others);

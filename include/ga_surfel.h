@@ -105,6 +105,9 @@ typedef struct GaSurfelForwardArgs {
 #define GA_SURFEL_FLAG_SPLIT_WALK 4  /* blend unsegmented lists with the SPLIT walk (evaluate with lanes = (entry, pixel) pairs, composite
                                        with lanes = pixels; surfel_blend.hip) instead of the fused lanes = pixels walk.  Built, parity
                                        green and measured in round 4 -- 175 us against 140 us on BASELINE configs[1] -- hence opt-in */
+#define GA_SURFEL_FLAG_BG_IN_BLEND 8  /* round 6, A/B aid: the background pixels of the EMPTY tiles (two thirds of the tiles at BASELINE configs[1]:
+                                         56 MB of stores) are written by the blend launch's own workgroups as in rounds 1-5; default: by the
+                                         otherwise idle waves of the per-tile sort launch in front of it, whose lists those tiles do not have */
 
 /* Byte offsets of the workspace sections (all 256-byte aligned).  Tests read the integer artefacts
  * (rect, tile ranges, sorted point list) straight out of the workspace through these offsets. */
