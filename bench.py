@@ -656,7 +656,8 @@ def summary_of(out):
     if out.get("stage_ms"):
         sm["stage_us"] = {k[:4]: round(v * 1e3, 1) for k, v in out["stage_ms"].items()}
     if out.get("roofline"):
-        sm["blend"] = {"hbm_frac": out["roofline"]["frac"], "valu_issue": out["roofline"].get("valu_issue_frac"),
+        sm["blend"] = {"hbm_frac": out["roofline"]["frac"], "hbm_frac_all_px": out["roofline"].get("frac_all_pixels"),
+                       "valu_issue": out["roofline"].get("valu_issue_frac"),
                        "valu_Minsts": None if not out["roofline"].get("valu_wave_instructions_per_launch") else
                        round(out["roofline"]["valu_wave_instructions_per_launch"] / 1e6, 1),
                        "traffic_MB": None if not out["roofline"].get("traffic") else round(out["roofline"]["traffic"] / 1e6, 1)}
@@ -866,7 +867,17 @@ def main():
         }
         if stage is not None:
             P = H * W
-            blend_bytes = 76.0 * int(st[0]) + 40.0 * P * v      # per launch (all V views), SURVEY.md 8d
+            # per launch (all V views), SURVEY.md 8d: 76 B per list entry + 40 B per pixel THE BLEND LAUNCH WRITES.  Since round 6 the pixels of
+            # the empty tiles (background only) are written by the sort launch in front of it (GA_SURFEL_FLAG_BG_IN_BLEND restores the old
+            # placement): they are not counted for this kernel any more -- `algorithmic_bytes_all_pixels` / `frac_all_pixels` keep the
+            # earlier rounds' accounting (all P pixels) beside it
+            tiles_v = ((W + 15) // 16) * ((H + 15) // 16)
+            tstart = plan.ws.section("tile_start", torch.int32, v * tiles_v + 1).cpu().numpy().astype(np.int64)
+            nonempty = int((np.diff(tstart) > 0).sum())
+            bg_in_blend = bool(plan.flags & 8)
+            px_blend = P * v if bg_in_blend else min(P * v, nonempty * 256)
+            blend_bytes_all = 76.0 * int(st[0]) + 40.0 * P * v
+            blend_bytes = 76.0 * int(st[0]) + 40.0 * px_blend
             achieved = blend_bytes / (stage["blend"] * 1e-3) / 1e9
             traffic, tsrc, valu_frac, valu_insts = None, None, None, None  # PMC counters cannot be collected live: committed rocprofv3 passes
             pj = committed_pmc("blend_pmc.json") if (a.scene == "surface" and n == 100_000 and v == 8 and H == 512) else None
@@ -880,6 +891,8 @@ def main():
                                "valu_issue_frac": valu_frac, "valu_wave_instructions_per_launch": valu_insts,
                                "valu_issue_frac_is": "SQ_INSTS_VALU x 4 cycles / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs (committed PMC pass)",
                                "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": int(blend_bytes),
+                               "algorithmic_bytes_all_pixels": int(blend_bytes_all), "frac_all_pixels": round(blend_bytes_all / (stage["blend"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                               "nonempty_tiles": nonempty, "pixels_written_by_the_blend": int(px_blend),
                                "avg_launch_ms": round(stage["blend"], 5),
                                "launch_duration_source": "HIP events on the launch stream, separate untimed pass of the same forwards",
                                "note": "achieved / peak: algorithmic HBM bytes of the blend against the HBM roof (SURVEY.md 8d); the binding roof is "
