@@ -68,6 +68,7 @@ struct GemmP {  // by-value kernel parameters (kept flat: no pointer into the ar
     // (gridDim.x / 2) x (gridDim.y / 4) block of output tiles instead of every 8th column of tiles: for the N = 1024 GEMMs, whose
     // activation operand is larger than the weight, an XCD's L2 then serves 7 of 8 reads of an activation tile instead of 1 of 2
     int xmap;
+    int wt;      // (experiment) write-through output stores
 };
 
 // Element offset of chunk c (8 bf16) of weight row n at K-tile 0, and the stride from one K-tile to the next: row-major
@@ -83,6 +84,17 @@ __device__ __forceinline__ void glds16(const uint16_t *gsrc, uint16_t *lds_wave_
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// Round-6 experiment (GemmP.wt, GA_GEMM_WT): output stores as agent-scope write-through (sc1) -- nothing is dirty in the L2 when the kernel ends
+__device__ __forceinline__ void st16(void *dst, uint4 v, int wt)
+{
+    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v));
+    else *reinterpret_cast<uint4 *>(dst) = v;
+}
+__device__ __forceinline__ void st16f(float4 *dst, float4 v, int wt)
+{
+    st16(dst, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)), wt);
 }
 
 // exact-GELU's erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of the result): ~14 VALU
@@ -342,7 +354,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[FN][M
                 uint16_t *dst = static_cast<uint16_t *>(p.out) + (size_t)m * p.ldo + n;
                 const uint2 lo = make_uint2(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]));
                 const uint2 hi2 = make_uint2(pack_bf16x2(w[4], w[5]), pack_bf16x2(w[6], w[7]));
-                if (hi && (p.ldo & 7) == 0) *reinterpret_cast<uint4 *>(dst) = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+                if (hi && (p.ldo & 7) == 0) st16(dst, make_uint4(lo.x, lo.y, hi2.x, hi2.y), p.wt);
                 else {
                     *reinterpret_cast<uint2 *>(dst) = lo;
                     if (hi) *reinterpret_cast<uint2 *>(dst + 4) = hi2;
@@ -369,8 +381,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[FN][M
                         xn[e] = x0[e] + g0[e] * w[e];
                         xn[4 + e] = hi ? x1[e] + g1[e] * w[4 + e] : 0.f;
                     }
-                    dst[0] = make_float4(xn[0], xn[1], xn[2], xn[3]);
-                    if (hi) dst[1] = make_float4(xn[4], xn[5], xn[6], xn[7]);
+                    st16f(dst, make_float4(xn[0], xn[1], xn[2], xn[3]), p.wt);
+                    if (hi) st16f(dst + 1, make_float4(xn[4], xn[5], xn[6], xn[7]), p.wt);
                     if (p.emit_x) {  // kernel-uniform; N % 64 == 0, so `hi` holds
 #pragma unroll
                         for (int e = 0; e < 8; ++e) emit_acc += xn[e] * xn[e];
@@ -387,9 +399,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[FN][M
                             xn[0] *= w0.x * (1.f + s0.x); xn[1] *= w0.y * (1.f + s0.y); xn[2] *= w0.z * (1.f + s0.z); xn[3] *= w0.w * (1.f + s0.w);
                             xn[4] *= w1.x * (1.f + s1.x); xn[5] *= w1.y * (1.f + s1.y); xn[6] *= w1.z * (1.f + s1.z); xn[7] *= w1.w * (1.f + s1.w);
                         }
-                        *reinterpret_cast<uint4 *>(p.emit_x + (size_t)m * p.emit_ld + n) =
-                            make_uint4(pack_bf16x2(xn[0], xn[1]), pack_bf16x2(xn[2], xn[3]), pack_bf16x2(xn[4], xn[5]),
-                                       pack_bf16x2(xn[6], xn[7]));
+                        st16(p.emit_x + (size_t)m * p.emit_ld + n,
+                             make_uint4(pack_bf16x2(xn[0], xn[1]), pack_bf16x2(xn[2], xn[3]), pack_bf16x2(xn[4], xn[5]),
+                                        pack_bf16x2(xn[6], xn[7])), p.wt);
                     }
                 } else {
                     dst[0] = make_float4(w[0], w[1], w[2], w[3]);
@@ -943,7 +955,7 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
                   a->qk_cols1, a->emit_x, a->emit_ss, a->emit_ld, a->row_ss, a->row_ss_tiles,
                   a->row_ss_dim > 0 ? 1.0f / (float)a->row_ss_dim : 0.f, a->row_ss_eps, a->w_tiled ? 1 : 0,
                   a->emit_w, a->emit_scale, a->emit_scale_stride, a->bias_stride, a->k_rows == a->M ? 0 : a->k_rows,
-                  0, nullptr, nullptr, 0};
+                  0, nullptr, nullptr, 0, []{ static const int v = [] { const char *e = getenv("GA_GEMM_WT"); return e ? atoi(e) : 0; }(); return v; }()};
     // Tile / ring choice (256 CUs).  A workgroup tile is 128 weight rows x 32 MT activation rows (MT = 4, 3, 2, 1); its work is
     // proportional to MT plus a tile-independent share (prologue, weight tile, epilogue: about one MT unit, tools/gemm_sweep.py) and
     // the launch ends with the busiest CU, so the cost of a choice is ceil(workgroups / 256) * (MT + 1)
