@@ -89,8 +89,11 @@ __device__ __forceinline__ void glds16(const uint16_t *gsrc, uint16_t *lds_wave_
 // Round-6 experiment (GemmP.wt, GA_GEMM_WT): output stores as agent-scope write-through (sc1) -- nothing is dirty in the L2 when the kernel ends
 __device__ __forceinline__ void st16(void *dst, uint4 v, int wt)
 {
-    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v));
-    else *reinterpret_cast<uint4 *>(dst) = v;
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    if (wt) {
+        const u32x4_t q = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(q));
+    } else *reinterpret_cast<uint4 *>(dst) = v;
 }
 __device__ __forceinline__ void st16f(float4 *dst, float4 v, int wt)
 {
