@@ -68,7 +68,7 @@ struct GemmP {  // by-value kernel parameters (kept flat: no pointer into the ar
     // (gridDim.x / 2) x (gridDim.y / 4) block of output tiles instead of every 8th column of tiles: for the N = 1024 GEMMs, whose
     // activation operand is larger than the weight, an XCD's L2 then serves 7 of 8 reads of an activation tile instead of 1 of 2
     int xmap;
-    int wt;      // (experiment) write-through output stores
+    int wt;      // write-through output stores (st16)
 };
 
 // Element offset of chunk c (8 bf16) of weight row n at K-tile 0, and the stride from one K-tile to the next: row-major
@@ -86,7 +86,8 @@ __device__ __forceinline__ void glds16(const uint16_t *gsrc, uint16_t *lds_wave_
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-// Round-6 experiment (GemmP.wt, GA_GEMM_WT): output stores as agent-scope write-through (sc1) -- nothing is dirty in the L2 when the kernel ends
+// Round 6 (GemmP.wt, GA_GEMM_WT): output stores as agent-scope write-through (sc1) -- the tile's rows leave for the memory side while the
+// other workgroups still compute, and nothing is dirty in the L2 when the kernel ends
 __device__ __forceinline__ void st16(void *dst, uint4 v, int wt)
 {
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -958,7 +959,12 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
                   a->qk_cols1, a->emit_x, a->emit_ss, a->emit_ld, a->row_ss, a->row_ss_tiles,
                   a->row_ss_dim > 0 ? 1.0f / (float)a->row_ss_dim : 0.f, a->row_ss_eps, a->w_tiled ? 1 : 0,
                   a->emit_w, a->emit_scale, a->emit_scale_stride, a->bias_stride, a->k_rows == a->M ? 0 : a->k_rows,
-                  0, nullptr, nullptr, 0, []{ static const int v = [] { const char *e = getenv("GA_GEMM_WT"); return e ? atoi(e) : 0; }(); return v; }()};
+                  0, nullptr, nullptr, 0, 0};
+    {   // write-through output stores (st16): same-box A/B (profiles/r6_wt_ab.txt) DiT-L at CFG batch 2 2.730 -> 2.691 ms per evaluation, DiT-B
+        // 1.244 -> 1.234, batch 1 -0.3 %, CFG batch 4 +0.4 %: on for the one-round grids.  GA_GEMM_WT: 0 off, 1 always, 2 (default) M <= 2048
+        static const int wt_env = [] { const char *e = getenv("GA_GEMM_WT"); return e ? atoi(e) : 2; }();
+        const_cast<GemmP &>(p).wt = wt_env == 1 || (wt_env == 2 && a->M <= 2048);
+    }
     // Tile / ring choice (256 CUs).  A workgroup tile is 128 weight rows x 32 MT activation rows (MT = 4, 3, 2, 1); its work is
     // proportional to MT plus a tile-independent share (prologue, weight tile, epilogue: about one MT unit, tools/gemm_sweep.py) and
     // the launch ends with the busiest CU, so the cost of a choice is ceil(workgroups / 256) * (MT + 1)
