@@ -954,7 +954,7 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
         return GA_DIT_ERR_BAD_SHAPE;
     if (a->bias_stride && (!a->bias || a->rows_per_batch <= 0 || a->bias_stride % 4 != 0 || a->bias_stride < a->N)) return GA_DIT_ERR_BAD_SHAPE;
     if (a->k_rows && (a->epilogue != GA_GEMM_EPI_RESIDUAL || a->k_rows < 0 || a->k_rows > a->M)) return GA_DIT_ERR_BAD_SHAPE;
-    const GemmP p{a->M, a->N, a->K, a->rows_per_batch, a->A, a->W, a->bias, a->gate, a->out, a->lda, a->ldo, a->gate_stride,
+    GemmP p{a->M, a->N, a->K, a->rows_per_batch, a->A, a->W, a->bias, a->gate, a->out, a->lda, a->ldo, a->gate_stride,
                   a->vt, a->vt_col0, a->vt ? (a->N - a->vt_col0) / 64 : 0, a->vt_ld, a->qk_w0, a->qk_w1, a->qk_cols0,
                   a->qk_cols1, a->emit_x, a->emit_ss, a->emit_ld, a->row_ss, a->row_ss_tiles,
                   a->row_ss_dim > 0 ? 1.0f / (float)a->row_ss_dim : 0.f, a->row_ss_eps, a->w_tiled ? 1 : 0,
@@ -963,7 +963,7 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
     {   // write-through output stores (st16): same-box A/B (profiles/r6_wt_ab.txt) DiT-L at CFG batch 2 2.730 -> 2.691 ms per evaluation, DiT-B
         // 1.244 -> 1.234, batch 1 -0.3 %, CFG batch 4 +0.4 %: on for the one-round grids.  GA_GEMM_WT: 0 off, 1 always, 2 (default) M <= 2048
         static const int wt_env = [] { const char *e = getenv("GA_GEMM_WT"); return e ? atoi(e) : 2; }();
-        const_cast<GemmP &>(p).wt = wt_env == 1 || (wt_env == 2 && a->M <= 2048);
+        p.wt = wt_env == 1 || (wt_env == 2 && a->M <= 2048);
     }
     // Tile / ring choice (256 CUs).  A workgroup tile is 128 weight rows x 32 MT activation rows (MT = 4, 3, 2, 1); its work is
     // proportional to MT plus a tile-independent share (prologue, weight tile, epilogue: about one MT unit, tools/gemm_sweep.py) and
