@@ -244,10 +244,7 @@ __global__ __launch_bounds__(256) void surfel_preprocess_kernel(
                     const int q = lane + 64 * j;
                     if (q < nq) {
                         typedef float v4f __attribute__((ext_vector_type(4)));
-                        if (nt == 2) {        // (round 6 experiment) agent-scope write-through: leaves the L2 at once, still lands in the Infinity Cache
-                            const v4f val = *reinterpret_cast<const v4f *>(wstage + q);
-                            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + q), "v"(val));
-                        } else if (nt) __builtin_nontemporal_store(*reinterpret_cast<const v4f *>(wstage + q), reinterpret_cast<v4f *>(dst + q));
+                        if (nt) __builtin_nontemporal_store(*reinterpret_cast<const v4f *>(wstage + q), reinterpret_cast<v4f *>(dst + q));
                         else dst[q] = wstage[q];
                     }
                 }
