@@ -91,7 +91,6 @@ struct AttnTail {
     PrefetchJob pf;      // every tail workgroup takes its share (after its shift-bias part, if it has one)
     int nwgs;            // tail workgroups in all
     int pf_on;
-    int wt;              // write-through output stores (GA_ATTN_WT)
 };
 
 template <int NW, int KS, bool KNORM>
@@ -562,9 +561,7 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
 #pragma unroll
         for (int df = 0; df < 4; ++df) {
             const uint2 p = make_uint2(pack_bf16x2(o[df][0] * inv, o[df][1] * inv), pack_bf16x2(o[df][2] * inv, o[df][3] * inv));
-            if (tail.wt)   // (round 6) write-through: see st16 in dit_gemm.hip
-                __hip_atomic_store(reinterpret_cast<unsigned long long *>(op + df * 16), ((unsigned long long)p.y << 32) | p.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else *reinterpret_cast<uint2 *>(op + df * 16) = p;
+            *reinterpret_cast<uint2 *>(op + df * 16) = p;
         }
     }
 }
@@ -583,8 +580,6 @@ static void launch_attention(const GaAttentionArgs &a, hipStream_t s, const Shif
     dim3 grid((a.Lq + rows - 1) / rows, a.heads, a.batch);
 #endif
     AttnTail tail{};
-    static const int wt_env = [] { const char *e = getenv("GA_ATTN_WT"); return e ? atoi(e) : 0; }();
-    tail.wt = wt_env;
     if (pf && pf_wgs > 0) { tail.pf = *pf; tail.pf_on = 1; } else pf_wgs = 0;
     if (job || pf_wgs) {
         if (job) tail.job = *job;
