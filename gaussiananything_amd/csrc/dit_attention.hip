@@ -53,9 +53,6 @@ constexpr int TILE = KB * HD;  // elements of one staged tile (8 KiB)
 #ifndef GA_ATTN_HEAD_MAJOR
 #define GA_ATTN_HEAD_MAJOR 1
 #endif
-#ifndef GA_ATTN_SETPRIO
-#define GA_ATTN_SETPRIO 0   // round 6 experiment: raise the wave priority around the two MFMA clusters of a tile
-#endif
 #ifndef GA_ATTN_ABLATE
 #define GA_ATTN_ABLATE 0   // tools/attn_ablate.sh builds timing-only variants with phases removed (wrong results)
 #endif
@@ -407,17 +404,11 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
         const float nm = -m_run;
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) s[kf] = f32x4{nm, nm, nm, nm};
-#if GA_ATTN_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
                 if (GA_ATTN_ABLATE != 2) s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag[kf][kk], qf[kk], s[kf], 0, 0, 0);
-#if GA_ATTN_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         __builtin_amdgcn_sched_barrier(0);
         STAMP(3);
         // the next-but-one tile's DMA is requested here, behind the head of the step's dependency chain (K fragments ->
@@ -476,18 +467,12 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
         // ---- O^T += V^T P^T : o[df][r] = O[q = c16][d = df*16 + g*4 + r]; the lane's 8 P of block kb are keys 32 kb + 8 g ..
         __builtin_amdgcn_sched_barrier(0);
         STAMP(5);
-#if GA_ATTN_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int df = 0; df < 4; ++df)
                 if (GA_ATTN_ABLATE != 1) o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag[df][kb], pf[kb], o[df], 0, 0, 0);
                 else o[df][0] += __builtin_bit_cast(float, (int)frag[df][kb][0] ^ (int)pf[kb][0]);
-#if GA_ATTN_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         __builtin_amdgcn_sched_barrier(0);
         STAMP(6);
     };
