@@ -1069,15 +1069,19 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
         //  = 192 of the 192 x 128 tile, 36 KB per K-tile instead of 40 -- measured the same to the microsecond, same-box A/B
         //  2.72 / 2.72 ms per evaluation: not kept)
         if (ring) {
-            static bool ring_attr_set = false;
-            if (!ring_attr_set) {
+            // (the LDS opt-in belongs to the function ON ONE DEVICE: one flag per device, set by whichever thread gets there -- idempotent)
+            static std::atomic<bool> ring_attr_dev[64];
+            int dev_ = 0;
+            (void)hipGetDevice(&dev_);
+            std::atomic<bool> &ring_attr_set = ring_attr_dev[dev_ >= 0 && dev_ < 64 ? dev_ : 63];
+            if (!ring_attr_set.load(std::memory_order_acquire) || dev_ >= 64) {
 #define GA_RATTR(E)                                                                                                       \
                 (void)hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 4, 2, 3, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 320 * BK * 2); \
                 (void)hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 2, 2, 3, 2, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 160 * BK * 2); \
                 (void)hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 4, 1, 1, 4, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * BK * 2);
                 GA_RATTR(0) GA_RATTR(1) GA_RATTR(2) GA_RATTR(3)
 #undef GA_RATTR
-                ring_attr_set = true;
+                ring_attr_set.store(true, std::memory_order_release);
             }
             // tile -> XCD blocking for the residual GEMMs on the 96 x 64 / 64 x 64 tiles (GemmP.xmap).  Same-box A/B (profiles/r6_xmap_ab.txt):
             // it pays where the natural dealing is ragged or the grid is more than one round -- DiT-B (12 tile columns: an XCD's
@@ -1131,8 +1135,11 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
 #ifdef GA_TUNING  // tuning builds only: GA_GEMM_CFG = 10 * MT + ring slots
     if (const char *e = getenv("GA_GEMM_CFG")) { const int c = atoi(e); if (c / 10 >= 1 && c / 10 <= 4 && (c % 10 == 2 || c % 10 == 4)) { mt = c / 10; nst = c % 10; } }
 #endif
-    static bool attr_set = false;
-    if (!attr_set) {  // > 64 KiB of dynamic LDS has to be opted into once per kernel
+    static std::atomic<bool> attr_dev[64];
+    int dev2_ = 0;
+    (void)hipGetDevice(&dev2_);
+    std::atomic<bool> &attr_set = attr_dev[dev2_ >= 0 && dev2_ < 64 ? dev2_ : 63];
+    if (!attr_set.load(std::memory_order_acquire) || dev2_ >= 64) {  // > 64 KiB of dynamic LDS has to be opted into once per kernel and device
 #define GA_ATTR(E)                                                                                                  \
         (void)hipFuncSetAttribute((const void *)gemm_bf16_kernel<E, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   4 * (BN + 128) * BK * 2);                                                          \
@@ -1144,7 +1151,7 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
                                   4 * (BN + 32) * BK * 2);
         GA_ATTR(0) GA_ATTR(1) GA_ATTR(2) GA_ATTR(3)
 #undef GA_ATTR
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
 #define GA_LAUNCH_MT(E, NSTV, MTV)                                                                                   \
     hipLaunchKernelGGL((gemm_bf16_kernel<E, NSTV, MTV>), dim3((unsigned)ncols, (unsigned)((a->M + 32 * MTV - 1) / (32 * MTV))), \
