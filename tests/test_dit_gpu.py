@@ -985,3 +985,42 @@ def test_fused_euler_step_without_guidance_equals_eager_loop(gpu_device, stage, 
         with torch.no_grad():
             outs[flag] = fn(x, model.forward_cond, context=c, cfg_scale=z["cfg_scale"])
     assert torch.equal(outs["0"], outs["1"]) and sampler.last_ode.last_stats.get("fused")
+
+
+def test_weight_prefetch_and_tail_placement_are_bit_neutral(gpu_device):
+    """Round 6: the weight prefetch by the idle workgroups of the cross-attention launch (GA_DIT_PREFETCH), the placement of the shift
+    rows behind each block's own cross-attention grid (GA_DIT_SB_ON_CA), the tile -> XCD blocking (GA_GEMM_XMAP) and the write-through
+    output stores (GA_GEMM_WT) change where and when bytes move, never a result: a DiT-B-shaped model (12 tile columns: the blocking
+    applies) evaluated in fresh processes with everything off and everything on gives the same bits.  (The switches are read once per
+    process, hence the subprocesses.)"""
+    import subprocess
+    import sys
+    code = """
+import hashlib, sys, torch
+sys.path.insert(0, %r)
+from gaussiananything_amd.dit import DiT_I23D_PCD_PixelArt_noclip
+torch.manual_seed(0)
+m = DiT_I23D_PCD_PixelArt_noclip(input_size=16, patch_size=1, in_channels=3, hidden_size=768, depth=3, num_heads=12, num_classes=0, learn_sigma=False,
+                                 context_dim=1024, pooling_ctx_dim=768, roll_out=True, use_clay_ca=True)
+g = torch.Generator().manual_seed(1)
+with torch.no_grad():
+    for p in m.parameters():
+        if float(p.abs().max()) == 0.0:
+            p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+x = torch.randn(2, 768, 3, generator=g); t = torch.tensor([0.4, 0.4])
+ctx = {"img_crossattn": torch.randn(2, 1369, 1024, generator=g), "img_vector": torch.randn(2, 1024, generator=g)}
+ctx["img_crossattn"][1] = 0; ctx["img_vector"][1] = 0
+m.cuda()
+with torch.no_grad():
+    y = m.forward_with_cfg(x.cuda(), t.cuda(), {k: v.cuda() for k, v in ctx.items()}, 4.0)
+    y1 = m.forward(x[:1].cuda(), t[:1].cuda(), {k: v[:1].cuda() for k, v in ctx.items()})
+print(hashlib.sha256(y.cpu().numpy().tobytes() + y1.cpu().numpy().tobytes()).hexdigest())
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hashes = []
+    for env in ({"GA_DIT_PREFETCH": "0", "GA_DIT_SB_ON_CA": "0", "GA_GEMM_XMAP": "0", "GA_GEMM_WT": "0"},
+                {"GA_DIT_PREFETCH": "4", "GA_DIT_SB_ON_CA": "1", "GA_GEMM_XMAP": "1", "GA_GEMM_WT": "1"}, {}):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        hashes.append(out.stdout.strip().splitlines()[-1])
+    assert hashes[0] == hashes[1] == hashes[2], hashes
+

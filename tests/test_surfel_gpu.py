@@ -473,6 +473,35 @@ def test_render_levels_overlapped_on_two_streams_equals_one_render_per_set(gpu_d
     assert key in dsr._ws_cache and dsr._ws_cache[key].capacity > dsr.default_capacity(2500, 6)     # it did overflow and grow
 
 
+def test_background_of_empty_tiles_written_by_the_sort_launch_is_bit_identical(gpu_device):
+    """Round 6: the background pixels of the empty tiles come from the waves of the per-tile sort launch that find an empty list
+    (surfel_bin.hip) instead of from blend workgroups; GA_SURFEL_FLAG_BG_IN_BLEND restores the old placement.  Same bits, on a scene
+    that leaves most tiles empty, with ragged image sizes (16-byte and scalar store paths), a clean and a reused workspace."""
+    from gaussiananything_amd import _lib
+    from gaussiananything_amd.diff_surfel_rasterization import SurfelForwardPlan
+    cams = synthetic.eval_cameras(3)
+    g = synthetic.random_surfels(400, seed=4)[0]
+    g[:, :3] = g[:, :3] * 0.3 + 0.1                      # a small object: most of the image is background
+    m, o, s, r, c = [t.to(gpu_device) for t in synthetic.split_gaussians(g)]
+    bg = torch.tensor([0.25, 0.5, 0.75], device=gpu_device)
+    for H, W in ((256, 256), (130, 250), (33, 17)):
+        outs = []
+        for flags in (0, _lib.GA_SURFEL_FLAG_BG_IN_BLEND):
+            plan = SurfelForwardPlan(m, o, c, s, r, cams["cam_view"].to(gpu_device), cams["cam_view_proj"].to(gpu_device), bg, H, W, flags=flags)
+            for _ in range(2):                            # second run: GA_SURFEL_FLAG_WORKSPACE_CLEAN
+                plan.color.fill_(-7.0)
+                plan.allmap.fill_(-7.0)
+                plan.run()
+            torch.cuda.synchronize()
+            outs.append((plan.color.clone(), plan.allmap.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (H, W)
+        assert float(outs[0][0].min()) >= 0.0 and float((outs[0][1] == -7.0).sum()) == 0      # every pixel written
+        bgpix = (outs[0][1][:, 1] == 0)                   # alpha exactly 0: background
+        assert int(bgpix.sum()) > 0.5 * bgpix.numel()
+        for ch in range(3):
+            assert torch.equal(outs[0][0][:, ch][bgpix], torch.full_like(outs[0][0][:, ch][bgpix], float(bg[ch])))
+
+
 def test_postprocess_kernel_exact(gpu_device):
     """ga_surfel_postprocess against the torch formulation of nsr/gs_surfel.py:121-163, NaN / inf / out-of-range included,
     image sizes with and without the 16-byte path; batch of two through the renderer."""
