@@ -242,36 +242,66 @@ struct EmbedArgs {
     float *xres;
 };
 
+// Round 6: kET tokens per workgroup.  One token per workgroup re-read the whole [D, 63] positional-embedding weight (258 KB) per token
+// with a stride of 63 floats between lanes -- 30 us for the 768 tokens of a stage-2 evaluation (11 without the xyz branch).  Now the
+// weight is staged 128 rows at a time through LDS (coalesced reads of the contiguous rows, stored transposed: conflict-free reads with
+// lanes = output columns) and serves kET tokens; the sums run over the features in the same order as before (same bits).
+constexpr int kET = 4;
 __global__ __launch_bounds__(256) void embed_tokens_kernel(EmbedArgs a)
 {
-    __shared__ float sx[16];
-    __shared__ float spe[64];
-    const int m = blockIdx.x;
-    if (threadIdx.x < a.C) sx[threadIdx.x] = bf16_to_f32(f32_to_bf16(a.x[(size_t)m * a.C + threadIdx.x]));  // autocast
-    if (a.stage2 && threadIdx.x < 63) {
+    __shared__ float sx[kET][16];
+    __shared__ float spe[kET][64];
+    __shared__ float wt[63][129];          // [feature][row of the 128-row weight tile] (+1: the transposing stores spread over the banks)
+    const int tid = threadIdx.x, m0 = blockIdx.x * kET;
+    for (int i = tid; i < kET * 16; i += 256) {
+        const int t = i >> 4, c = i & 15, m = m0 + t;
+        sx[t][c] = (c < a.C && m < a.M) ? bf16_to_f32(f32_to_bf16(a.x[(size_t)m * a.C + c])) : 0.f;  // autocast
+    }
+    if (a.stage2) {
         // [x, sin(2^k x), cos(2^k x)]_{k=0..9}: index 3 + 6k + {0..2 sin, 3..5 cos}
-        const int j = threadIdx.x;
-        float v;
-        if (j < 3) v = a.xyz[(size_t)m * 3 + j];
-        else {
-            const int k = (j - 3) / 6, r = (j - 3) % 6, c = r % 3;
-            const float arg = a.xyz[(size_t)m * 3 + c] * (float)(1 << k);
-            v = r < 3 ? sinf(arg) : cosf(arg);
+        const int t = tid >> 6, j = tid & 63, m = m0 + t;
+        float v = 0.f;
+        if (j < 63 && m < a.M) {
+            if (j < 3) v = a.xyz[(size_t)m * 3 + j];
+            else {
+                const int k = (j - 3) / 6, r = (j - 3) % 6, c = r % 3;
+                const float arg = a.xyz[(size_t)m * 3 + c] * (float)(1 << k);
+                v = r < 3 ? sinf(arg) : cosf(arg);
+            }
         }
-        spe[j] = bf16_to_f32(f32_to_bf16(v));
+        spe[t][j] = bf16_to_f32(f32_to_bf16(v));
     }
     __syncthreads();
-    for (int n = threadIdx.x; n < a.D; n += 256) {
-        float acc = a.b1[n];
-        for (int c = 0; c < a.C; ++c) acc += sx[c] * bf16_to_f32(f32_to_bf16(a.w1[(size_t)n * a.C + c]));
-        const float u = 0.7978845608028654f * (acc + 0.044715f * acc * acc * acc);
-        a.h[(size_t)m * a.D + n] = f32_to_bf16(0.5f * acc * (1.0f + tanhf(u)));
-        float r = 0.f;
+    const int nl = tid & 127, th = tid >> 7;          // my column inside a 128-column tile; my tokens: th and th + 2
+    for (int n0 = 0; n0 < a.D; n0 += 128) {
+        const int n = n0 + nl;
         if (a.stage2) {
-            r = a.bx[n];
-            for (int j = 0; j < 63; ++j) r += spe[j] * bf16_to_f32(f32_to_bf16(a.wx[(size_t)n * 63 + j]));
+            __syncthreads();                          // (the previous tile has been read)
+            const int rows = min(128, a.D - n0), cnt = rows * 63;
+            const float *src = a.wx + (size_t)n0 * 63;
+            for (int i = tid; i < cnt; i += 256) {
+                const int r = i / 63, j = i - r * 63;
+                wt[j][r] = bf16_to_f32(f32_to_bf16(src[i]));
+            }
+            __syncthreads();
         }
-        a.xres[(size_t)m * a.D + n] = r;
+        if (n < a.D) {
+#pragma unroll
+            for (int q = 0; q < kET / 2; ++q) {
+                const int t = th + 2 * q, m = m0 + t;
+                if (m >= a.M) continue;
+                float acc = a.b1[n];
+                for (int c = 0; c < a.C; ++c) acc += sx[t][c] * bf16_to_f32(f32_to_bf16(a.w1[(size_t)n * a.C + c]));
+                const float u = 0.7978845608028654f * (acc + 0.044715f * acc * acc * acc);
+                a.h[(size_t)m * a.D + n] = f32_to_bf16(0.5f * acc * (1.0f + tanhf(u)));
+                float r = 0.f;
+                if (a.stage2) {
+                    r = a.bx[n];
+                    for (int j = 0; j < 63; ++j) r += spe[t][j] * wt[j][nl];
+                }
+                a.xres[(size_t)m * a.D + n] = r;
+            }
+        }
     }
 }
 
@@ -307,7 +337,7 @@ __device__ __forceinline__ float euler_update(float y, float dt, float v)
     return y + p;
 }
 
-__device__ __forceinline__ void final_layer_row(const FinalArgs &a, int row, int lane, float (&res)[16])
+__device__ __forceinline__ void final_layer_row(const FinalArgs &a, int row, int lane, float (&res)[16], const float *wl = nullptr)
 {
     const int D = a.D, b = row / a.rows_per_batch;
     const float *x = a.x + (size_t)row * D, *tb = a.t + (size_t)b * D;
@@ -358,9 +388,14 @@ __device__ __forceinline__ void final_layer_row(const FinalArgs &a, int row, int
 #pragma unroll
             for (int o = 0; o < 16; ++o)
                 if (o < a.Cout) {
-                    const float4 w4 = *reinterpret_cast<const float4 *>(a.w + (size_t)o * D + d);
-                    acc[o] += y[0] * bf16_to_f32(f32_to_bf16(w4.x)) + y[1] * bf16_to_f32(f32_to_bf16(w4.y)) +
-                              y[2] * bf16_to_f32(f32_to_bf16(w4.z)) + y[3] * bf16_to_f32(f32_to_bf16(w4.w));
+                    if (wl) {      // (round 6) the weight rows, already rounded to bf16, from the workgroup's LDS image
+                        const float4 w4 = *reinterpret_cast<const float4 *>(wl + (size_t)o * D + d);
+                        acc[o] += y[0] * w4.x + y[1] * w4.y + y[2] * w4.z + y[3] * w4.w;
+                    } else {
+                        const float4 w4 = *reinterpret_cast<const float4 *>(a.w + (size_t)o * D + d);
+                        acc[o] += y[0] * bf16_to_f32(f32_to_bf16(w4.x)) + y[1] * bf16_to_f32(f32_to_bf16(w4.y)) +
+                                  y[2] * bf16_to_f32(f32_to_bf16(w4.z)) + y[3] * bf16_to_f32(f32_to_bf16(w4.w));
+                    }
                 }
         }
     }
@@ -368,13 +403,28 @@ __device__ __forceinline__ void final_layer_row(const FinalArgs &a, int row, int
     for (int o = 0; o < 16; ++o) res[o] = o < a.Cout ? wave_sum(acc[o]) + a.bias[o] : 0.f;
 }
 
-__global__ __launch_bounds__(256) void final_layer_kernel(FinalArgs a)
+// Round 6: the Cout x D weight (fp32, rounded to bf16 as the autocast Linear does) is staged once per workgroup into LDS when it fits the
+// launch's dynamic allocation: every wave read all of it from the L2 before, Cout dependent round trips per 256 columns -- 26 us for the
+// 768 rows x 10 channels of a stage-2 evaluation.  Same products, same order: same bits.
+__global__ __launch_bounds__(256) void final_layer_kernel(FinalArgs a, int w_in_lds)
 {
+    extern __shared__ __attribute__((aligned(16))) float wlds[];
+    const float *wl = nullptr;
+    if (w_in_lds) {   // kernel-uniform
+        const int n4 = a.Cout * a.D / 4;
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            const float4 w4 = reinterpret_cast<const float4 *>(a.w)[i];
+            reinterpret_cast<float4 *>(wlds)[i] = make_float4(bf16_to_f32(f32_to_bf16(w4.x)), bf16_to_f32(f32_to_bf16(w4.y)),
+                                                             bf16_to_f32(f32_to_bf16(w4.z)), bf16_to_f32(f32_to_bf16(w4.w)));
+        }
+        __syncthreads();
+        wl = wlds;
+    }
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (a.state == nullptr) {
         if (row >= a.M) return;
         float r[16];
-        final_layer_row(a, row, lane, r);
+        final_layer_row(a, row, lane, r, wl);
         if (lane < a.Cout) {
             float mine = 0.f;
 #pragma unroll
@@ -391,7 +441,7 @@ __global__ __launch_bounds__(256) void final_layer_kernel(FinalArgs a)
     if (a.cfg) {
         const int w = threadIdx.x >> 6, pair = w & 1, role = w >> 1, r2 = blockIdx.x * 2 + pair;
         const bool have = r2 < half;
-        if (have) final_layer_row(a, r2 + role * half, lane, v);
+        if (have) final_layer_row(a, r2 + role * half, lane, v, wl);
         if (role == 1 && have && lane < 16) {
             float mine = 0.f;
 #pragma unroll
@@ -404,7 +454,7 @@ __global__ __launch_bounds__(256) void final_layer_kernel(FinalArgs a)
         for (int o = 0; o < 16; ++o) v[o] = cfg_combine(v[o], twin[pair][o], a.cfg_scale);
     } else {
         if (row >= half) return;
-        final_layer_row(a, row, lane, v);
+        final_layer_row(a, row, lane, v, wl);
     }
     const int rowc = a.cfg ? blockIdx.x * 2 + ((threadIdx.x >> 6) & 1) : row;   // my row of the (conditional) half
     if (lane < a.Cout) {
@@ -732,7 +782,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     {
         EmbedArgs e{Mrows, D, m->in_channels, m->stage2, a->x, m->xe_fc1_w, m->xe_fc1_b, a->fps_xyz, m->xyz_w, m->xyz_b,
                     w.xn, w.xres};
-        hipLaunchKernelGGL(embed_tokens_kernel, dim3(Mrows), dim3(256), 0, s, e);
+        hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)((Mrows + kET - 1) / kET)), dim3(256), 0, s, e);
         GaGemmArgs g{};
         g.M = Mrows; g.N = D; g.K = D; g.epilogue = GA_GEMM_EPI_RESIDUAL; g.A = w.xn; g.lda = D; g.W = m->xe_fc2_w; g.w_tiled = m->gemm_weights_tiled;
         g.bias = m->xe_fc2_b; g.out = w.xres; g.ldo = D; g.gate = nullptr; g.rows_per_batch = L;
@@ -943,7 +993,9 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
             rows = st->cfg ? Mrows / 2 : Mrows;
         }
         // (with CFG a workgroup serves two rows of the conditional half: two waves each for the rows and their unconditional twins)
-        hipLaunchKernelGGL(final_layer_kernel, dim3(a->step && a->step->cfg ? (rows + 1) / 2 : (rows + 3) / 4), dim3(256), 0, s, f);
+        const size_t wbytes = (size_t)m->out_channels * D * sizeof(float);
+        const int w_in_lds = wbytes <= 60 * 1024 ? 1 : 0;      // (the default dynamic LDS limit; beyond it the rows read the weight from the L2 as before)
+        hipLaunchKernelGGL(final_layer_kernel, dim3(a->step && a->step->cfg ? (rows + 1) / 2 : (rows + 3) / 4), dim3(256), w_in_lds ? wbytes : 0, s, f, w_in_lds);
     }
     return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
 }
