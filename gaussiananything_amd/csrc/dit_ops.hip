@@ -242,66 +242,68 @@ struct EmbedArgs {
     float *xres;
 };
 
-// Round 6: kET tokens per workgroup.  One token per workgroup re-read the whole [D, 63] positional-embedding weight (258 KB) per token
-// with a stride of 63 floats between lanes -- 30 us for the 768 tokens of a stage-2 evaluation (11 without the xyz branch).  Now the
-// weight is staged 128 rows at a time through LDS (coalesced reads of the contiguous rows, stored transposed: conflict-free reads with
-// lanes = output columns) and serves kET tokens; the sums run over the features in the same order as before (same bits).
-constexpr int kET = 4;
+// Round 6: a workgroup = kET tokens x one 128-column tile of the outputs (grid: token groups x column tiles).  One token per workgroup
+// re-read the whole [D, 63] positional-embedding weight (258 KB) per token with a stride of 63 floats between lanes -- 30 us for the 768
+// tokens of a stage-2 evaluation.  Now a tile's 128 weight rows are staged once through LDS (coalesced reads of the contiguous rows,
+// stored transposed: conflict-free reads with lanes = output columns) and serve kET tokens; the sums run over the features in the same
+// order as before (same bits).  (Four tokens x all D columns per workgroup -- 192 workgroups, eight tiles each -- measured 61 us: too
+// few waves for a chain of staging rounds.)
+constexpr int kET = 8;
 __global__ __launch_bounds__(256) void embed_tokens_kernel(EmbedArgs a)
 {
     __shared__ float sx[kET][16];
     __shared__ float spe[kET][64];
     __shared__ float wt[63][129];          // [feature][row of the 128-row weight tile] (+1: the transposing stores spread over the banks)
-    const int tid = threadIdx.x, m0 = blockIdx.x * kET;
-    for (int i = tid; i < kET * 16; i += 256) {
-        const int t = i >> 4, c = i & 15, m = m0 + t;
+    const int tid = threadIdx.x, m0 = blockIdx.x * kET, n0 = blockIdx.y * 128;
+    if (tid < kET * 16) {
+        const int t = tid >> 4, c = tid & 15, m = m0 + t;
         sx[t][c] = (c < a.C && m < a.M) ? bf16_to_f32(f32_to_bf16(a.x[(size_t)m * a.C + c])) : 0.f;  // autocast
     }
     if (a.stage2) {
         // [x, sin(2^k x), cos(2^k x)]_{k=0..9}: index 3 + 6k + {0..2 sin, 3..5 cos}
-        const int t = tid >> 6, j = tid & 63, m = m0 + t;
-        float v = 0.f;
-        if (j < 63 && m < a.M) {
-            if (j < 3) v = a.xyz[(size_t)m * 3 + j];
-            else {
-                const int k = (j - 3) / 6, r = (j - 3) % 6, c = r % 3;
-                const float arg = a.xyz[(size_t)m * 3 + c] * (float)(1 << k);
-                v = r < 3 ? sinf(arg) : cosf(arg);
+        for (int i = tid; i < kET * 64; i += 256) {
+            const int t = i >> 6, j = i & 63, m = m0 + t;
+            float v = 0.f;
+            if (j < 63 && m < a.M) {
+                if (j < 3) v = a.xyz[(size_t)m * 3 + j];
+                else {
+                    const int k = (j - 3) / 6, r = (j - 3) % 6, c = r % 3;
+                    const float arg = a.xyz[(size_t)m * 3 + c] * (float)(1 << k);
+                    v = r < 3 ? sinf(arg) : cosf(arg);
+                }
             }
+            spe[t][j] = bf16_to_f32(f32_to_bf16(v));
         }
-        spe[t][j] = bf16_to_f32(f32_to_bf16(v));
+        const int rows = min(128, a.D - n0), cnt = rows * 63;
+        const float *src = a.wx + (size_t)n0 * 63;
+        for (int i = tid; i < cnt; i += 256) {
+            const int r = i / 63, j = i - r * 63;
+            wt[j][r] = bf16_to_f32(f32_to_bf16(src[i]));
+        }
     }
     __syncthreads();
-    const int nl = tid & 127, th = tid >> 7;          // my column inside a 128-column tile; my tokens: th and th + 2
-    for (int n0 = 0; n0 < a.D; n0 += 128) {
-        const int n = n0 + nl;
-        if (a.stage2) {
-            __syncthreads();                          // (the previous tile has been read)
-            const int rows = min(128, a.D - n0), cnt = rows * 63;
-            const float *src = a.wx + (size_t)n0 * 63;
-            for (int i = tid; i < cnt; i += 256) {
-                const int r = i / 63, j = i - r * 63;
-                wt[j][r] = bf16_to_f32(f32_to_bf16(src[i]));
-            }
-            __syncthreads();
-        }
-        if (n < a.D) {
+    const int nl = tid & 127, th = tid >> 7, n = n0 + nl;          // my column; my tokens: th, th + 2, th + 4, th + 6
+    if (n >= a.D) return;
+    float w1r[16];
 #pragma unroll
-            for (int q = 0; q < kET / 2; ++q) {
-                const int t = th + 2 * q, m = m0 + t;
-                if (m >= a.M) continue;
-                float acc = a.b1[n];
-                for (int c = 0; c < a.C; ++c) acc += sx[t][c] * bf16_to_f32(f32_to_bf16(a.w1[(size_t)n * a.C + c]));
-                const float u = 0.7978845608028654f * (acc + 0.044715f * acc * acc * acc);
-                a.h[(size_t)m * a.D + n] = f32_to_bf16(0.5f * acc * (1.0f + tanhf(u)));
-                float r = 0.f;
-                if (a.stage2) {
-                    r = a.bx[n];
-                    for (int j = 0; j < 63; ++j) r += spe[t][j] * wt[j][nl];
-                }
-                a.xres[(size_t)m * a.D + n] = r;
-            }
+    for (int c = 0; c < 16; ++c) w1r[c] = c < a.C ? bf16_to_f32(f32_to_bf16(a.w1[(size_t)n * a.C + c])) : 0.f;
+    const float b1n = a.b1[n], bxn = a.stage2 ? a.bx[n] : 0.f;
+#pragma unroll
+    for (int q = 0; q < kET / 2; ++q) {
+        const int t = th + 2 * q, m = m0 + t;
+        if (m >= a.M) continue;
+        float acc = b1n;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < a.C) acc += sx[t][c] * w1r[c];
+        const float u = 0.7978845608028654f * (acc + 0.044715f * acc * acc * acc);
+        a.h[(size_t)m * a.D + n] = f32_to_bf16(0.5f * acc * (1.0f + tanhf(u)));
+        float r = 0.f;
+        if (a.stage2) {
+            r = bxn;
+            for (int j = 0; j < 63; ++j) r += spe[t][j] * wt[j][nl];
         }
+        a.xres[(size_t)m * a.D + n] = r;
     }
 }
 
@@ -782,7 +784,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     {
         EmbedArgs e{Mrows, D, m->in_channels, m->stage2, a->x, m->xe_fc1_w, m->xe_fc1_b, a->fps_xyz, m->xyz_w, m->xyz_b,
                     w.xn, w.xres};
-        hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)((Mrows + kET - 1) / kET)), dim3(256), 0, s, e);
+        hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)((Mrows + kET - 1) / kET), (unsigned)((D + 127) / 128)), dim3(256), 0, s, e);
         GaGemmArgs g{};
         g.M = Mrows; g.N = D; g.K = D; g.epilogue = GA_GEMM_EPI_RESIDUAL; g.A = w.xn; g.lda = D; g.W = m->xe_fc2_w; g.w_tiled = m->gemm_weights_tiled;
         g.bias = m->xe_fc2_b; g.out = w.xres; g.ldo = D; g.gate = nullptr; g.rows_per_batch = L;
