@@ -1052,14 +1052,11 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
         // grid is 1.5 - 2 workgroups per CU (qkv 384, fc1 512) while this one is 192 / 256 with 30 % fewer operand bytes on the busiest CU
         // same-box A/B (profiles/r6_ring4_ab.txt): DiT-L on the conditional sequence alone 2.376 -> 2.315 ms per evaluation, nothing else moves.  GA_GEMM_RING4=0: off
         static const int ring4_env = [] { const char *e = getenv("GA_GEMM_RING4"); return e ? atoi(e) : 1; }();
-        static const int ring5_env = [] { const char *e = getenv("GA_GEMM_RING5"); return e ? atoi(e) : 0; }();
+        // (a 48 x 64 two-wave tile that would give the N = 1024 residual GEMMs at 768 rows 256 workgroups instead of 192 measured 3 % slower per evaluation: not kept)
         const long long wg_96x128 = (long long)((a->N + 127) / 128) * ((a->M + 95) / 96);
         if (nk % 4 == 0 && nk >= 8) {
             if (wg_big >= 160 && rows48) ring = 1;
             else if (ring4_env && a->epilogue != GA_GEMM_EPI_STORE_F32 && wg_96x128 >= 160 && wg_96x128 <= 256 && rows48) ring = 4;
-            // (experiment, GA_GEMM_RING5=1) 48 x 64, two waves: the N = 1024 residual GEMMs at 768 rows as 256 workgroups instead of 192 of 64 x 64
-            else if (ring5_env && a->epilogue == GA_GEMM_EPI_RESIDUAL && wg_mid < 160 && rows48 &&
-                     (long long)((a->N + 63) / 64) * ((a->M + 47) / 48) >= 224 && (long long)((a->N + 63) / 64) * ((a->M + 47) / 48) <= 256) ring = 5;
             // (per-head norm on the 96 x 64 tile: its two 32-column waves exchange their sums through LDS, a barrier more than the
             //  64-column waves of the other tiles need -- worth it while the grid is one residency round, 2 x 256 workgroups:
             //  DiT-L's qkv at M = 768 13.4 -> 12.1 us; DiT-B's at M = 1536, 576 workgroups, is faster on 64 x 64, same-box A/B)
@@ -1101,11 +1098,6 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
                 if (pays && ring != 1 && a->epilogue == GA_GEMM_EPI_RESIDUAL && gx % 2 == 0 && gy % 4 == 0 && (gx * gy) % 8 == 0) pr.xmap = 1;
             }
             // (round 6: the k-step software pipeline of the 192 x 128 kernel on the 96 x 64 tile measured 1.5 - 2 % slower per evaluation: not kept)
-            if (ring == 5) {   // EPI 2 only
-                if (hipFuncSetAttribute((const void *)gemm_ring_kernel<2, 1, 2, 3, 2, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 112 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH;
-                hipLaunchKernelGGL((gemm_ring_kernel<2, 1, 2, 3, 2, 4, 0>), dim3((unsigned)((a->N + 63) / 64), (unsigned)((a->M + 47) / 48)), dim3(128), 4 * 112 * BK * 2, s, p);
-                return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
-            }
 #define GA_RLAUNCH(E)                                                                                                     \
             if (ring == 4) {                                                                                              \
                 if (hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 2, 2, 3, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 224 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
