@@ -736,16 +736,19 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     static const bool sb_tail_env = [] { const char *e = getenv("GA_DIT_SBTAIL"); return !e || atoi(e) != 0; }();
     // the shift rows of block i + 1 ride behind the self-attention grid of block i while that grid leaves CUs idle (a CFG pair: 192
     // workgroups + 56 of the tail on 256 CUs); on a full grid they would queue behind it (8 items: 9.2 -> 9.8 ms) -- one launch up front then
+    // compute units of the device the launches go to (the tails only ride where the attention grid leaves CUs idle): 256 on a whole MI355X,
+    // fewer in a partitioned mode; asked once per process
+    static const int ncu = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();
     bool sb_tail = false, sb_tail0 = false;
     const int ca_batch = (a->ca_batch <= 0 || a->ca_batch > B) ? B : a->ca_batch;
     if (fold_mod && sb_tail_env) {
         const GaAttentionArgs probe{B, m->heads, L, L, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0};
-        sb_tail = attention_workgroups(&probe) + shift_bias_wgs(3 * D, 4 * D) <= 256;
+        sb_tail = attention_workgroups(&probe) + shift_bias_wgs(3 * D, 4 * D) <= ncu;
         // round 5: block 0's rows ride the same way behind block 0's CROSS-attention grid (its qkv projection is the first consumer):
         // the stand-alone 12 us launch in front of the blocks is gone when that grid leaves the CUs free as well
         const GaAttentionArgs probe_ca{ca_batch, m->heads, L, a->ctx_tokens, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0};
         static const bool sb_tail0_env = [] { const char *e = getenv("GA_DIT_SBTAIL0"); return !e || atoi(e) != 0; }();   // A/B aid
-        sb_tail0 = sb_tail0_env && sb_tail && attention_workgroups(&probe_ca) + shift_bias_wgs(3 * D, 4 * D) <= 256;
+        sb_tail0 = sb_tail0_env && sb_tail && attention_workgroups(&probe_ca) + shift_bias_wgs(3 * D, 4 * D) <= ncu;
     }
     // Round 6: WEIGHT PREFETCH.  A GEMM whose weights sit in the Infinity Cache instead of HBM starts and streams faster (fc2 at 1536
     // rows 24.0 -> 21.1 us, at 768 rows 19.3 -> 15.7; fc1 18.0 -> 17.1; tools/warm_vs_cold.py), and every attention grid of a CFG pair
@@ -760,8 +763,8 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     if (hd == 64 && pf_mode > 0) {
         const GaAttentionArgs probe_sa{B, m->heads, L, L, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0};
         const GaAttentionArgs probe_ca{ca_batch, m->heads, L, a->ctx_tokens, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0};
-        pf_ca = std::max(0, 256 - attention_workgroups(&probe_ca));
-        pf_sa = std::max(0, 256 - attention_workgroups(&probe_sa));
+        pf_ca = std::min(64, std::max(0, ncu - attention_workgroups(&probe_ca)));
+        pf_sa = std::min(64, std::max(0, ncu - attention_workgroups(&probe_sa)));
         if (pf_ca < 16 || pf_mode == 2) pf_ca = 0;
         if (pf_sa < 16 || pf_mode != 2) pf_sa = 0;
     }
