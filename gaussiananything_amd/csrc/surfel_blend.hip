@@ -1094,6 +1094,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
     } stamp_exit{stamps, t_entry, lane};
 #endif
     if (blockIdx.x < seg_region) {
+#ifdef GA_BLEND_PROBE
+        if (GA_BLEND_PROBE == 2) return;
+#endif
         if (blockIdx.x >= segwork) return;   // more workgroups than work items: whole workgroups leave
         BlendArgs ks = k;
         ks.epoch = seg_table[kSegEpochWord];   // this launch's epoch (written by the tile scan, a kernel boundary ago)
@@ -1128,6 +1131,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GA_BLEND_WA
         // arrives); the slots of the segmented tiles lead the schedule and belong to the segment region
         const uint32_t pos = tslot;
         if (pos < nlong) return;
+#ifdef GA_BLEND_PROBE   // timing-only builds (wrong images): 1 = leave the tiles with lists of fewer than 512 entries out, 2 = only those
+        if (GA_BLEND_PROBE == 1 && my_sched.z > 0 && my_sched.z < 512) return;
+        if (GA_BLEND_PROBE == 2 && my_sched.z >= 512) return;
+#endif
         if (my_sched.z == 0) {   // empty list (more than half of the tiles at BASELINE configs[1]): background pixels, nothing else
             if (!(k.flags & GA_SURFEL_FLAG_BG_IN_BLEND)) return;   // (round 6: written by the sort launch's waves, surfel_bin.hip)
             const int v = (int)(my_sched.x / (uint32_t)dm.tiles), tile = (int)(my_sched.x - (uint32_t)v * dm.tiles);
