@@ -32,15 +32,14 @@ __global__ __launch_bounds__(256) void attention_hd_kernel(GaAttentionHdArgs a)
     constexpr int KB = 64, KROW = HDP + 8, VROW = KB + 8, NK = HDP / 32, ND = HDP / 16;
     // (round 6) two buffers each: tile t + 1 is requested into registers before tile t is multiplied and committed to the other buffer
     // after it -- the single-buffered first version had every global round trip on the critical path (49 us per launch at 16 heads of 72)
-    constexpr int NB = HDP <= 96 ? 2 : 1;       // (head dims above 96 keep one buffer: two would pass the 64 KiB of static LDS)
-    __shared__ __attribute__((aligned(16))) uint16_t Ks2[NB][KB * KROW];    // [key][d], d >= head_dim zero
-    __shared__ __attribute__((aligned(16))) uint16_t Vt2[NB][HDP * VROW];   // [d][key]
+    __shared__ __attribute__((aligned(16))) uint16_t Ks2[2][KB * KROW];    // [key][d], d >= head_dim zero
+    __shared__ __attribute__((aligned(16))) uint16_t Vt2[2][HDP * VROW];   // [d][key]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int hd = a.head_dim, cpr = hd >> 3;                          // 16-byte chunks per row
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64 + wave * 16;
     const int Lq = a.Lq, Lk = a.Lk;
-    for (int i = tid; i < NB * KB * KROW; i += 256) (&Ks2[0][0])[i] = 0;
-    for (int i = tid; i < NB * HDP * VROW; i += 256) (&Vt2[0][0])[i] = 0;
+    for (int i = tid; i < 2 * KB * KROW; i += 256) (&Ks2[0][0])[i] = 0;
+    for (int i = tid; i < 2 * HDP * VROW; i += 256) (&Vt2[0][0])[i] = 0;
 
     // Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + c16][kk*32 + g*8 .. +7] * head_dim^-1/2 * log2(e), zero beyond head_dim
     bf16x8 qf[NK];
@@ -103,15 +102,9 @@ __global__ __launch_bounds__(256) void attention_hd_kernel(GaAttentionHdArgs a)
     __syncthreads();                           // the zero fill is done
     commit(0);
     for (int t = 0; t < ntiles; ++t) {
-        if (NB == 2) {
-            if (t + 1 < ntiles) issue(t + 1);  // in flight while tile t is multiplied
-        } else if (t > 0) {
-            __syncthreads();                   // one buffer: everybody has left tile t - 1
-            issue(t);
-            commit(0);
-        }
-        __syncthreads();                       // tile t has been committed by everybody; (two buffers:) everybody has left tile t - 1
-        const uint16_t *Ks = Ks2[NB == 2 ? (t & 1) : 0], *Vt = Vt2[NB == 2 ? (t & 1) : 0];
+        if (t + 1 < ntiles) issue(t + 1);      // in flight while tile t is multiplied
+        __syncthreads();                       // tile t has been committed by everybody; everybody has left tile t - 1
+        const uint16_t *Ks = Ks2[t & 1], *Vt = Vt2[t & 1];
         // S^T = K Q^T : s[kf][r] <-> key 32 (kf >> 1) + 8 g + 4 (kf & 1) + r of the tile, query c16
         f32x4 s[4];
 #pragma unroll
@@ -157,7 +150,7 @@ __global__ __launch_bounds__(256) void attention_hd_kernel(GaAttentionHdArgs a)
                 const bf16x8 vfrag = *reinterpret_cast<const bf16x8 *>(Vt + (df * 16 + c16) * VROW + kb * 32 + g * 8);
                 o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pf[kb], o[df], 0, 0, 0);
             }
-        if (NB == 2 && t + 1 < ntiles) commit((t + 1) & 1);   // (its last readers passed this iteration's barrier after tile t - 1)
+        if (t + 1 < ntiles) commit((t + 1) & 1);   // (its last readers passed this iteration's barrier after tile t - 1)
     }
     float l = l_run;
     l += __shfl_xor(l, 16, 64);
