@@ -30,16 +30,14 @@ template <int HDP>
 __global__ __launch_bounds__(256) void attention_hd_kernel(GaAttentionHdArgs a)
 {
     constexpr int KB = 64, KROW = HDP + 8, VROW = KB + 8, NK = HDP / 32, ND = HDP / 16;
-    // (round 6) two buffers each: tile t + 1 is requested into registers before tile t is multiplied and committed to the other buffer
-    // after it -- the single-buffered first version had every global round trip on the critical path (49 us per launch at 16 heads of 72)
-    __shared__ __attribute__((aligned(16))) uint16_t Ks2[2][KB * KROW];    // [key][d], d >= head_dim zero
-    __shared__ __attribute__((aligned(16))) uint16_t Vt2[2][HDP * VROW];   // [d][key]
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[KB * KROW];    // [key][d], d >= head_dim zero
+    __shared__ __attribute__((aligned(16))) uint16_t Vt[HDP * VROW];   // [d][key]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int hd = a.head_dim, cpr = hd >> 3;                          // 16-byte chunks per row
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64 + wave * 16;
     const int Lq = a.Lq, Lk = a.Lk;
-    for (int i = tid; i < 2 * KB * KROW; i += 256) (&Ks2[0][0])[i] = 0;
-    for (int i = tid; i < 2 * HDP * VROW; i += 256) (&Vt2[0][0])[i] = 0;
+    for (int i = tid; i < KB * KROW; i += 256) Ks[i] = 0;
+    for (int i = tid; i < HDP * VROW; i += 256) Vt[i] = 0;
 
     // Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + c16][kk*32 + g*8 .. +7] * head_dim^-1/2 * log2(e), zero beyond head_dim
     bf16x8 qf[NK];
@@ -67,44 +65,22 @@ __global__ __launch_bounds__(256) void attention_hd_kernel(GaAttentionHdArgs a)
     const uint16_t *vb_ = a.v + (size_t)b * Lk * a.v_stride + (size_t)h * hd;
     const int ntiles = (Lk + KB - 1) / KB, nchunk = KB * cpr;
     const int krow = 8 * (c16 >> 2) + (c16 & 3);
-    constexpr int CH = (KB * (HDP / 8) + 255) / 256;     // 16-byte chunks per thread and operand of one tile (at most)
-    uint4 rk[CH], rv[CH];
-    auto issue = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int c = tid + 256 * i;
-            if (c < nchunk) {
-                const int row = c / cpr, part = c - row * cpr;
-                const int key = min(t * KB + row, Lk - 1);     // keys beyond the end are masked below
-                rk[i] = *reinterpret_cast<const uint4 *>(kb_ + (size_t)key * a.k_stride + part * 8);
-                rv[i] = *reinterpret_cast<const uint4 *>(vb_ + (size_t)key * a.v_stride + part * 8);
-            }
-        }
-    };
-    auto commit = [&](int buf) {
-        uint16_t *Ks = Ks2[buf], *Vt = Vt2[buf];
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int c = tid + 256 * i;
-            if (c < nchunk) {
-                const int row = c / cpr, part = c - row * cpr;
-                *reinterpret_cast<uint4 *>(Ks + row * KROW + part * 8) = rk[i];
-                const uint32_t w[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    Vt[(part * 8 + 2 * e) * VROW + row] = (uint16_t)(w[e] & 0xffffu);
-                    Vt[(part * 8 + 2 * e + 1) * VROW + row] = (uint16_t)(w[e] >> 16);
-                }
-            }
-        }
-    };
-    issue(0);
-    __syncthreads();                           // the zero fill is done
-    commit(0);
     for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) issue(t + 1);      // in flight while tile t is multiplied
-        __syncthreads();                       // tile t has been committed by everybody; everybody has left tile t - 1
-        const uint16_t *Ks = Ks2[t & 1], *Vt = Vt2[t & 1];
+        __syncthreads();                       // everybody has finished the previous tile (and the zero fill)
+        for (int c = tid; c < nchunk; c += 256) {
+            const int row = c / cpr, part = c - row * cpr;
+            const int key = min(t * KB + row, Lk - 1);     // keys beyond the end are masked below
+            const uint4 kv = *reinterpret_cast<const uint4 *>(kb_ + (size_t)key * a.k_stride + part * 8);
+            const uint4 vv = *reinterpret_cast<const uint4 *>(vb_ + (size_t)key * a.v_stride + part * 8);
+            *reinterpret_cast<uint4 *>(Ks + row * KROW + part * 8) = kv;
+            const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Vt[(part * 8 + 2 * e) * VROW + row] = (uint16_t)(w[e] & 0xffffu);
+                Vt[(part * 8 + 2 * e + 1) * VROW + row] = (uint16_t)(w[e] >> 16);
+            }
+        }
+        __syncthreads();
         // S^T = K Q^T : s[kf][r] <-> key 32 (kf >> 1) + 8 g + 4 (kf & 1) + r of the tile, query c16
         f32x4 s[4];
 #pragma unroll
@@ -150,7 +126,6 @@ __global__ __launch_bounds__(256) void attention_hd_kernel(GaAttentionHdArgs a)
                 const bf16x8 vfrag = *reinterpret_cast<const bf16x8 *>(Vt + (df * 16 + c16) * VROW + kb * 32 + g * 8);
                 o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pf[kb], o[df], 0, 0, 0);
             }
-        if (t + 1 < ntiles) commit((t + 1) & 1);   // (its last readers passed this iteration's barrier after tile t - 1)
     }
     float l = l_run;
     l += __shfl_xor(l, 16, 64);
