@@ -1055,7 +1055,9 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
         // (a 48 x 64 two-wave tile that would give the N = 1024 residual GEMMs at 768 rows 256 workgroups instead of 192 measured 3 % slower per evaluation: not kept)
         const long long wg_96x128 = (long long)((a->N + 127) / 128) * ((a->M + 95) / 96);
         if (nk % 4 == 0 && nk >= 8) {
-            static const int bigmin = [] { const char *e = getenv("GA_GEMM_BIGMIN"); return e ? atoi(e) : 160; }();   // (experiment)
+            // (round 6: 144 instead of 160 -- DiT-B's qkv, 18 x 8 workgroups, is better off on this tile than on 864 of 64 x 64: 1.237 -> 1.222 ms per
+            //  evaluation same-box; nothing else falls between the two.  GA_GEMM_BIGMIN: A/B aid)
+            static const int bigmin = [] { const char *e = getenv("GA_GEMM_BIGMIN"); return e ? atoi(e) : 144; }();
             if (wg_big >= bigmin && rows48) ring = 1;
             else if (ring4_env && a->epilogue != GA_GEMM_EPI_STORE_F32 && wg_96x128 >= 160 && wg_96x128 <= 256 && rows48) ring = 4;
             // (per-head norm on the 96 x 64 tile: its two 32-column waves exchange their sums through LDS, a barrier more than the
