@@ -93,6 +93,8 @@ class GaussianRenderer2DGS:
             bg_color = self.bg_color
         sets = [g.contiguous().float() for g in gaussian_sets]
         dev = sets[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("gaussiananything_amd surfel rasterizer only runs on an MI355X (HIP) device; there is no CPU path")
         if cam_view.shape[0] != 1 or len(sets) < 2 or os.environ.get("GA_RENDER_LEVELS", "1") == "0":   # (GA_RENDER_LEVELS=0: A/B aid; batch items of one set share a workspace, hence its status words: one at a time)
             return [self.render(g, cam_view, cam_view_proj, cam_pos, tanfov, bg_color, scale_modifier, S) for g, S in zip(sets, output_sizes)]
         main = torch.cuda.current_stream(dev)
