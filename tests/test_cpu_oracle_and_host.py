@@ -453,6 +453,12 @@ def test_rasterizer_refuses_cpu_tensors():
     cams = synthetic.eval_cameras(1)
     with pytest.raises(RuntimeError):
         rasterize_views(m, o, c, s, r, cams["cam_view"], cams["cam_view_proj"], torch.ones(3), 64, 64)
+    # the multi-set entry point of the renderer (round 6) refuses the same way, before it touches a stream
+    from gaussiananything_amd.gs_surfel import GaussianRenderer2DGS
+    rd = GaussianRenderer2DGS.__new__(GaussianRenderer2DGS)      # (the constructor places its background tensor on the GPU)
+    rd.bg_color = torch.ones(3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        rd.render_levels([g[None], g[None]], [32, 64], cams["cam_view"][None], cams["cam_view_proj"][None], cams["cam_pos"][None], cams["tanfov"])
 
 
 def test_shard_samples_partition():
