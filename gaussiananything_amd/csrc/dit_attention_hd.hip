@@ -11,6 +11,8 @@
 // (ga_head_rmsnorm_bf16 below: the GEMM epilogue's per-head norm is 64-wide as well).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "dit_common.h"
 
 namespace gadit {
@@ -141,6 +143,276 @@ __global__ __launch_bounds__(256) void attention_hd_kernel(GaAttentionHdArgs a)
     }
 }
 
+// Round 6: the TUNED variant, taken when the caller passes V^T (GaAttentionHdArgs.vt: the image the projection GEMM's epilogue stores for
+// any width, [batch * heads * head_dim][vt_ld], keys contiguous).  What changed against the kernel above:
+//   * V^T arrives transposed: both tiles are 16-byte row copies (the 2-byte transposing LDS stores are gone);
+//   * QF = 2 query fragments per wave (128-query workgroups): every K / V^T fragment read from LDS feeds two MFMAs, a tile is staged once for
+//     twice the queries; QF = 1 where 128-query workgroups would leave most CUs empty (one sample's cross-attention: 16 heads x 6 tiles);
+//   * grid (heads * batch, query tiles): the workgroups of one (batch, head) sit on one XCD and share its L2 copy of K / V^T;
+//   * two LDS buffers, tile t + 1 in registers while tile t is multiplied: one barrier per tile;
+//   * the head dim in 16-wide steps, not 32: 72 = two MFMA k-steps of 32 and one of 16 for Q K^T (80 columns, not 96), five d tiles for P V;
+//   * q's per-head RMSNorm here (q_norm_weight): the lane groups that hold a row's fragments add up its squares with two lane swaps -- a
+//     launch per attention less; the softmax scale goes into the exponent's FMA instead of a second bf16 rounding of q.
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_hd __attribute__((ext_vector_type(4)));
+
+template <int B_, int E_, class F>
+__device__ __forceinline__ void static_for_hd(F &&f)
+{
+    if constexpr (B_ < E_) {
+        f(std::integral_constant<int, B_>{});
+        static_for_hd<B_ + 1, E_>(f);
+    }
+}
+
+template <int HD16, int QF, int NW = 4>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2))) void attention_hdv_kernel(GaAttentionHdArgs a)
+{
+    constexpr int NT = 64 * NW;     // NW waves of QF x 16 queries
+    constexpr int KB = 64, HDP = HD16 * 16, KROW = HDP + 8, VROW = KB + 8, NK32 = HD16 / 2;
+    constexpr bool K16 = (HD16 & 1) != 0;
+    constexpr int KCH = (KB * HD16 * 2 + NT - 1) / NT, VCH = (HDP * 8 + NT - 1) / NT;   // 16-byte chunks per thread and tile (upper bounds)
+    constexpr int KT = KB * KROW, VT = HDP * VROW;
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem_hd[];     // K[2][key][d] (d >= head_dim zero), V^T[2][d][key] (rows >= head_dim zero)
+    uint16_t *Ks2 = smem_hd, *Vt2 = smem_hd + 2 * KT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    const int hd = a.head_dim, cpr = hd >> 3;
+    const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads, q0 = blockIdx.y * (16 * NW * QF) + wave * (16 * QF);
+    const int Lq = a.Lq, Lk = a.Lk;
+    for (int i = tid; i < (2 * KT + 2 * VT) / 8; i += NT) reinterpret_cast<uint4 *>(smem_hd)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+    // Q fragments (B operand of S^T = K Q^T): lane holds Q[q][kk*32 + g*8 .. +7] (k-steps of 32) and Q[q][NK32*32 + g*4 .. +3] (the step of 16)
+    bf16x8 qf[QF][NK32 > 0 ? NK32 : 1];
+    bf16x4 qh[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        const int row = min(q0 + f * 16 + c16, Lq - 1);
+        const uint16_t *qp = a.q + ((size_t)b * Lq + row) * a.q_stride + (size_t)h * hd;
+        uint4 raw[NK32 > 0 ? NK32 : 1];
+        uint2 rawh = make_uint2(0u, 0u);
+#pragma unroll
+        for (int kk = 0; kk < NK32; ++kk) {
+            raw[kk] = make_uint4(0u, 0u, 0u, 0u);
+            if (kk * 4 + g < cpr) raw[kk] = *reinterpret_cast<const uint4 *>(qp + kk * 32 + g * 8);
+        }
+        if (K16 && NK32 * 32 + g * 4 < hd) rawh = *reinterpret_cast<const uint2 *>(qp + NK32 * 32 + g * 4);
+        if (a.q_norm_weight) {      // kernel-uniform
+            float ss = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < NK32; ++kk) {
+                const uint32_t w[4] = {raw[kk].x, raw[kk].y, raw[kk].z, raw[kk].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+                    ss += lo * lo + hi * hi;
+                }
+            }
+            if (K16) {
+                const uint32_t w[2] = {rawh.x, rawh.y};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+                    ss += lo * lo + hi * hi;
+                }
+            }
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const float rs = rsqrtf(ss / (float)hd + 1e-5f);
+#pragma unroll
+            for (int kk = 0; kk < NK32; ++kk) {
+                if (kk * 4 + g < cpr) {
+                    const float4 w0 = *reinterpret_cast<const float4 *>(a.q_norm_weight + kk * 32 + g * 8);
+                    const float4 w1 = *reinterpret_cast<const float4 *>(a.q_norm_weight + kk * 32 + g * 8 + 4);
+                    const uint32_t w[4] = {raw[kk].x, raw[kk].y, raw[kk].z, raw[kk].w};
+                    const float ws[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                    uint32_t o4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        o4[e] = pack_bf16x2(__uint_as_float(w[e] << 16) * (rs * ws[2 * e]), __uint_as_float(w[e] & 0xffff0000u) * (rs * ws[2 * e + 1]));
+                    raw[kk] = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+                }
+            }
+            if (K16 && NK32 * 32 + g * 4 < hd) {
+                const float4 w0 = *reinterpret_cast<const float4 *>(a.q_norm_weight + NK32 * 32 + g * 4);
+                rawh = make_uint2(pack_bf16x2(__uint_as_float(rawh.x << 16) * (rs * w0.x), __uint_as_float(rawh.x & 0xffff0000u) * (rs * w0.y)),
+                                  pack_bf16x2(__uint_as_float(rawh.y << 16) * (rs * w0.z), __uint_as_float(rawh.y & 0xffff0000u) * (rs * w0.w)));
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < NK32; ++kk) qf[f][kk] = __builtin_bit_cast(bf16x8, raw[kk]);
+        qh[f] = __builtin_bit_cast(bf16x4, rawh);
+    }
+    const float cs = rsqrtf((float)hd) * 1.4426950408889634f;   // softmax scale x log2(e): applied inside the exponent's FMA
+
+    f32x4 o[QF][HD16];
+    float m_run[QF], l_run[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        m_run[f] = -1e30f; l_run[f] = 0.f;
+#pragma unroll
+        for (int i = 0; i < HD16; ++i) o[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const uint16_t *kb_ = a.k + (size_t)b * Lk * a.k_stride + (size_t)h * hd;
+    const uint16_t *vb_ = a.vt + ((size_t)b * a.heads + h) * hd * a.vt_ld;
+    const int ntiles = (Lk + KB - 1) / KB;
+    // this thread's chunks of a tile: K chunk c = tid + 256 i -> (key row c / cpr, part c % cpr); V^T chunk -> (d row c >> 3, part c & 7)
+    // (compile-time indices throughout -- static_for, not unrolled loops inside the lambdas: those left the staging registers in scratch)
+    int k_row[KCH], k_lds[KCH], v_lds[VCH];
+    const uint16_t *v_src[VCH];
+    uint32_t k_part[KCH];
+    static_for_hd<0, KCH>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        const int c = tid + NT * i, row = c / cpr, part = c - row * cpr;
+        k_row[i] = row < KB ? row : -1; k_part[i] = (uint32_t)(row < KB ? part : 0) * 8u; k_lds[i] = row * KROW + part * 8;
+    });
+    static_for_hd<0, VCH>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        const int c = tid + NT * i, row = c >> 3, part = c & 7;
+        v_src[i] = vb_ + (size_t)min(row, hd - 1) * a.vt_ld + part * 8;
+        v_lds[i] = row < hd ? row * VROW + part * 8 : -1;
+    });
+    u32x4_hd kreg[KCH], vreg[VCH];     // (LLVM vector values, not HIP_vector_type structs: those were copied with memcpy and stayed in scratch)
+    auto issue = [&](int t) __attribute__((always_inline)) {
+        static_for_hd<0, KCH>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            // (no branch around a load: a chunk slot past the tile re-reads a valid address and is not committed.  With branches the register
+            //  allocator joins the paths through copies of the loaded registers -- s_waitcnt vmcnt(0) straight after the barrier)
+            kreg[i] = *reinterpret_cast<const u32x4_hd *>(kb_ + (size_t)min(t * KB + max(k_row[i], 0), Lk - 1) * a.k_stride + k_part[i]);
+        });
+        static_for_hd<0, VCH>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            vreg[i] = *reinterpret_cast<const u32x4_hd *>(v_src[i] + t * KB);
+        });
+    };
+    auto commit = [&](int buf) __attribute__((always_inline)) {
+        static_for_hd<0, KCH>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            if (k_row[i] >= 0) *reinterpret_cast<u32x4_hd *>(Ks2 + buf * KT + k_lds[i]) = kreg[i];
+        });
+        static_for_hd<0, VCH>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            if (v_lds[i] >= 0) *reinterpret_cast<u32x4_hd *>(Vt2 + buf * VT + v_lds[i]) = vreg[i];
+        });
+    };
+    issue(0);
+    __syncthreads();                               // the zero fill is done
+    commit(0);
+    const int krow = 8 * (c16 >> 2) + (c16 & 3);
+    for (int t = 0; t < ntiles; ++t) {
+        issue(min(t + 1, ntiles - 1));             // in flight while tile t is multiplied (past the end: a harmless re-fetch -- unconditional, so
+                                                   // that the staging registers are plain values, not merged paths)
+        // tile t is committed by everybody; everybody has left tile t - 1 (the other buffer).  NOT __syncthreads(): its fence waits for
+        // vmcnt(0) -- loads and stores share that counter on gfx9 -- i.e. for the tile just requested: every global round trip back on the
+        // critical path (the first version of this kernel, and round 6's double-buffering of the kernel above, measured exactly that)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const uint16_t *Ks = Ks2 + (t & 1) * KT, *Vt = Vt2 + (t & 1) * VT;
+        // S^T = K Q^T : s[f][kf][r] <-> key 32 (kf >> 1) + 8 g + 4 (kf & 1) + r of the tile, query c16 of fragment f
+        f32x4 s[QF][4];
+#pragma unroll
+        for (int f = 0; f < QF; ++f)
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) s[f][kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < NK32; ++kk)
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) {
+                const bf16x8 kfrag = *reinterpret_cast<const bf16x8 *>(Ks + ((kf >> 1) * 32 + (kf & 1) * 4 + krow) * KROW + kk * 32 + g * 8);
+#pragma unroll
+                for (int f = 0; f < QF; ++f) s[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[f][kk], s[f][kf], 0, 0, 0);
+            }
+        if (K16) {
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) {
+                const bf16x4 kfrag = *reinterpret_cast<const bf16x4 *>(Ks + ((kf >> 1) * 32 + (kf & 1) * 4 + krow) * KROW + NK32 * 32 + g * 4);
+#pragma unroll
+                for (int f = 0; f < QF; ++f) s[f][kf] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kfrag, qh[f], s[f][kf], 0, 0, 0);
+            }
+        }
+        const int kbase = t * KB + g * 8;
+        const bool edge = (t + 1) * KB > Lk;       // uniform: only the last tile masks
+        bf16x8 pf[QF][2];
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            float tmax = -1e30f;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (edge && kbase + (kf >> 1) * 32 + (kf & 1) * 4 + r >= Lk) s[f][kf][r] = -1e30f;
+                    tmax = fmaxf(tmax, s[f][kf][r]);
+                }
+            tmax = group_max_hd(tmax);
+            const float m_new = fmaxf(m_run[f], tmax * cs);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);
+            m_run[f] = m_new;
+            float psum = 0.f;
+            uint32_t pw[2][4];
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) {
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(s[f][kf][0], cs, -m_new)), p1 = __builtin_amdgcn_exp2f(fmaf(s[f][kf][1], cs, -m_new));
+                const float p2 = __builtin_amdgcn_exp2f(fmaf(s[f][kf][2], cs, -m_new)), p3 = __builtin_amdgcn_exp2f(fmaf(s[f][kf][3], cs, -m_new));
+                psum += (p0 + p1) + (p2 + p3);
+                pw[kf >> 1][(kf & 1) * 2] = pack_bf16x2(p0, p1);
+                pw[kf >> 1][(kf & 1) * 2 + 1] = pack_bf16x2(p2, p3);
+            }
+            pf[f][0] = __builtin_bit_cast(bf16x8, make_uint4(pw[0][0], pw[0][1], pw[0][2], pw[0][3]));
+            pf[f][1] = __builtin_bit_cast(bf16x8, make_uint4(pw[1][0], pw[1][1], pw[1][2], pw[1][3]));
+            l_run[f] = l_run[f] * alpha + psum;
+#pragma unroll
+            for (int df = 0; df < HD16; ++df) { o[f][df][0] *= alpha; o[f][df][1] *= alpha; o[f][df][2] *= alpha; o[f][df][3] *= alpha; }
+        }
+        // O^T += V^T P^T : o[f][df][r] = O[q = c16][d = df*16 + g*4 + r]; the lane's 8 P of block kb are keys 32 kb + 8 g ..
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int df = 0; df < HD16; ++df) {
+                const bf16x8 vfrag = *reinterpret_cast<const bf16x8 *>(Vt + (df * 16 + c16) * VROW + kb * 32 + g * 8);
+#pragma unroll
+                for (int f = 0; f < QF; ++f) o[f][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pf[f][kb], o[f][df], 0, 0, 0);
+            }
+        commit((t + 1) & 1);                       // (its last readers passed this iteration's barrier after tile t - 1; after the last tile nobody reads it)
+    }
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        float l = l_run[f];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int row = q0 + f * 16 + c16;
+        if (row < Lq) {
+            uint16_t *op = a.out + ((size_t)b * Lq + row) * a.out_stride + (size_t)h * hd + g * 4;
+#pragma unroll
+            for (int df = 0; df < HD16; ++df)
+                if (df * 16 + g * 4 < hd)
+                    *reinterpret_cast<uint2 *>(op + df * 16) = make_uint2(pack_bf16x2(o[f][df][0] * inv, o[f][df][1] * inv), pack_bf16x2(o[f][df][2] * inv, o[f][df][3] * inv));
+        }
+    }
+}
+
+template <int HD16>
+static int launch_hdv(const GaAttentionHdArgs &a, hipStream_t s)
+{
+    constexpr size_t lds = (size_t)(2 * 64 * (HD16 * 16 + 8) + 2 * HD16 * 16 * 72) * 2;
+    // configurations: 1 = 4 waves x 16 queries (64-query workgroups), 2 = 4 waves x 32 (128), 3 = 8 waves x 16 (128: two waves per SIMD
+    // hide each other's LDS / exponent latencies).  GA_ATTN_HD_QF forces one (A/B aid)
+    static const int qf_env = [] { const char *e = getenv("GA_ATTN_HD_QF"); return e ? atoi(e) : 0; }();
+    const long long wg128 = (long long)a.batch * a.heads * ((a.Lq + 127) / 128);
+    const int cfg = qf_env ? qf_env : (wg128 >= 160 ? 2 : 1);
+    const int qpw = cfg == 1 ? 64 : 128;
+    const dim3 grid((unsigned)(a.batch * a.heads), (unsigned)((a.Lq + qpw - 1) / qpw));
+#define GA_HDV_LAUNCH(QFV, NWV)                                                                                                   \
+    do {                                                                                                                          \
+        if (lds > 65536 && hipFuncSetAttribute((const void *)attention_hdv_kernel<HD16, QFV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
+        hipLaunchKernelGGL((attention_hdv_kernel<HD16, QFV, NWV>), grid, dim3(64 * NWV), lds, s, a);                               \
+    } while (0)
+    if (cfg == 2) GA_HDV_LAUNCH(2, 4);
+    else if (cfg == 3) GA_HDV_LAUNCH(1, 8);
+    else GA_HDV_LAUNCH(1, 4);
+#undef GA_HDV_LAUNCH
+    return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
+}
+
 // x[r][h][:] <- x[r][h][:] * rsqrt(mean(x[r][h][:]^2) + 1e-5) * w[:], one wavefront per (row, head); head_dim <= 128
 __global__ __launch_bounds__(256) void head_rmsnorm_kernel(uint16_t *__restrict__ x, int64_t rows, int64_t row_stride, int heads, int hd,
                                                             const float *__restrict__ w)
@@ -163,11 +435,28 @@ __global__ __launch_bounds__(256) void head_rmsnorm_kernel(uint16_t *__restrict_
 extern "C" int ga_attention_hd_bf16(const GaAttentionHdArgs *a, void *stream)
 {
     using namespace gadit;
-    if (!a || !a->q || !a->k || !a->v || !a->out) return GA_DIT_ERR_NULL_ARG;
+    if (!a || !a->q || !a->k || (!a->v && !a->vt) || !a->out) return GA_DIT_ERR_NULL_ARG;
     if (a->batch <= 0 || a->heads <= 0 || a->Lq <= 0 || a->Lk <= 0 || a->head_dim < 8 || a->head_dim > 128 || a->head_dim % 8 ||
-        a->q_stride % 8 || a->k_stride % 8 || a->v_stride % 8 || a->out_stride % 4)
+        a->q_stride % 8 || a->k_stride % 8 || a->out_stride % 4)
         return GA_DIT_ERR_BAD_SHAPE;
-    if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) % 16 != 0 || (uintptr_t)a->out % 8 != 0) return GA_DIT_ERR_BAD_SHAPE;
+    if (((uintptr_t)a->q | (uintptr_t)a->k) % 16 != 0 || (uintptr_t)a->out % 8 != 0) return GA_DIT_ERR_BAD_SHAPE;
+    if (a->vt) {     // the tuned variant: V^T [batch * heads * head_dim][vt_ld], vt_ld a multiple of 64 that covers the keys
+        if (a->vt_ld % 64 != 0 || a->vt_ld < (a->Lk + 63) / 64 * 64 || (uintptr_t)a->vt % 16 != 0 || (a->q_norm_weight && (uintptr_t)a->q_norm_weight % 16 != 0))
+            return GA_DIT_ERR_BAD_SHAPE;
+        hipStream_t sv = reinterpret_cast<hipStream_t>(stream);
+        switch ((a->head_dim + 15) / 16) {
+        case 1: return launch_hdv<1>(*a, sv);
+        case 2: return launch_hdv<2>(*a, sv);
+        case 3: return launch_hdv<3>(*a, sv);
+        case 4: return launch_hdv<4>(*a, sv);
+        case 5: return launch_hdv<5>(*a, sv);
+        case 6: return launch_hdv<6>(*a, sv);
+        case 7: return launch_hdv<7>(*a, sv);
+        default: return launch_hdv<8>(*a, sv);
+        }
+    }
+    if (a->q_norm_weight) return GA_DIT_ERR_BAD_SHAPE;     // (the norm inside the kernel belongs to the V^T variant)
+    if (a->v_stride % 8 || (uintptr_t)a->v % 16 != 0) return GA_DIT_ERR_BAD_SHAPE;
     const dim3 grid((unsigned)((a->Lq + 63) / 64), (unsigned)a->heads, (unsigned)a->batch);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int hdp = (a->head_dim + 31) / 32 * 32;

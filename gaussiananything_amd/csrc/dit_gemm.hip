@@ -181,20 +181,25 @@ __device__ __forceinline__ void residual_prefetch(const GemmP &p, ResidualPrefet
 }
 
 // the consumer's row sums of squares (<= 16 partials per row), requested before the K loop like the residual rows
-template <int MT>
+// (rows of the partial sums are ss_ld(tiles) floats apart: the tile count rounded up to a multiple of 4, the pad entries written as zeros by
+//  the producer -- 18 tiles at width 1152 -> 20; NP float4 groups per row: 4 for the widths the four-slot kernels see, <= 1024, 5 in the
+//  three-slot ones, <= 1280)
+__host__ __device__ __forceinline__ int ss_ld(int tiles) { return (tiles + 3) & ~3; }
+
+template <int MT, int NP = 4>
 struct RowSsPrefetch {
-    f32x4 part[MT][4];
+    f32x4 part[MT][NP];
 };
 
-template <int MT>
-__device__ __forceinline__ void rowss_prefetch(const GemmP &p, RowSsPrefetch<MT> &pf, int mrow0, int lane)
+template <int MT, int NP = 4>
+__device__ __forceinline__ void rowss_prefetch(const GemmP &p, RowSsPrefetch<MT, NP> &pf, int mrow0, int lane)
 {
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int m = min(mrow0 + j * 16 + (lane & 15), p.M - 1);
-        const float *rp = p.row_ss + (size_t)m * p.row_ss_tiles;
+        const float *rp = p.row_ss + (size_t)m * ss_ld(p.row_ss_tiles);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < NP; ++t) {
             pf.part[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (4 * t < p.row_ss_tiles) {
                 const float4 v = *reinterpret_cast<const float4 *>(rp + 4 * t);
@@ -207,9 +212,9 @@ __device__ __forceinline__ void rowss_prefetch(const GemmP &p, RowSsPrefetch<MT>
 // FN = 16-column fragments per wave: 4 (the wave's 64 columns are one attention head / one emit_ss group) or 2 (32 columns: no
 // per-head RMSNorm, no V^T store; the row sums of squares of a 64-column group are returned in `emit_part` for the caller to
 // combine across the two waves of the group)
-template <int EPI, int MT, int FN, bool PRE, bool RSSPRE, bool PREONLY = false>
+template <int EPI, int MT, int FN, bool PRE, bool RSSPRE, bool PREONLY = false, int NP = 4>
 __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[FN][MT], const ResidualPrefetch<MT> *pre,
-                                              const RowSsPrefetch<MT> *rss, int mrow0, int ncol0, int lane, float *emit_part = nullptr,
+                                              const RowSsPrefetch<MT, NP> *rss, int mrow0, int ncol0, int lane, float *emit_part = nullptr,
                                               const f32x4 *bias_pre = nullptr, const f32x4 *qkw_pre = nullptr,
                                               float *qk_mine = nullptr, const float *qk_other = nullptr,
                                               const f32x4 (*emul_pre)[2] = nullptr)
@@ -248,9 +253,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[FN][M
             float tot = 0.f;
             if (RSSPRE) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) tot += (rss->part[j][t][0] + rss->part[j][t][1]) + (rss->part[j][t][2] + rss->part[j][t][3]);
+                for (int t = 0; t < NP; ++t) tot += (rss->part[j][t][0] + rss->part[j][t][1]) + (rss->part[j][t][2] + rss->part[j][t][3]);
             } else {  // two-workgroups-per-CU configuration: no registers to spare for a prefetch, same summation order
-                const float *rp = p.row_ss + (size_t)min(m, M - 1) * p.row_ss_tiles;
+                const float *rp = p.row_ss + (size_t)min(m, M - 1) * ss_ld(p.row_ss_tiles);
                 for (int t = 0; t < p.row_ss_tiles; t += 4) {
                     const float4 q4 = *reinterpret_cast<const float4 *>(rp + t);
                     tot += (q4.x + q4.y) + (q4.z + q4.w);
@@ -417,7 +422,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, f32x4 (&acc)[FN][M
             emit_acc += __shfl_xor(emit_acc, 16, 64);
             emit_acc += __shfl_xor(emit_acc, 32, 64);
             if (FN == 4) {
-                if (g == 0 && m < M && nhead < N) p.emit_ss[(size_t)m * (N >> 6) + (nhead >> 6)] = emit_acc;
+                if (g == 0 && m < M && nhead < N) {
+                    float *er = p.emit_ss + (size_t)m * ss_ld(N >> 6);
+                    er[nhead >> 6] = emit_acc;
+                    if ((nhead >> 6) + 1 == (N >> 6))            // the last group's writer zeroes the pad entries of the row
+                        for (int z = N >> 6; z < ss_ld(N >> 6); ++z) er[z] = 0.f;
+                }
             } else if (g == 0) emit_part[j * 16 + (lane & 15)] = emit_acc;   // half a group: the caller adds the two waves up
         }
     }
@@ -705,8 +715,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
     ResidualPrefetch<PRE ? FM : 1> pre;
     if (PRE) residual_prefetch<FM, FN / 2>(p, reinterpret_cast<ResidualPrefetch<FM> &>(pre), mrow0, ncol0, lane);
     constexpr bool RSS = EPI == GA_GEMM_EPI_STORE_BF16 || EPI == GA_GEMM_EPI_GELU_BF16;
-    RowSsPrefetch<RSS ? FM : 1> rss;
-    if (RSS && p.row_ss) rowss_prefetch<FM>(p, reinterpret_cast<RowSsPrefetch<FM> &>(rss), mrow0, lane);
+    constexpr int NP = NST == 3 ? 5 : 4;      // (the three-slot instances serve the widths that are no multiple of 256: up to 20 partial sums per row)
+    RowSsPrefetch<RSS ? FM : 1, NP> rss;
+    if (RSS && p.row_ss) rowss_prefetch<FM, NP>(p, reinterpret_cast<RowSsPrefetch<FM, NP> &>(rss), mrow0, lane);
 
     // nk = n_main * NST + NST: the last NST tiles are peeled (compile-time slot, wait count, request-or-not)
     const int n_main = nk / NST - 1;
@@ -877,8 +888,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
     }
 
     if constexpr (FN == 4) {
-        gemm_epilogue<EPI, FM, 4, PRE, RSS, true>(p, acc, reinterpret_cast<const ResidualPrefetch<FM> *>(&pre),
-                                                  reinterpret_cast<const RowSsPrefetch<FM> *>(&rss), mrow0, ncol0, lane, nullptr, bias_pre, qkw_pre, nullptr, nullptr, emul);
+        gemm_epilogue<EPI, FM, 4, PRE, RSS, true, NP>(p, acc, reinterpret_cast<const ResidualPrefetch<FM> *>(&pre),
+                                                      reinterpret_cast<const RowSsPrefetch<FM, NP> *>(&rss), mrow0, ncol0, lane, nullptr, bias_pre, qkw_pre, nullptr, nullptr, emul);
     } else {
         // 32-column waves: the two waves of a 64-column group add their row sums of squares through LDS (the ring is idle now)
         static_assert(WN == 2, "a 64-column tile is two 32-column waves");
@@ -887,14 +898,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
         // the workgroup's 64 columns are a q or k head with a per-head RMSNorm: its two waves exchange their halves of the row sums
         const bool qk2 = EPI == GA_GEMM_EPI_STORE_BF16 && n0 < p.qk_cols1;   // workgroup-uniform
         if (emit || qk2) __syncthreads();
-        gemm_epilogue<EPI, FM, 2, PRE, RSS, true>(p, acc, reinterpret_cast<const ResidualPrefetch<FM> *>(&pre),
-                                            reinterpret_cast<const RowSsPrefetch<FM> *>(&rss), mrow0, ncol0, lane, part, bias_pre, qkw_pre,
+        gemm_epilogue<EPI, FM, 2, PRE, RSS, true, NP>(p, acc, reinterpret_cast<const ResidualPrefetch<FM> *>(&pre),
+                                            reinterpret_cast<const RowSsPrefetch<FM, NP> *>(&rss), mrow0, ncol0, lane, part, bias_pre, qkw_pre,
                                             qk2 ? part : nullptr,
                                             reinterpret_cast<const float *>(smem) + ((wn ^ 1) * WM + wm) * FM * 16, emul);
         if (emit) {
             __syncthreads();
             const float *all = reinterpret_cast<const float *>(smem);
-            if (tid < BM && m0 + tid < M) p.emit_ss[(size_t)(m0 + tid) * (N >> 6) + (n0 >> 6)] = all[tid] + all[BM + tid];
+            if (tid < BM && m0 + tid < M) {
+                float *er = p.emit_ss + (size_t)(m0 + tid) * ss_ld(N >> 6);
+                er[n0 >> 6] = all[tid] + all[BM + tid];
+                if ((n0 >> 6) + 1 == (N >> 6))
+                    for (int z = N >> 6; z < ss_ld(N >> 6); ++z) er[z] = 0.f;
+            }
         }
     }
 }
@@ -948,8 +964,10 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
         return GA_DIT_ERR_BAD_SHAPE;
     if (a->w_tiled && a->N % 8 != 0) return GA_DIT_ERR_BAD_SHAPE;
     if (a->row_ss && ((a->epilogue != GA_GEMM_EPI_STORE_BF16 && a->epilogue != GA_GEMM_EPI_GELU_BF16) || a->row_ss_tiles <= 0 ||
-                      a->row_ss_tiles > 16 || a->row_ss_tiles % 4 != 0 || a->row_ss_dim <= 0))
+                      a->row_ss_tiles > 20 || a->row_ss_dim <= 0 || (uintptr_t)a->row_ss % 16 != 0))
         return GA_DIT_ERR_BAD_SHAPE;
+    // (more than 16 partial sums per row: only the three-slot ring instances and the 2-slot general kernel read a fifth group)
+    const bool wide_ss = a->row_ss && a->row_ss_tiles > 16;
     if ((a->emit_w || a->emit_scale) && (!a->emit_x || !a->emit_w || !a->emit_scale || a->rows_per_batch <= 0 || a->emit_scale_stride % 4 != 0))
         return GA_DIT_ERR_BAD_SHAPE;
     if (a->bias_stride && (!a->bias || a->rows_per_batch <= 0 || a->bias_stride % 4 != 0 || a->bias_stride < a->N)) return GA_DIT_ERR_BAD_SHAPE;
@@ -1054,15 +1072,24 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
         static const int ring4_env = [] { const char *e = getenv("GA_GEMM_RING4"); return e ? atoi(e) : 1; }();
         // (a 48 x 64 two-wave tile that would give the N = 1024 residual GEMMs at 768 rows 256 workgroups instead of 192 measured 3 % slower per evaluation: not kept)
         const long long wg_96x128 = (long long)((a->N + 127) / 128) * ((a->M + 95) / 96);
-        if (nk % 4 == 0 && nk >= 8) {
+        // round 6: K that is no multiple of 256 but one of 192 (DiT-PixArt-PCD-CLAY-XL: 1152, 4608) runs the same tiles on a ring of THREE slots
+        const int nst_ring = (nk % 4 == 0 && nk >= 8) ? (wide_ss ? 0 : 4) : ((nk % 3 == 0 && nk >= 6) ? 3 : 0);
+        if (nst_ring) {
             // (round 6: 144 instead of 160 -- DiT-B's qkv, 18 x 8 workgroups, is better off on this tile than on 864 of 64 x 64: 1.237 -> 1.222 ms per
             //  evaluation same-box; nothing else falls between the two.  GA_GEMM_BIGMIN: A/B aid)
             static const int bigmin = [] { const char *e = getenv("GA_GEMM_BIGMIN"); return e ? atoi(e) : 144; }();
-            if (wg_big >= bigmin && rows48) ring = 1;
+            // (a 192 x 128 grid of a little over one round -- XL's fc1, 36 x 8 = 288 workgroups on 256 CUs -- pays two rounds for 1.1: 37.8 us
+            //  against 28.2 on the 2-slot 128 x 128 kernel below, 432 workgroups two to a CU; the rule is confined to the three-slot shapes so
+            //  that no released model's choice moves)
+            const bool ragged_big = nst_ring == 3 && wg_big > 256 && wg_big * 4 < ((wg_big + 255) / 256) * 256 * 3;
+            if (nst_ring == 3 && (a->epilogue == GA_GEMM_EPI_STORE_F32 || ragged_big)) ring = 0;   // (no three-slot instance of the fp32 store: nothing asks for it)
+            else if (wg_big >= bigmin && rows48) ring = 1;
             else if (ring4_env && a->epilogue != GA_GEMM_EPI_STORE_F32 && wg_96x128 >= 160 && wg_96x128 <= 256 && rows48) ring = 4;
             // (per-head norm on the 96 x 64 tile: its two 32-column waves exchange their sums through LDS, a barrier more than the
             //  64-column waves of the other tiles need -- worth it while the grid is one residency round, 2 x 256 workgroups:
             //  DiT-L's qkv at M = 768 13.4 -> 12.1 us; DiT-B's at M = 1536, 576 workgroups, is faster on 64 x 64, same-box A/B)
+            // (round 6: a 64 x 128 four-wave tile for the residual GEMMs whose 96 x 64 grid is a little over one round -- width 1152 at 1536 rows:
+            //  288 workgroups against 216 -- measured no better: fc2 37.6 us against 37.1, the K = 1152 projections 20.4 against 17.2: not kept)
             else if (wg_mid >= 160 && rows48 && (!(a->qk_cols0 || a->qk_cols1) || wg_mid <= 512)) ring = 2;
             else if (wg_small >= 96 && rows16) ring = 3;
         }
@@ -1101,27 +1128,33 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
                 if (pays && ring != 1 && a->epilogue == GA_GEMM_EPI_RESIDUAL && gx % 2 == 0 && gy % 4 == 0 && (gx * gy) % 8 == 0) pr.xmap = 1;
             }
             // (round 6: the k-step software pipeline of the 192 x 128 kernel on the 96 x 64 tile measured 1.5 - 2 % slower per evaluation: not kept)
-#define GA_RLAUNCH(E)                                                                                                     \
+#define GA_RLAUNCH_N(E, NSTV)                                                                                             \
             if (ring == 4) {                                                                                              \
-                if (hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 2, 2, 3, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 224 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
-                hipLaunchKernelGGL((gemm_ring_kernel<E, 2, 2, 3, 4, 4, 2>), dim3((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 95) / 96)), \
-                                   dim3(256), 4 * 224 * BK * 2, s, p);                                                    \
-            } else if (ring == 1)                                                                                                \
-                hipLaunchKernelGGL((gemm_ring_kernel<E, 4, 2, 3, 4, 4, 2>), dim3((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 191) / 192)), \
-                                   dim3(512), 4 * 320 * BK * 2, s, p);                                                    \
-            else if (ring == 2)                                                                                           \
-                hipLaunchKernelGGL((gemm_ring_kernel<E, 2, 2, 3, 2, 4, 0>), dim3((unsigned)((a->N + 63) / 64), (unsigned)((a->M + 95) / 96)), \
-                                   dim3(256), 4 * 160 * BK * 2, s, pr);                                                   \
-            else                                                                                                          \
-                hipLaunchKernelGGL((gemm_ring_kernel<E, 4, 1, 1, 4, 4, 0>), dim3((unsigned)((a->N + 63) / 64), (unsigned)((a->M + 63) / 64)), \
-                                   dim3(256), 4 * 128 * BK * 2, s, pr);
+                if (hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 2, 2, 3, 4, NSTV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTV * 224 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
+                hipLaunchKernelGGL((gemm_ring_kernel<E, 2, 2, 3, 4, NSTV, 2>), dim3((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 95) / 96)), \
+                                   dim3(256), NSTV * 224 * BK * 2, s, p);                                                 \
+            } else if (ring == 1) {                                                                                       \
+                if (NSTV != 4 && hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 4, 2, 3, 4, NSTV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTV * 320 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
+                hipLaunchKernelGGL((gemm_ring_kernel<E, 4, 2, 3, 4, NSTV, 2>), dim3((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 191) / 192)), \
+                                   dim3(512), NSTV * 320 * BK * 2, s, p);                                                 \
+            } else if (ring == 2) {                                                                                       \
+                if (NSTV != 4 && hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 2, 2, 3, 2, NSTV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTV * 160 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
+                hipLaunchKernelGGL((gemm_ring_kernel<E, 2, 2, 3, 2, NSTV, 0>), dim3((unsigned)((a->N + 63) / 64), (unsigned)((a->M + 95) / 96)), \
+                                   dim3(256), NSTV * 160 * BK * 2, s, pr);                                                \
+            } else {                                                                                                      \
+                if (NSTV != 4 && hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 4, 1, 1, 4, NSTV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTV * 128 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
+                hipLaunchKernelGGL((gemm_ring_kernel<E, 4, 1, 1, 4, NSTV, 0>), dim3((unsigned)((a->N + 63) / 64), (unsigned)((a->M + 63) / 64)), \
+                                   dim3(256), NSTV * 128 * BK * 2, s, pr);                                                \
+            }
+#define GA_RLAUNCH(E) if (nst_ring == 4) { GA_RLAUNCH_N(E, 4) } else { GA_RLAUNCH_N(E, 3) }
             switch (a->epilogue) {
             case GA_GEMM_EPI_STORE_BF16: GA_RLAUNCH(0) break;
             case GA_GEMM_EPI_GELU_BF16: GA_RLAUNCH(1) break;
             case GA_GEMM_EPI_RESIDUAL: GA_RLAUNCH(2) break;
-            case GA_GEMM_EPI_STORE_F32: GA_RLAUNCH(3) break;
+            case GA_GEMM_EPI_STORE_F32: if (nst_ring != 4) return GA_DIT_ERR_BAD_SHAPE; GA_RLAUNCH_N(3, 4) break;
             default: return GA_DIT_ERR_BAD_SHAPE;
             }
+#undef GA_RLAUNCH_N
 #undef GA_RLAUNCH
             return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
         }
@@ -1135,7 +1168,7 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
         if (best < 0 || cost < best) { best = cost; mt = cand; }
     }
     long long wgs = ncols * ((a->M + 32 * mt - 1) / (32 * mt));
-    int nst = wgs > 256 ? 2 : 4;
+    int nst = (wgs > 256 || wide_ss) ? 2 : 4;
 #ifdef GA_TUNING  // tuning builds only: GA_GEMM_CFG = 10 * MT + ring slots
     if (const char *e = getenv("GA_GEMM_CFG")) { const int c = atoi(e); if (c / 10 >= 1 && c / 10 <= 4 && (c % 10 == 2 || c % 10 == 4)) { mt = c / 10; nst = c % 10; } }
 #endif

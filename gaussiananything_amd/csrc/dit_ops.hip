@@ -547,14 +547,14 @@ static Ws carve(const GaDitModel *m, int B, int L, void *base)
     unsigned char *p = static_cast<unsigned char *>(base);
     Ws w;
     const size_t Lp = ((size_t)L + 63) / 64 * 64;
-    const size_t qkv_cols = (m->hidden / m->heads == 64) ? 2 : 3;   // head dims other than 64: v row-major beside q | k (no V^T image)
+    const size_t qkv_cols = 2;      // q | k row-major; v goes to the V^T image (round 6: for every head dim)
     const size_t o_xres = take(M * D * 4), o_xn = take(M * D * 2), o_qkv = take(M * qkv_cols * D * 2), o_att = take(M * D * 2);
     const size_t o_vt = take((size_t)B * D * Lp * 2);
     const size_t o_hmid = take(M * 4 * D * 2), o_tfreq = take((size_t)B * 256 * 4), o_t1 = take((size_t)B * D * 4);
     const size_t o_pln = take((size_t)B * m->context_dim * 4), o_pvec = take((size_t)B * D * 4);
     const size_t o_tvec = take((size_t)B * D * 4), o_t0 = take((size_t)B * 6 * D * 4);
     const size_t o_mod = take((size_t)m->depth * B * 6 * D * 4);
-    const size_t o_rowss = take(M * (D / 64) * 4);   // per-row partial sums of squares of the residual stream (folded pre-norm)
+    const size_t o_rowss = take(M * (((D / 64) + 3) & ~(size_t)3) * 4);   // per-row partial sums of squares of the residual stream (folded pre-norm)
     const size_t o_sbias = take((size_t)m->depth * B * 7 * D * 4);   // shift_b W^T + bias of the qkv and fc1 projections (folded modulated pre-norms)
     // (round 6) split-K scratch of the MLP's second linear: counters + partial tiles; only where a 4-way split can fill the chip
     // (fc2: up to 4 splits of [M, D]; qkv / fc1 at 768 rows: 2 splits of [M, 4 D] -- half of the 4-split bound)
@@ -579,7 +579,12 @@ static Ws carve(const GaDitModel *m, int B, int L, void *base)
 // block i's cross-attention pre-norm can be folded into fc2 of block i-1 and its own q projection (include/ga_dit.h)
 static bool can_fold(const GaDitModel *m, int i)
 {
-    return m->blocks[i].ca_q_w_prenorm != nullptr && m->hidden % 256 == 0 && m->hidden <= 1024 && m->hidden / m->heads == 64;
+    // heads of 64 (the fused q projection of the attention kernel reads the partial sums four at a time): widths the four-slot GEMM
+    // instances serve; other head dims (round 6, DiT-PixArt-PCD-CLAY-XL): those and the three-slot widths, up to 20 partial sums per row
+    const int D = m->hidden;
+    const bool w256 = D % 256 == 0 && D <= 1024;
+    const bool width_ok = m->hidden / m->heads == 64 ? w256 : (w256 || (D % 192 == 0 && D <= 1280));
+    return m->blocks[i].ca_q_w_prenorm != nullptr && width_ok;
 }
 
 static bool model_ok(const GaDitModel *m)
@@ -617,24 +622,16 @@ extern "C" int ga_dit_cache_context(const GaDitModel *m, int32_t batch, int32_t 
     if (batch <= 0 || ctx_tokens <= 0) return GA_DIT_ERR_BAD_SHAPE;
     const int rows = batch * ctx_tokens, D = m->hidden;
     const int64_t Mp = ((int64_t)ctx_tokens + 63) / 64 * 64;
-    if (D / m->heads != 64) {   // head dims other than 64 (ga_attention_hd_bf16): ca_k holds K | V row-major, [depth][rows, 2 D]; ca_vt is not used
-        for (int i = 0; i < m->depth; ++i) {
-            GaGemmArgs g{};
-            g.M = rows; g.N = 2 * D; g.K = m->context_dim; g.epilogue = GA_GEMM_EPI_STORE_BF16; g.A = ctx; g.lda = m->context_dim;
-            g.W = m->blocks[i].ca_kv_w; g.w_tiled = m->gemm_weights_tiled; g.out = ca_k + (size_t)i * rows * 2 * D; g.ldo = 2 * D;
-            GA_TRY(ga_gemm_bf16(&g, stream));
-            GA_TRY(ga_head_rmsnorm_bf16(ca_k + (size_t)i * rows * 2 * D, rows, 2 * D, m->heads, D / m->heads, m->blocks[i].ca_k_norm_w, stream));
-        }
-        return GA_DIT_OK;
-    }
+    const bool hd64 = D / m->heads == 64;   // other head dims (ga_attention_hd_bf16): the same K | V^T images, k's per-head norm as a pass of its own
     for (int i = 0; i < m->depth; ++i) {
         GaGemmArgs g{};
         g.M = rows; g.N = 2 * D; g.K = m->context_dim; g.epilogue = GA_GEMM_EPI_STORE_BF16;
         g.A = ctx; g.lda = m->context_dim; g.W = m->blocks[i].ca_kv_w; g.w_tiled = m->gemm_weights_tiled; g.bias = nullptr;
         g.out = ca_k + (size_t)i * rows * D; g.ldo = D;                    // K columns [0, D)
         g.vt = ca_vt + (size_t)i * batch * D * Mp; g.vt_col0 = D; g.vt_ld = Mp; g.rows_per_batch = ctx_tokens;
-        g.qk_w0 = m->blocks[i].ca_k_norm_w; g.qk_cols0 = D; g.qk_cols1 = D;  // k_norm applied once, here
+        if (hd64) { g.qk_w0 = m->blocks[i].ca_k_norm_w; g.qk_cols0 = D; g.qk_cols1 = D; }  // k_norm applied once, here
         GA_TRY(ga_gemm_bf16(&g, stream));
+        if (!hd64) GA_TRY(ga_head_rmsnorm_bf16(ca_k + (size_t)i * rows * D, rows, D, m->heads, D / m->heads, m->blocks[i].ca_k_norm_w, stream));
     }
     return GA_DIT_OK;
 }
@@ -741,7 +738,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     static const int ncu = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();
     bool sb_tail = false, sb_tail0 = false;
     const int ca_batch = (a->ca_batch <= 0 || a->ca_batch > B) ? B : a->ca_batch;
-    if (fold_mod && sb_tail_env) {
+    if (fold_mod && sb_tail_env && hd == 64) {      // (other head dims: all blocks' shift rows in the one launch up front)
         const GaAttentionArgs probe{B, m->heads, L, L, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0};
         sb_tail = attention_workgroups(&probe) + shift_bias_wgs(3 * D, 4 * D) <= ncu;
         // round 5: block 0's rows ride the same way behind block 0's CROSS-attention grid (its qkv projection is the first consumer):
@@ -805,47 +802,74 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
         // rowss (below); the q projection, with the norm weight folded into its columns, applies rsqrt(mean + eps) to its rows.
         const bool folded = i > 0 && can_fold(m, i);
         if (hd != 64) {
-            // HEAD DIMS OTHER THAN 64 (DiT-PixArt-PCD-CLAY-XL: 16 heads of 72): the same block with nothing folded -- plain projections, the
-            // per-head q / k norms as a pass of their own, ga_attention_hd_bf16 on row-major q | k | v (correctness-first, dit_attention_hd.hip)
-            GaRmsNormArgs n0{Mca, D, L, w.xres, bw.prenorm_ca_w, nullptr, nullptr, 0, w.xn, nullptr, 0};
-            GA_TRY(ga_rmsnorm_modulate(&n0, stream));
+            // HEAD DIMS OTHER THAN 64 (DiT-PixArt-PCD-CLAY-XL: 16 heads of 72): the same block without the attention-launch tails -- k's per-head
+            // norm as a pass of its own (the GEMM epilogue's is 64-wide), ga_attention_hd_bf16 on q | k row-major + V^T
+            // round 6: the three pre-norms folded into the neighbouring GEMMs as on the 64-wide path (fold_mod; `folded`: this block's
+            // cross-attention pre-norm, whose operand the previous block's fc2 left behind) -- three launches per block less
+            const float *sbias_x = w.sbias + (size_t)i * B * 7 * D;   // [B][3D] qkv | [B][4D] fc1
+            if (!(fold_mod && folded)) {
+                GaRmsNormArgs n0{Mca, D, L, w.xres, bw.prenorm_ca_w, nullptr, nullptr, 0, w.xn, nullptr, 0};
+                GA_TRY(ga_rmsnorm_modulate(&n0, stream));
+            }
             GaGemmArgs gq{};
-            gq.M = Mca; gq.N = D; gq.K = D; gq.epilogue = GA_GEMM_EPI_STORE_BF16; gq.A = w.xn; gq.lda = D; gq.W = bw.ca_q_w;
+            gq.M = Mca; gq.N = D; gq.K = D; gq.epilogue = GA_GEMM_EPI_STORE_BF16; gq.A = w.xn; gq.lda = D;
+            gq.W = (fold_mod && folded) ? bw.ca_q_w_prenorm : bw.ca_q_w;
             gq.w_tiled = m->gemm_weights_tiled; gq.out = w.qkv; gq.ldo = D;
+            if (fold_mod && folded) { gq.row_ss = w.rowss; gq.row_ss_tiles = D / 64; gq.row_ss_dim = D; gq.row_ss_eps = 1e-5f; }
             GA_TRY(ga_gemm_bf16(&gq, stream));
-            GA_TRY(ga_head_rmsnorm_bf16(w.qkv, Mca, D, m->heads, hd, bw.ca_q_norm_w, stream));
-            const ga_bf16 *ckv = a->ca_k + (size_t)i * kv_rows * 2 * D;
             if (i == 0 && !join()) return GA_DIT_ERR_LAUNCH;
-            GaAttentionHdArgs ca{ca_batch, m->heads, L, a->ctx_tokens, hd, w.qkv, ckv, ckv + D, D, 2 * D, 2 * D, w.att, D};
+            // (V^T of the image tokens from the cache like the 64-wide path, q's norm inside the attention kernel)
+            GaAttentionHdArgs ca{ca_batch, m->heads, L, a->ctx_tokens, hd, w.qkv, a->ca_k + (size_t)i * kv_rows * D, nullptr, D, D, 0, w.att, D,
+                                 a->ca_vt + (size_t)i * B * D * Mp, Mp, bw.ca_q_norm_w};
             GA_TRY(ga_attention_hd_bf16(&ca, stream));
             GaGemmArgs go{};
             go.M = Mca; go.N = D; go.K = D; go.epilogue = GA_GEMM_EPI_RESIDUAL; go.A = w.att; go.lda = D; go.W = bw.ca_out_w; go.w_tiled = m->gemm_weights_tiled;
             go.bias = bw.ca_out_b; go.out = w.xres; go.ldo = D; go.gate = nullptr; go.rows_per_batch = L;
+            if (fold_mod) {     // over ALL rows (the items that skipped the cross-attention take the bias with a zero product), emitting norm1's operand
+                go.M = Mrows; go.k_rows = Mca;
+                go.emit_x = w.xn; go.emit_ld = D; go.emit_ss = w.rowss; go.emit_w = bw.norm1_w; go.emit_scale = mod + 1 * D; go.emit_scale_stride = 6 * (int64_t)D;
+            }
             GA_TRY(ga_gemm_bf16(&go, stream));
-            GaRmsNormArgs n1{Mrows, D, L, w.xres, bw.norm1_w, mod + 1 * D, mod + 0 * D, 6 * (int64_t)D, w.xn, Mca < Mrows ? bw.ca_out_b : nullptr, Mca};
-            GA_TRY(ga_rmsnorm_modulate(&n1, stream));
+            if (!fold_mod) {
+                GaRmsNormArgs n1{Mrows, D, L, w.xres, bw.norm1_w, mod + 1 * D, mod + 0 * D, 6 * (int64_t)D, w.xn, Mca < Mrows ? bw.ca_out_b : nullptr, Mca};
+                GA_TRY(ga_rmsnorm_modulate(&n1, stream));
+            }
             GaGemmArgs gqkv{};
             gqkv.M = Mrows; gqkv.N = 3 * D; gqkv.K = D; gqkv.epilogue = GA_GEMM_EPI_STORE_BF16; gqkv.A = w.xn; gqkv.lda = D; gqkv.W = bw.qkv_w;
-            gqkv.w_tiled = m->gemm_weights_tiled; gqkv.bias = bw.qkv_b; gqkv.out = w.qkv; gqkv.ldo = 3 * D;
+            gqkv.w_tiled = m->gemm_weights_tiled; gqkv.bias = bw.qkv_b; gqkv.out = w.qkv; gqkv.ldo = 2 * D;      // q | k row-major ...
+            gqkv.vt = w.vt; gqkv.vt_col0 = 2 * D; gqkv.vt_ld = Lp; gqkv.rows_per_batch = L;                      // ... v transposed (width-generic)
+            if (fold_mod) {
+                gqkv.row_ss = w.rowss; gqkv.row_ss_tiles = D / 64; gqkv.row_ss_dim = D; gqkv.row_ss_eps = 1e-5f;
+                gqkv.bias = sbias_x; gqkv.bias_stride = 3 * (int64_t)D;
+            }
             GA_TRY(ga_gemm_bf16(&gqkv, stream));
-            GA_TRY(ga_head_rmsnorm_bf16(w.qkv, Mrows, 3 * D, m->heads, hd, bw.q_norm_w, stream));
-            GA_TRY(ga_head_rmsnorm_bf16(w.qkv + D, Mrows, 3 * D, m->heads, hd, bw.k_norm_w, stream));
-            GaAttentionHdArgs sa{B, m->heads, L, L, hd, w.qkv, w.qkv + D, w.qkv + 2 * D, 3 * D, 3 * D, 3 * D, w.att, D};
+            GA_TRY(ga_head_rmsnorm_bf16(w.qkv + D, Mrows, 2 * D, m->heads, hd, bw.k_norm_w, stream));
+            GaAttentionHdArgs sa{B, m->heads, L, L, hd, w.qkv, w.qkv + D, nullptr, 2 * D, 2 * D, 0, w.att, D, w.vt, Lp, bw.q_norm_w};
             GA_TRY(ga_attention_hd_bf16(&sa, stream));
             GaGemmArgs gp{};
             gp.M = Mrows; gp.N = D; gp.K = D; gp.epilogue = GA_GEMM_EPI_RESIDUAL; gp.A = w.att; gp.lda = D; gp.W = bw.proj_w; gp.w_tiled = m->gemm_weights_tiled;
             gp.bias = bw.proj_b; gp.out = w.xres; gp.ldo = D; gp.gate = mod + 2 * D; gp.gate_stride = 6 * (int64_t)D; gp.rows_per_batch = L;
+            if (fold_mod) {
+                gp.emit_x = w.xn; gp.emit_ld = D; gp.emit_ss = w.rowss; gp.emit_w = bw.norm2_w; gp.emit_scale = mod + 4 * D; gp.emit_scale_stride = 6 * (int64_t)D;
+            }
             GA_TRY(ga_gemm_bf16(&gp, stream));
-            GaRmsNormArgs n2{Mrows, D, L, w.xres, bw.norm2_w, mod + 4 * D, mod + 3 * D, 6 * (int64_t)D, w.xn, nullptr, 0};
-            GA_TRY(ga_rmsnorm_modulate(&n2, stream));
+            if (!fold_mod) {
+                GaRmsNormArgs n2{Mrows, D, L, w.xres, bw.norm2_w, mod + 4 * D, mod + 3 * D, 6 * (int64_t)D, w.xn, nullptr, 0};
+                GA_TRY(ga_rmsnorm_modulate(&n2, stream));
+            }
             GaGemmArgs g1{};
             g1.M = Mrows; g1.N = 4 * D; g1.K = D; g1.epilogue = GA_GEMM_EPI_GELU_BF16; g1.A = w.xn; g1.lda = D; g1.W = bw.fc1_w; g1.w_tiled = m->gemm_weights_tiled;
             g1.bias = bw.fc1_b; g1.out = w.hmid; g1.ldo = 4 * D;
+            if (fold_mod) {
+                g1.row_ss = w.rowss; g1.row_ss_tiles = D / 64; g1.row_ss_dim = D; g1.row_ss_eps = 1e-5f;
+                g1.bias = sbias_x + (size_t)B * 3 * D; g1.bias_stride = 4 * (int64_t)D; g1.rows_per_batch = L;
+            }
             GA_TRY(ga_gemm_bf16(&g1, stream));
             GaGemmArgs g2{};
             g2.M = Mrows; g2.N = D; g2.K = 4 * D; g2.epilogue = GA_GEMM_EPI_RESIDUAL; g2.A = w.hmid; g2.lda = 4 * D; g2.W = bw.fc2_w;
             g2.w_tiled = m->gemm_weights_tiled; g2.bias = bw.fc2_b; g2.out = w.xres; g2.ldo = D; g2.gate = mod + 5 * D; g2.gate_stride = 6 * (int64_t)D;
             g2.rows_per_batch = L;
+            if (fold_mod && i + 1 < m->depth && can_fold(m, i + 1)) { g2.emit_x = w.xn; g2.emit_ld = D; g2.emit_ss = w.rowss; }
             GA_TRY(ga_gemm_bf16(&g2, stream));
             continue;
         }

@@ -278,14 +278,13 @@ class DiT_I23D_PCD_PixelArt_noclip(nn.Module):
         ctx = ctx_tokens.detach().to(torch.bfloat16).contiguous()
         Mp = (M + 63) // 64 * 64
         old = self._ctx_cache[1] if self._ctx_cache is not None else None
-        hd64 = self.embed_dim // self.num_heads == 64
-        kcols = self.embed_dim if hd64 else 2 * self.embed_dim      # head dims other than 64: K | V row-major, no V^T image (ga_dit.h)
+        kcols = self.embed_dim      # (round 6: K row-major + V^T for every head dim)
         if old is not None and old[0].shape == (self.depth, B * M, kcols) and old[0].device == ctx.device:
             ck, cvt = old[0], old[1]   # same shapes: projected in place (the pad columns of cvt stay zero), so a captured sampler step
                                        # that has these addresses baked in serves the next sample's conditioning as well
         else:
             ck = torch.empty((self.depth, B * M, kcols), dtype=torch.bfloat16, device=ctx.device)
-            cvt = torch.zeros((self.depth, B * self.embed_dim, Mp) if hd64 else (8,), dtype=torch.bfloat16, device=ctx.device)
+            cvt = torch.zeros((self.depth, B * self.embed_dim, Mp), dtype=torch.bfloat16, device=ctx.device)
         stream = ctypes.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream)
         ops.check(ops.lib().ga_dit_cache_context(ctypes.byref(pack["model"]), B, M, ctx.data_ptr(), ck.data_ptr(),
                                                  cvt.data_ptr(), stream), "ga_dit_cache_context")

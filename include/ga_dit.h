@@ -71,8 +71,10 @@ typedef struct GaGemmArgs {
      *   producer, EPI 2 only, optional (N % 64 == 0): besides x += ..., write emit_x[m][n] = bf16(x_new[m][n]) and
      *     emit_ss[m][n / 64] = sum of x_new[m][.]^2 over that 64-column group (fixed order: deterministic);
      *   consumer, EPI 0 only, optional: with A = emit_x and W', every output row is scaled by
-     *     rsqrt(sum_t row_ss[m][t] / row_ss_dim + row_ss_eps) (t < row_ss_tiles <= 16, row_ss_tiles % 4 == 0) before the
-     *     per-head qk-norm and the store.
+     *     rsqrt(sum_t row_ss[m][t] / row_ss_dim + row_ss_eps) (t < row_ss_tiles) before the per-head qk-norm and the store.
+     *     Row m of emit_ss / row_ss starts (tiles rounded up to a multiple of 4) floats after row m - 1; the producer writes the pad
+     *     entries as zeros (round 6: widths that are no multiple of 256 -- 1152: 18 sums, 20 floats per row).  row_ss_tiles <= 16
+     *     when K is a multiple of 256, <= 20 otherwise; 16-byte aligned.
      * The activations are rounded to bf16 before instead of after the row scale and weight: the same relative rounding. */
     ga_bf16 *emit_x;
     float *emit_ss;
@@ -160,14 +162,21 @@ int ga_attention_bf16(const GaAttentionArgs *args, void *stream);
 /* The same attention for head dims OTHER than 64 (head_dim % 8 == 0, <= 128): DiT-PixArt-PCD-CLAY-XL of the reference registry has 16
  * heads of 72 (/root/reference/dit/dit_i23d.py:1526-1535, 1677).  q, k, v row-major: row (b, i) of q starts at q + (b*Lq + i)*q_stride +
  * h*head_dim (k, v: b*Lk + j); q and k ALREADY carry their per-head RMSNorm (ga_head_rmsnorm_bf16); softmax scale head_dim^-1/2.
- * 16-byte aligned operands, strides % 8 == 0; out 8-byte aligned, out_stride % 4 == 0.  A correctness-first kernel (the 64-wide one
- * is the tuned path of the released models). */
+ * 16-byte aligned operands, strides % 8 == 0; out 8-byte aligned, out_stride % 4 == 0.  With v row-major: the correctness-first kernel of
+ * round 5; with vt (below): the tuned one ga_dit_forward uses. */
 typedef struct GaAttentionHdArgs {
     int32_t batch, heads, Lq, Lk, head_dim;
     const ga_bf16 *q, *k, *v;
     int64_t q_stride, k_stride, v_stride;   /* elements */
     ga_bf16 *out;
     int64_t out_stride;
+    /* Round 6, the tuned variant: vt != NULL -> v / v_stride are ignored and V is read TRANSPOSED, row (b*heads + h)*head_dim + d of
+     * vt holds V[b][:, h, d] with the keys contiguous (vt_ld elements per row, a multiple of 64 >= Lk rounded up to 64, columns >= Lk
+     * finite) -- the image GaGemmArgs.vt stores for any width.  q_norm_weight != NULL (fp32 [head_dim], 16-byte aligned; V^T variant
+     * only): q arrives WITHOUT its per-head RMSNorm, which is applied here (eps 1e-5, dit/norm.py:29-43). */
+    const ga_bf16 *vt;
+    int64_t vt_ld;
+    const float *q_norm_weight;
 } GaAttentionHdArgs;
 
 int ga_attention_hd_bf16(const GaAttentionHdArgs *args, void *stream);

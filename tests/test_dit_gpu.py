@@ -20,7 +20,9 @@ def rel_l2(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 384, 128), (1536, 1024, 1024), (77, 260, 192)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 384, 128), (1536, 1024, 1024), (77, 260, 192),
+                                   # K a multiple of 192 but not of 256 (DiT-PixArt-PCD-CLAY-XL: width 1152): the three-slot ring, all four tiles
+                                   (1536, 3456, 1152), (1536, 1152, 4608), (768, 1152, 1152), (768, 4608, 1152), (200, 136, 384)])
 def test_gemm_epilogues(gpu_device, M, N, K):
     from gaussiananything_amd import dit_ops as ops
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
@@ -111,6 +113,22 @@ def test_qkv_projection_with_head_norm_and_transposed_v_on_every_tile(gpu_device
     assert L == Lp or float(vt[:, L:].abs().max()) == 0.0
 
 
+def test_gemm_transposed_v_store_is_width_generic(gpu_device):
+    """Round 6: the same V^T store for heads of 72 (width 1152 = 18 column groups of 64, heads straddle them): row b*D + c of the image is
+    column c of item b's V, whatever the head dim -- what ga_attention_hd_bf16's tuned variant reads."""
+    from gaussiananything_amd import dit_ops as ops
+    B, L, D, K = 2, 768, 1152, 1152
+    g = torch.Generator(device="cpu").manual_seed(19)
+    A = torch.randn(B * L, K, generator=g).to(gpu_device).bfloat16()
+    W = (torch.randn(3 * D, K, generator=g) / 34).to(gpu_device).bfloat16()
+    bias = torch.randn(3 * D, generator=g).to(gpu_device)
+    vt = torch.zeros(B * D, L, device=gpu_device, dtype=torch.bfloat16)
+    out = ops.gemm(A, W, bias, ops.EPI_STORE_BF16, rows_per_batch=L, vt=vt, vt_col0=2 * D)
+    ref = (A.float() @ W.float().T + bias)
+    assert out.shape == (B * L, 2 * D) and rel_l2(out.float(), ref[:, :2 * D]) < 1e-2
+    assert rel_l2(vt.float(), ref[:, 2 * D:].reshape(B, L, D).permute(0, 2, 1).reshape(B * D, L)) < 1e-2
+
+
 def test_gemm_is_transpose_sensitive(gpu_device):
     """A = I with an asymmetric W: a swapped row/column mapping in the epilogue cannot pass."""
     from gaussiananything_amd import dit_ops as ops
@@ -122,7 +140,8 @@ def test_gemm_is_transpose_sensitive(gpu_device):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(1536, 4096, 1024, "gelu"), (1536, 1024, 4096, "res"), (768, 1024, 1024, "bf16"),
-                                       (1536, 3072, 1024, "bf16"), (200, 264, 192, "f32"), (6144, 1024, 1024, "res")])
+                                       (1536, 3072, 1024, "bf16"), (200, 264, 192, "f32"), (6144, 1024, 1024, "res"),
+                                       (1536, 4608, 1152, "gelu"), (1536, 1152, 4608, "res"), (768, 1152, 1152, "bf16"), (768, 3456, 1152, "bf16")])
 def test_gemm_tiled_weight_image_gives_the_same_bits(gpu_device, M, N, K, epi):
     """GaGemmArgs.w_tiled (the [N/8][K/64][8][64] image the DiT stores its weights in): only the addresses the LDS-DMA reads
     from change, so every kernel variant (the three ring tiles and the 2-slot kernel of the small shape) must give the
@@ -321,6 +340,7 @@ def test_attention_for_head_dims_other_than_64(gpu_device, B, H, Lq, Lk, d):
     q_ref = nrm(qkv[:, :H * d].float().view(B, Lq, H, d), wq)
     k_ref = nrm(kv[:, :H * d].float().view(B, Lk, H, d), wk)
     v_ref = kv[:, H * d:].float().view(B, Lk, H, d)
+    q_raw = qkv.clone()
     ops.head_rmsnorm_(qkv, H, d, wq)
     ops.head_rmsnorm_(kv, H, d, wk)
     assert rel_l2(qkv[:, :H * d].float().view(B, Lq, H, d), q_ref) < 6e-3 and rel_l2(kv[:, :H * d].float().view(B, Lk, H, d), k_ref) < 6e-3
@@ -330,6 +350,33 @@ def test_attention_for_head_dims_other_than_64(gpu_device, B, H, Lq, Lk, d):
     sc = torch.einsum("bqhd,bkhd->bhqk", q_ref, k_ref) / d ** 0.5
     ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(sc, -1), v_ref).reshape(B, Lq, H * d)
     assert rel_l2(out.float(), ref) < 1.2e-2, rel_l2(out.float(), ref)
+    # round 6, the tuned variant (what ga_dit_forward runs): V^T as the projection GEMM stores it, q's norm inside the kernel
+    vt = ops.v_transposed_hd(kv.view(B, Lk, 2 * H * d)[..., H * d:].unflatten(-1, (H, d)))
+    k_n = kv.view(B, Lk, 2 * H * d)[..., :H * d].unflatten(-1, (H, d))
+    for force in ("1", "2", None):           # 64- and 128-query workgroups, then the launcher's own choice
+        got = _run_hdv(gpu_device, q_raw.view(B, Lq, 3 * H * d)[..., :H * d].unflatten(-1, (H, d)), k_n, vt, wq, force)
+        assert rel_l2(got.float(), ref) < 1.2e-2, (force, rel_l2(got.float(), ref))
+        assert rel_l2(got.float(), out.float()) < 8e-3, (force, rel_l2(got.float(), out.float()))
+    got2 = ops.attention_hd(qkv.view(B, Lq, 3 * H * d)[..., :H * d].unflatten(-1, (H, d)), k_n, vt=vt)     # q normalised by the caller
+    assert rel_l2(got2.float(), ref) < 1.2e-2
+
+
+def _run_hdv(dev, q, k, vt, wq, force_qf):
+    """GA_ATTN_HD_QF is read once per process: the forced variants run in a child process on the same tensors (saved / loaded)."""
+    from gaussiananything_amd import dit_ops as ops
+    if force_qf is None:
+        return ops.attention_hd(q, k, vt=vt, q_norm_weight=wq)
+    import os, subprocess, sys, tempfile
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "io.pt")
+        torch.save({"q": q.cpu(), "k": k.cpu(), "vt": vt.cpu(), "wq": wq.cpu()}, f)
+        code = ("import torch\nfrom gaussiananything_amd import dit_ops as ops\n"
+                f"z = torch.load({f!r})\nq, k, vt, wq = (z[n].to('cuda:0') for n in ('q', 'k', 'vt', 'wq'))\n"
+                "q = q.contiguous(); k = k.contiguous()\n"
+                f"torch.save(ops.attention_hd(q, k, vt=vt, q_norm_weight=wq).cpu(), {f + '.out'!r})\n")
+        env = dict(os.environ, GA_ATTN_HD_QF=force_qf, PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + sys.path))
+        subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=600)
+        return torch.load(f + ".out").to(dev)
 
 
 def test_model_with_heads_of_72_matches_the_reference_golden(gpu_device):
@@ -659,6 +706,49 @@ def test_final_layer_statistics_on_rows_with_a_large_common_offset(gpu_device):
     with torch.no_grad():
         y = model(x.to(gpu_device), t.to(gpu_device), {k: v.to(gpu_device) for k, v in ctx.items()})
     assert rel_l2(y.cpu(), ref) < 1e-2, rel_l2(y.cpu(), ref)
+
+
+def test_xl_geometry_against_oracle_folded_and_unfolded(gpu_device):
+    """DiT-PixArt-PCD-CLAY-XL's geometry (/root/reference/dit/dit_i23d.py:1526-1535: width 1152, 16 heads of 72) at the release shapes, depth 3,
+    against the fp32 oracle: the round-6 path -- three-slot GEMM rings (K = 1152 is no multiple of 256), 18 -> 20 partial sums per row behind
+    the folded pre-norms, V^T for heads of 72, q's norm inside the attention kernel -- and, in a child process (GA_DIT_FOLD_MOD is read once),
+    the same model with the pre-norms as launches of their own."""
+    import subprocess, sys, tempfile
+    from gaussiananything_amd.dit import DiT_I23D_PCD_PixelArt_noclip
+    from oracle import dit as od
+    kw = dict(input_size=16, patch_size=1, in_channels=3, hidden_size=1152, depth=3, num_heads=16, num_classes=0, learn_sigma=False,
+              context_dim=1024, pooling_ctx_dim=768, roll_out=True, use_clay_ca=True)
+    torch.manual_seed(0)
+    model = DiT_I23D_PCD_PixelArt_noclip(**kw)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for p in model.parameters():
+            if float(p.abs().max()) == 0.0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = torch.randn(2, 768, 3, generator=g)
+    t = torch.tensor([0.6, 0.6])
+    ctx = {"img_crossattn": torch.randn(2, 1369, 1024, generator=g), "img_vector": torch.randn(2, 1024, generator=g)}
+    ctx["img_crossattn"][1] = 0
+    ctx["img_vector"][1] = 0
+    torch.set_num_threads(min(64, len(os.sched_getaffinity(0))))
+    ref = od.dit_forward(sd, x, t, ctx)
+    model.to(gpu_device)
+    with torch.no_grad():
+        y = model(x.to(gpu_device), t.to(gpu_device), {k: v.to(gpu_device) for k, v in ctx.items()})
+    assert rel_l2(y.cpu(), ref) < 1.5e-2, rel_l2(y.cpu(), ref)
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "io.pt")
+        torch.save({"kw": kw, "sd": sd, "x": x, "t": t, "ctx": ctx}, f)
+        code = ("import torch\nfrom gaussiananything_amd.dit import DiT_I23D_PCD_PixelArt_noclip\n"
+                f"z = torch.load({f!r})\nm = DiT_I23D_PCD_PixelArt_noclip(**z['kw'])\nm.load_state_dict(z['sd'])\nm.to('cuda:0')\n"
+                "with torch.no_grad():\n    y = m(z['x'].to('cuda:0'), z['t'].to('cuda:0'), {k: v.to('cuda:0') for k, v in z['ctx'].items()})\n"
+                f"torch.save(y.cpu(), {f + '.out'!r})\n")
+        env = dict(os.environ, GA_DIT_FOLD_MOD="0", PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + sys.path))
+        subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=600)
+        y_unf = torch.load(f + ".out")
+    assert rel_l2(y_unf, ref) < 1.5e-2, rel_l2(y_unf, ref)
+    assert rel_l2(y.cpu(), y_unf) < 1e-2 and not torch.equal(y.cpu(), y_unf)       # (two different launch sequences, both at the oracle's bar)
 
 
 @pytest.mark.parametrize("arch,C", [("DiT-PixArt-PCD-CLAY-L", 3), ("DiT-PixArt-PCD-CLAY-stage2-L", 10)])
