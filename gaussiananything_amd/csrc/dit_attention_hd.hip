@@ -146,13 +146,15 @@ __global__ __launch_bounds__(256) void attention_hd_kernel(GaAttentionHdArgs a)
 // Round 6: the TUNED variant, taken when the caller passes V^T (GaAttentionHdArgs.vt: the image the projection GEMM's epilogue stores for
 // any width, [batch * heads * head_dim][vt_ld], keys contiguous).  What changed against the kernel above:
 //   * V^T arrives transposed: both tiles are 16-byte row copies (the 2-byte transposing LDS stores are gone);
-//   * QF = 2 query fragments per wave (128-query workgroups): every K / V^T fragment read from LDS feeds two MFMAs, a tile is staged once for
-//     twice the queries; QF = 1 where 128-query workgroups would leave most CUs empty (one sample's cross-attention: 16 heads x 6 tiles);
+//   * 128-query workgroups of EIGHT waves x 16 queries where they give the chip a round of work (a CFG pair's self-attention: 192): two
+//     waves per SIMD overlap each other's LDS / exponent / MFMA phases; 64-query workgroups of four waves otherwise (one sample's
+//     cross-attention: 192 of those); four waves x 32 queries (QF = 2: every fragment read feeds two MFMAs) measured behind both;
 //   * grid (heads * batch, query tiles): the workgroups of one (batch, head) sit on one XCD and share its L2 copy of K / V^T;
 //   * two LDS buffers, tile t + 1 in registers while tile t is multiplied: one barrier per tile;
 //   * the head dim in 16-wide steps, not 32: 72 = two MFMA k-steps of 32 and one of 16 for Q K^T (80 columns, not 96), five d tiles for P V;
 //   * q's per-head RMSNorm here (q_norm_weight): the lane groups that hold a row's fragments add up its squares with two lane swaps -- a
-//     launch per attention less; the softmax scale goes into the exponent's FMA instead of a second bf16 rounding of q.
+//     launch per attention less; the softmax scale goes into the exponent's FMA instead of a second bf16 rounding of q; k's
+//     (k_norm_weight) by the 4 / 8 neighbouring lanes that stage a key row, between the tile's arrival in registers and its LDS store.
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_hd __attribute__((ext_vector_type(4)));
 
@@ -171,7 +173,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
     constexpr int NT = 64 * NW;     // NW waves of QF x 16 queries
     constexpr int KB = 64, HDP = HD16 * 16, KROW = HDP + 8, VROW = KB + 8, NK32 = HD16 / 2;
     constexpr bool K16 = (HD16 & 1) != 0;
-    constexpr int KCH = (KB * HD16 * 2 + NT - 1) / NT, VCH = (HDP * 8 + NT - 1) / NT;   // 16-byte chunks per thread and tile (upper bounds)
+    // K staging: TPR threads per key row (row tid / TPR), thread q of a row moves its 16-byte chunks q, q + TPR, ... -- a row's chunks sit in
+    // TPR neighbouring lanes, so k's per-head RMSNorm (k_norm_weight) is a lane-local sum and log2(TPR) xor-shuffles at commit time
+    constexpr int TPR = NT / KB, KCH = (HD16 * 2 + TPR - 1) / TPR, VCH = (HDP * 8 + NT - 1) / NT;   // chunks per thread and tile (upper bounds)
     constexpr int KT = KB * KROW, VT = HDP * VROW;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem_hd[];     // K[2][key][d] (d >= head_dim zero), V^T[2][d][key] (rows >= head_dim zero)
     uint16_t *Ks2 = smem_hd, *Vt2 = smem_hd + 2 * KT;
@@ -255,15 +259,23 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
     const uint16_t *kb_ = a.k + (size_t)b * Lk * a.k_stride + (size_t)h * hd;
     const uint16_t *vb_ = a.vt + ((size_t)b * a.heads + h) * hd * a.vt_ld;
     const int ntiles = (Lk + KB - 1) / KB;
-    // this thread's chunks of a tile: K chunk c = tid + 256 i -> (key row c / cpr, part c % cpr); V^T chunk -> (d row c >> 3, part c & 7)
+    // this thread's chunks of a tile: K chunks (row tid / TPR, part tid % TPR + TPR i); V^T chunk c = tid + NT i -> (d row c >> 3, part c & 7)
     // (compile-time indices throughout -- static_for, not unrolled loops inside the lambdas: those left the staging registers in scratch)
-    int k_row[KCH], k_lds[KCH], v_lds[VCH];
+    int v_lds[VCH];
     const uint16_t *v_src[VCH];
-    uint32_t k_part[KCH];
+    const int k_row = tid / TPR, k_q = tid - k_row * TPR;
+    bool k_ok[KCH];
+    static_for_hd<0, KCH>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; k_ok[i] = k_q + TPR * i < cpr; });
+    // k's norm weights of this thread's chunks (zero where there is no chunk, or no norm)
+    float kw[KCH][8];
     static_for_hd<0, KCH>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
-        const int c = tid + NT * i, row = c / cpr, part = c - row * cpr;
-        k_row[i] = row < KB ? row : -1; k_part[i] = (uint32_t)(row < KB ? part : 0) * 8u; k_lds[i] = row * KROW + part * 8;
+        float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+        if (a.k_norm_weight && k_ok[i]) {
+            w0 = *reinterpret_cast<const float4 *>(a.k_norm_weight + (k_q + TPR * i) * 8);
+            w1 = *reinterpret_cast<const float4 *>(a.k_norm_weight + (k_q + TPR * i) * 8 + 4);
+        }
+        kw[i][0] = w0.x; kw[i][1] = w0.y; kw[i][2] = w0.z; kw[i][3] = w0.w; kw[i][4] = w1.x; kw[i][5] = w1.y; kw[i][6] = w1.z; kw[i][7] = w1.w;
     });
     static_for_hd<0, VCH>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
             constexpr int i = decltype(ic)::value;
             // (no branch around a load: a chunk slot past the tile re-reads a valid address and is not committed.  With branches the register
             //  allocator joins the paths through copies of the loaded registers -- s_waitcnt vmcnt(0) straight after the barrier)
-            kreg[i] = *reinterpret_cast<const u32x4_hd *>(kb_ + (size_t)min(t * KB + max(k_row[i], 0), Lk - 1) * a.k_stride + k_part[i]);
+            kreg[i] = *reinterpret_cast<const u32x4_hd *>(kb_ + (size_t)min(t * KB + k_row, Lk - 1) * a.k_stride + (k_ok[i] ? k_q + TPR * i : 0) * 8);
         });
         static_for_hd<0, VCH>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
@@ -285,9 +297,29 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
         });
     };
     auto commit = [&](int buf) __attribute__((always_inline)) {
+        if (a.k_norm_weight) {      // kernel-uniform: k rows RMS-normalised on their way into LDS (bf16-rounded like ga_head_rmsnorm_bf16's)
+            float ss = 0.f;
+            static_for_hd<0, KCH>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = __uint_as_float(kreg[i][e] << 16), hi = __uint_as_float(kreg[i][e] & 0xffff0000u);
+                    ss += k_ok[i] ? lo * lo + hi * hi : 0.f;
+                }
+            });
+#pragma unroll
+            for (int o = 1; o < TPR; o <<= 1) ss += __shfl_xor(ss, o, 64);
+            const float rs = rsqrtf(ss / (float)hd + 1e-5f);
+            static_for_hd<0, KCH>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    kreg[i][e] = pack_bf16x2(__uint_as_float(kreg[i][e] << 16) * (rs * kw[i][2 * e]), __uint_as_float(kreg[i][e] & 0xffff0000u) * (rs * kw[i][2 * e + 1]));
+            });
+        }
         static_for_hd<0, KCH>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
-            if (k_row[i] >= 0) *reinterpret_cast<u32x4_hd *>(Ks2 + buf * KT + k_lds[i]) = kreg[i];
+            if (k_ok[i]) *reinterpret_cast<u32x4_hd *>(Ks2 + buf * KT + k_row * KROW + (k_q + TPR * i) * 8) = kreg[i];
         });
         static_for_hd<0, VCH>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
@@ -398,7 +430,10 @@ static int launch_hdv(const GaAttentionHdArgs &a, hipStream_t s)
     // hide each other's LDS / exponent latencies).  GA_ATTN_HD_QF forces one (A/B aid)
     static const int qf_env = [] { const char *e = getenv("GA_ATTN_HD_QF"); return e ? atoi(e) : 0; }();
     const long long wg128 = (long long)a.batch * a.heads * ((a.Lq + 127) / 128);
-    const int cfg = qf_env ? qf_env : (wg128 >= 160 ? 2 : 1);
+    // same-box (tools/attn_hd_bench.py, 16 heads of 72; us for configurations 1 | 2 | 3): a CFG pair's self-attention 23.4 | 25.2 | 21.4, one
+    // sample's cross-attention 27.9 | 40.3 | 33.6, one sample's self-attention 17.5 | 24.7 | 20.5 -- one wave per SIMD runs its phases back to back,
+    // two overlap; below a round of 128-query workgroups the 64-query ones win by filling more CUs
+    const int cfg = qf_env ? qf_env : (wg128 >= 160 ? 3 : 1);
     const int qpw = cfg == 1 ? 64 : 128;
     const dim3 grid((unsigned)(a.batch * a.heads), (unsigned)((a.Lq + qpw - 1) / qpw));
 #define GA_HDV_LAUNCH(QFV, NWV)                                                                                                   \
@@ -441,7 +476,8 @@ extern "C" int ga_attention_hd_bf16(const GaAttentionHdArgs *a, void *stream)
         return GA_DIT_ERR_BAD_SHAPE;
     if (((uintptr_t)a->q | (uintptr_t)a->k) % 16 != 0 || (uintptr_t)a->out % 8 != 0) return GA_DIT_ERR_BAD_SHAPE;
     if (a->vt) {     // the tuned variant: V^T [batch * heads * head_dim][vt_ld], vt_ld a multiple of 64 that covers the keys
-        if (a->vt_ld % 64 != 0 || a->vt_ld < (a->Lk + 63) / 64 * 64 || (uintptr_t)a->vt % 16 != 0 || (a->q_norm_weight && (uintptr_t)a->q_norm_weight % 16 != 0))
+        if (a->vt_ld % 64 != 0 || a->vt_ld < (a->Lk + 63) / 64 * 64 || (uintptr_t)a->vt % 16 != 0 || (a->q_norm_weight && (uintptr_t)a->q_norm_weight % 16 != 0) ||
+            (a->k_norm_weight && (uintptr_t)a->k_norm_weight % 16 != 0))
             return GA_DIT_ERR_BAD_SHAPE;
         hipStream_t sv = reinterpret_cast<hipStream_t>(stream);
         switch ((a->head_dim + 15) / 16) {
@@ -455,7 +491,7 @@ extern "C" int ga_attention_hd_bf16(const GaAttentionHdArgs *a, void *stream)
         default: return launch_hdv<8>(*a, sv);
         }
     }
-    if (a->q_norm_weight) return GA_DIT_ERR_BAD_SHAPE;     // (the norm inside the kernel belongs to the V^T variant)
+    if (a->q_norm_weight || a->k_norm_weight) return GA_DIT_ERR_BAD_SHAPE;     // (the norms inside the kernel belong to the V^T variant)
     if (a->v_stride % 8 || (uintptr_t)a->v % 16 != 0) return GA_DIT_ERR_BAD_SHAPE;
     const dim3 grid((unsigned)((a->Lq + 63) / 64), (unsigned)a->heads, (unsigned)a->batch);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -820,7 +820,7 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
             if (i == 0 && !join()) return GA_DIT_ERR_LAUNCH;
             // (V^T of the image tokens from the cache like the 64-wide path, q's norm inside the attention kernel)
             GaAttentionHdArgs ca{ca_batch, m->heads, L, a->ctx_tokens, hd, w.qkv, a->ca_k + (size_t)i * kv_rows * D, nullptr, D, D, 0, w.att, D,
-                                 a->ca_vt + (size_t)i * B * D * Mp, Mp, bw.ca_q_norm_w};
+                                 a->ca_vt + (size_t)i * B * D * Mp, Mp, bw.ca_q_norm_w, nullptr};
             GA_TRY(ga_attention_hd_bf16(&ca, stream));
             GaGemmArgs go{};
             go.M = Mca; go.N = D; go.K = D; go.epilogue = GA_GEMM_EPI_RESIDUAL; go.A = w.att; go.lda = D; go.W = bw.ca_out_w; go.w_tiled = m->gemm_weights_tiled;
@@ -843,8 +843,10 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
                 gqkv.bias = sbias_x; gqkv.bias_stride = 3 * (int64_t)D;
             }
             GA_TRY(ga_gemm_bf16(&gqkv, stream));
-            GA_TRY(ga_head_rmsnorm_bf16(w.qkv + D, Mrows, 2 * D, m->heads, hd, bw.k_norm_w, stream));
-            GaAttentionHdArgs sa{B, m->heads, L, L, hd, w.qkv, w.qkv + D, nullptr, 2 * D, 2 * D, 0, w.att, D, w.vt, Lp, bw.q_norm_w};
+            // (k's per-head norm inside the attention kernel too, GA_DIT_HD_KNORM=0: as a launch of its own -- A/B aid)
+            static const bool knorm_in = [] { const char *e = getenv("GA_DIT_HD_KNORM"); return !e || atoi(e) != 0; }();
+            if (!knorm_in) GA_TRY(ga_head_rmsnorm_bf16(w.qkv + D, Mrows, 2 * D, m->heads, hd, bw.k_norm_w, stream));
+            GaAttentionHdArgs sa{B, m->heads, L, L, hd, w.qkv, w.qkv + D, nullptr, 2 * D, 2 * D, 0, w.att, D, w.vt, Lp, bw.q_norm_w, knorm_in ? bw.k_norm_w : nullptr};
             GA_TRY(ga_attention_hd_bf16(&sa, stream));
             GaGemmArgs gp{};
             gp.M = Mrows; gp.N = D; gp.K = D; gp.epilogue = GA_GEMM_EPI_RESIDUAL; gp.A = w.att; gp.lda = D; gp.W = bw.proj_w; gp.w_tiled = m->gemm_weights_tiled;

@@ -34,7 +34,7 @@ class GaAttentionArgs(ctypes.Structure):
 class GaAttentionHdArgs(ctypes.Structure):
     _fields_ = [("batch", i32), ("heads", i32), ("Lq", i32), ("Lk", i32), ("head_dim", i32), ("q", c_p), ("k", c_p), ("v", c_p),
                 ("q_stride", i64), ("k_stride", i64), ("v_stride", i64), ("out", c_p), ("out_stride", i64),
-                ("vt", c_p), ("vt_ld", i64), ("q_norm_weight", c_p)]
+                ("vt", c_p), ("vt_ld", i64), ("q_norm_weight", c_p), ("k_norm_weight", c_p)]
 
 
 class GaRmsNormArgs(ctypes.Structure):
@@ -240,10 +240,10 @@ def attention(q, k, vt, q_norm_weight=None, k_norm_weight=None, qp=None):
     return out
 
 
-def attention_hd(q, k, v=None, vt=None, q_norm_weight=None):
+def attention_hd(q, k, v=None, vt=None, q_norm_weight=None, k_norm_weight=None):
     """Head dims other than 64: q [B,Lq,H,d], k / v [B,Lk,H,d] bf16 views (token stride arbitrary, head stride d), k already head-normalised
     -> [B,Lq,H*d] bf16.  ``v`` row-major: the round-5 kernel (q normalised by the caller).  ``vt`` = V^T [B*H*d, Lpad] (``v_transposed_hd``):
-    the tuned kernel; ``q_norm_weight`` fp32 [d] makes it apply q's per-head RMSNorm itself."""
+    the tuned kernel; ``q_norm_weight`` / ``k_norm_weight`` fp32 [d] make it apply q's / k's per-head RMSNorm itself."""
     _need_cuda(q, k, v if vt is None else vt)
     B, Lq, H, d = q.shape
     Lk = k.shape[1]
@@ -252,11 +252,11 @@ def attention_hd(q, k, v=None, vt=None, q_norm_weight=None):
     out = torch.empty((B, Lq, H * d), device=q.device, dtype=torch.bfloat16)
     if vt is None:
         a = GaAttentionHdArgs(B, H, Lq, Lk, d, q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(1), k.stride(1), v.stride(1), out.data_ptr(), H * d,
-                              None, 0, None)
+                              None, 0, None, None)
     else:
         assert vt.dtype == torch.bfloat16 and vt.stride(1) == 1 and vt.shape[0] == B * H * d
         a = GaAttentionHdArgs(B, H, Lq, Lk, d, q.data_ptr(), k.data_ptr(), None, q.stride(1), k.stride(1), 0, out.data_ptr(), H * d,
-                              vt.data_ptr(), vt.stride(0), _ptr(q_norm_weight))
+                              vt.data_ptr(), vt.stride(0), _ptr(q_norm_weight), _ptr(k_norm_weight))
     check(lib().ga_attention_hd_bf16(ctypes.byref(a), _stream(q)), "ga_attention_hd_bf16")
     return out
 

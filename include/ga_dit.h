@@ -177,6 +177,7 @@ typedef struct GaAttentionHdArgs {
     const ga_bf16 *vt;
     int64_t vt_ld;
     const float *q_norm_weight;
+    const float *k_norm_weight;   /* the same for k (every workgroup normalises the key rows it stages) */
 } GaAttentionHdArgs;
 
 int ga_attention_hd_bf16(const GaAttentionHdArgs *args, void *stream);

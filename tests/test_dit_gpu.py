@@ -340,7 +340,7 @@ def test_attention_for_head_dims_other_than_64(gpu_device, B, H, Lq, Lk, d):
     q_ref = nrm(qkv[:, :H * d].float().view(B, Lq, H, d), wq)
     k_ref = nrm(kv[:, :H * d].float().view(B, Lk, H, d), wk)
     v_ref = kv[:, H * d:].float().view(B, Lk, H, d)
-    q_raw = qkv.clone()
+    q_raw, kv_raw = qkv.clone(), kv.clone()
     ops.head_rmsnorm_(qkv, H, d, wq)
     ops.head_rmsnorm_(kv, H, d, wk)
     assert rel_l2(qkv[:, :H * d].float().view(B, Lq, H, d), q_ref) < 6e-3 and rel_l2(kv[:, :H * d].float().view(B, Lk, H, d), k_ref) < 6e-3
@@ -353,27 +353,32 @@ def test_attention_for_head_dims_other_than_64(gpu_device, B, H, Lq, Lk, d):
     # round 6, the tuned variant (what ga_dit_forward runs): V^T as the projection GEMM stores it, q's norm inside the kernel
     vt = ops.v_transposed_hd(kv.view(B, Lk, 2 * H * d)[..., H * d:].unflatten(-1, (H, d)))
     k_n = kv.view(B, Lk, 2 * H * d)[..., :H * d].unflatten(-1, (H, d))
-    for force in ("1", "2", None):           # 64- and 128-query workgroups, then the launcher's own choice
-        got = _run_hdv(gpu_device, q_raw.view(B, Lq, 3 * H * d)[..., :H * d].unflatten(-1, (H, d)), k_n, vt, wq, force)
+    k_raw = kv_raw.view(B, Lk, 2 * H * d)[..., :H * d].unflatten(-1, (H, d))
+    for force in ("1", "2", "3", None):      # 4 waves x 16 / x 32 queries, 8 waves x 16, then the launcher's own choice
+        got = _run_hdv(gpu_device, q_raw.view(B, Lq, 3 * H * d)[..., :H * d].unflatten(-1, (H, d)), k_n, vt, wq, None, force)
         assert rel_l2(got.float(), ref) < 1.2e-2, (force, rel_l2(got.float(), ref))
         assert rel_l2(got.float(), out.float()) < 8e-3, (force, rel_l2(got.float(), out.float()))
-    got2 = ops.attention_hd(qkv.view(B, Lq, 3 * H * d)[..., :H * d].unflatten(-1, (H, d)), k_n, vt=vt)     # q normalised by the caller
+        # ... and k's norm inside as well (every workgroup normalises the key rows it stages)
+        gotk = _run_hdv(gpu_device, q_raw.view(B, Lq, 3 * H * d)[..., :H * d].unflatten(-1, (H, d)), k_raw, vt, wq, wk, force)
+        assert rel_l2(gotk.float(), ref) < 1.2e-2, (force, rel_l2(gotk.float(), ref))
+        assert rel_l2(gotk.float(), got.float()) < 4e-3, (force, rel_l2(gotk.float(), got.float()))
+    got2 = ops.attention_hd(qkv.view(B, Lq, 3 * H * d)[..., :H * d].unflatten(-1, (H, d)), k_n, vt=vt)     # q and k normalised by the caller
     assert rel_l2(got2.float(), ref) < 1.2e-2
 
 
-def _run_hdv(dev, q, k, vt, wq, force_qf):
+def _run_hdv(dev, q, k, vt, wq, wk, force_qf):
     """GA_ATTN_HD_QF is read once per process: the forced variants run in a child process on the same tensors (saved / loaded)."""
     from gaussiananything_amd import dit_ops as ops
     if force_qf is None:
-        return ops.attention_hd(q, k, vt=vt, q_norm_weight=wq)
+        return ops.attention_hd(q, k, vt=vt, q_norm_weight=wq, k_norm_weight=wk)
     import os, subprocess, sys, tempfile
     with tempfile.TemporaryDirectory() as td:
         f = os.path.join(td, "io.pt")
-        torch.save({"q": q.cpu(), "k": k.cpu(), "vt": vt.cpu(), "wq": wq.cpu()}, f)
+        torch.save({"q": q.cpu(), "k": k.cpu(), "vt": vt.cpu(), "wq": wq.cpu(), "wk": None if wk is None else wk.cpu()}, f)
         code = ("import torch\nfrom gaussiananything_amd import dit_ops as ops\n"
                 f"z = torch.load({f!r})\nq, k, vt, wq = (z[n].to('cuda:0') for n in ('q', 'k', 'vt', 'wq'))\n"
-                "q = q.contiguous(); k = k.contiguous()\n"
-                f"torch.save(ops.attention_hd(q, k, vt=vt, q_norm_weight=wq).cpu(), {f + '.out'!r})\n")
+                "wk = None if z['wk'] is None else z['wk'].to('cuda:0')\nq = q.contiguous(); k = k.contiguous()\n"
+                f"torch.save(ops.attention_hd(q, k, vt=vt, q_norm_weight=wq, k_norm_weight=wk).cpu(), {f + '.out'!r})\n")
         env = dict(os.environ, GA_ATTN_HD_QF=force_qf, PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + sys.path))
         subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=600)
         return torch.load(f + ".out").to(dev)
