@@ -602,9 +602,13 @@ __device__ __forceinline__ void static_for(F &&f)
 // finds SK - 1 there reads the partials back with agent-scope loads and adds them IN SPLIT ORDER ((p0 + p1) + p2) + p3 -- its own
 // from registers, the same bits it stored -- so the result does not depend on who arrives last.  No fence (an agent-scope fence
 // writes back / invalidates the whole L2 of the XCD, see surfel_bin.hip: merge_runs); nobody waits for anybody: no residency assumption.
-template <int EPI, int WM, int WN, int FM, int FN, int NST, int PIPE, int SK = 0>
+// R: K-tiles beyond a multiple of NST (round 6: K = 1152 = 18 tiles runs the FOUR-slot ring with R = 2 -- the peeled tail is NST + R tiles
+// long; on the three-slot ring the same GEMMs ran 1.5 x longer, two tiles in flight per DMA latency instead of three)
+template <int EPI, int WM, int WN, int FM, int FN, int NST, int PIPE, int SK = 0, int R = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
 {
+    static_assert(R >= 0 && R < NST && (R == 0 || SK == 0), "remainder tiles");
+    constexpr int TAIL = NST + R;
     constexpr int NW = WM * WN, BM = WM * FM * 16, BNT = WN * FN * 16;
     constexpr int KS = 2, CPK = 4;            // k-steps of 32 per K-tile, 16-byte chunks per k-step
     constexpr int ROWS = BNT + BM;
@@ -715,11 +719,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
     ResidualPrefetch<PRE ? FM : 1> pre;
     if (PRE) residual_prefetch<FM, FN / 2>(p, reinterpret_cast<ResidualPrefetch<FM> &>(pre), mrow0, ncol0, lane);
     constexpr bool RSS = EPI == GA_GEMM_EPI_STORE_BF16 || EPI == GA_GEMM_EPI_GELU_BF16;
-    constexpr int NP = NST == 3 ? 5 : 4;      // (the three-slot instances serve the widths that are no multiple of 256: up to 20 partial sums per row)
+    constexpr int NP = (NST == 3 || R != 0) ? 5 : 4;      // (the instances that serve the widths that are no multiple of 256: up to 20 partial sums per row)
     RowSsPrefetch<RSS ? FM : 1, NP> rss;
     if (RSS && p.row_ss) rowss_prefetch<FM, NP>(p, reinterpret_cast<RowSsPrefetch<FM, NP> &>(rss), mrow0, lane);
 
-    // nk = n_main * NST + NST: the last NST tiles are peeled (compile-time slot, wait count, request-or-not)
+    // nk = n_main * NST + TAIL: the last TAIL = NST + R tiles are peeled (compile-time slot, wait count, request-or-not)
     const int n_main = nk / NST - 1;
     if (product) {
     static_for<0, NST - 1>([&](auto bc) __attribute__((always_inline)) { stage(bc, decltype(bc)::value); });
@@ -753,11 +757,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
             });
             kt += NST;
         }
-        static_for<0, NST>([&](auto ic) __attribute__((always_inline)) {
+        static_for<0, TAIL>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
-            constexpr bool st = i == 0;                        // tile kt+i+NST-1 exists
-            constexpr int fly = st ? NST - 2 : NST - 1 - i;    // issued tiles younger than this one
-            tile(ic, kt + i, std::integral_constant<bool, st>{}, std::integral_constant<int, fly>{});
+            constexpr bool st = i + NST - 1 < TAIL;            // tile kt+i+NST-1 exists
+            constexpr int fly = st ? NST - 2 : TAIL - 1 - i;   // issued tiles younger than this one
+            tile(std::integral_constant<int, i % NST>{}, kt + i, std::integral_constant<bool, st>{}, std::integral_constant<int, fly>{});
         });
     } else {
         bf16x8 fw[2][FN], fa[2][FM];
@@ -819,11 +823,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
             });
             kt += NST;
         }
-        static_for<0, NST>([&](auto ic) __attribute__((always_inline)) {
+        static_for<0, TAIL>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
-            constexpr int HO = i == NST - 1 ? 0 : (i == 0 ? 2 : 1);
-            constexpr int fly = HO == 2 ? NST - 3 : (NST - i - 2 > 0 ? NST - i - 2 : 0);   // issued tiles younger than kt+1
-            tile(ic, kt + i, std::integral_constant<int, HO>{}, std::integral_constant<int, fly>{});
+            constexpr int HO = i == TAIL - 1 ? 0 : (i + NST - 1 < TAIL ? 2 : 1);
+            constexpr int fly = HO == 2 ? NST - 3 : (TAIL - i - 2 > 0 ? (TAIL - i - 2 < NST - 3 ? TAIL - i - 2 : NST - 3) : 0);   // issued tiles younger than kt+i+1
+            tile(std::integral_constant<int, i % NST>{}, kt + i, std::integral_constant<int, HO>{}, std::integral_constant<int, fly>{});
         });
     }
     }   // product
@@ -1073,7 +1077,15 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
         // (a 48 x 64 two-wave tile that would give the N = 1024 residual GEMMs at 768 rows 256 workgroups instead of 192 measured 3 % slower per evaluation: not kept)
         const long long wg_96x128 = (long long)((a->N + 127) / 128) * ((a->M + 95) / 96);
         // round 6: K that is no multiple of 256 but one of 192 (DiT-PixArt-PCD-CLAY-XL: 1152, 4608) runs the same tiles on a ring of THREE slots
-        const int nst_ring = (nk % 4 == 0 && nk >= 8) ? (wide_ss ? 0 : 4) : ((nk % 3 == 0 && nk >= 6) ? 3 : 0);
+        // ... and, better (the same shapes ran 1.5 x longer on three slots: two tiles in flight per DMA latency instead of three): the FOUR-slot
+        // ring with two remainder tiles in its peeled tail where K is 2 tiles past a multiple of 4 (1152 = 18 tiles); three slots for what is left
+        // (GA_GEMM_REM=0: three slots as before, A/B aid)
+        static const int rem_env = [] { const char *e = getenv("GA_GEMM_REM"); return e ? atoi(e) : 1; }();
+        int nst_ring = 0, rem = 0;
+        if (nk % 4 == 0 && nk >= 8) nst_ring = wide_ss ? 0 : 4;
+        else if (rem_env && nk % 4 == 2 && nk >= 10) { nst_ring = 4; rem = 2; }
+        else if (nk % 3 == 0 && nk >= 6) nst_ring = 3;
+        const bool odd_k = nst_ring == 3 || rem != 0;     // (the instances added for such K: no fp32 store among them)
         if (nst_ring) {
             // (round 6: 144 instead of 160 -- DiT-B's qkv, 18 x 8 workgroups, is better off on this tile than on 864 of 64 x 64: 1.237 -> 1.222 ms per
             //  evaluation same-box; nothing else falls between the two.  GA_GEMM_BIGMIN: A/B aid)
@@ -1081,8 +1093,9 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
             // (a 192 x 128 grid of a little over one round -- XL's fc1, 36 x 8 = 288 workgroups on 256 CUs -- pays two rounds for 1.1: 37.8 us
             //  against 28.2 on the 2-slot 128 x 128 kernel below, 432 workgroups two to a CU; the rule is confined to the three-slot shapes so
             //  that no released model's choice moves)
-            const bool ragged_big = nst_ring == 3 && wg_big > 256 && wg_big * 4 < ((wg_big + 255) / 256) * 256 * 3;
-            if (nst_ring == 3 && (a->epilogue == GA_GEMM_EPI_STORE_F32 || ragged_big)) ring = 0;   // (no three-slot instance of the fp32 store: nothing asks for it)
+            static const int ragged_env = [] { const char *e = getenv("GA_GEMM_RAGGED"); return e ? atoi(e) : 1; }();
+            const bool ragged_big = ragged_env && odd_k && wg_big > 256 && wg_big * 4 < ((wg_big + 255) / 256) * 256 * 3;
+            if (odd_k && (a->epilogue == GA_GEMM_EPI_STORE_F32 || ragged_big)) ring = 0;   // (no such instance of the fp32 store: nothing asks for it)
             else if (wg_big >= bigmin && rows48) ring = 1;
             else if (ring4_env && a->epilogue != GA_GEMM_EPI_STORE_F32 && wg_96x128 >= 160 && wg_96x128 <= 256 && rows48) ring = 4;
             // (per-head norm on the 96 x 64 tile: its two 32-column waves exchange their sums through LDS, a barrier more than the
@@ -1128,30 +1141,30 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
                 if (pays && ring != 1 && a->epilogue == GA_GEMM_EPI_RESIDUAL && gx % 2 == 0 && gy % 4 == 0 && (gx * gy) % 8 == 0) pr.xmap = 1;
             }
             // (round 6: the k-step software pipeline of the 192 x 128 kernel on the 96 x 64 tile measured 1.5 - 2 % slower per evaluation: not kept)
-#define GA_RLAUNCH_N(E, NSTV)                                                                                             \
+#define GA_RLAUNCH_N(E, NSTV, RV)                                                                                         \
             if (ring == 4) {                                                                                              \
-                if (hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 2, 2, 3, 4, NSTV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTV * 224 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
-                hipLaunchKernelGGL((gemm_ring_kernel<E, 2, 2, 3, 4, NSTV, 2>), dim3((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 95) / 96)), \
+                if (hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 2, 2, 3, 4, NSTV, 2, 0, RV>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTV * 224 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
+                hipLaunchKernelGGL((gemm_ring_kernel<E, 2, 2, 3, 4, NSTV, 2, 0, RV>), dim3((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 95) / 96)), \
                                    dim3(256), NSTV * 224 * BK * 2, s, p);                                                 \
             } else if (ring == 1) {                                                                                       \
-                if (NSTV != 4 && hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 4, 2, 3, 4, NSTV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTV * 320 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
-                hipLaunchKernelGGL((gemm_ring_kernel<E, 4, 2, 3, 4, NSTV, 2>), dim3((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 191) / 192)), \
+                if ((NSTV != 4 || RV != 0) && hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 4, 2, 3, 4, NSTV, 2, 0, RV>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTV * 320 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
+                hipLaunchKernelGGL((gemm_ring_kernel<E, 4, 2, 3, 4, NSTV, 2, 0, RV>), dim3((unsigned)((a->N + 127) / 128), (unsigned)((a->M + 191) / 192)), \
                                    dim3(512), NSTV * 320 * BK * 2, s, p);                                                 \
             } else if (ring == 2) {                                                                                       \
-                if (NSTV != 4 && hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 2, 2, 3, 2, NSTV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTV * 160 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
-                hipLaunchKernelGGL((gemm_ring_kernel<E, 2, 2, 3, 2, NSTV, 0>), dim3((unsigned)((a->N + 63) / 64), (unsigned)((a->M + 95) / 96)), \
+                if ((NSTV != 4 || RV != 0) && hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 2, 2, 3, 2, NSTV, 0, 0, RV>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTV * 160 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
+                hipLaunchKernelGGL((gemm_ring_kernel<E, 2, 2, 3, 2, NSTV, 0, 0, RV>), dim3((unsigned)((a->N + 63) / 64), (unsigned)((a->M + 95) / 96)), \
                                    dim3(256), NSTV * 160 * BK * 2, s, pr);                                                \
             } else {                                                                                                      \
-                if (NSTV != 4 && hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 4, 1, 1, 4, NSTV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTV * 128 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
-                hipLaunchKernelGGL((gemm_ring_kernel<E, 4, 1, 1, 4, NSTV, 0>), dim3((unsigned)((a->N + 63) / 64), (unsigned)((a->M + 63) / 64)), \
+                if ((NSTV != 4 || RV != 0) && hipFuncSetAttribute((const void *)gemm_ring_kernel<E, 4, 1, 1, 4, NSTV, 0, 0, RV>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTV * 128 * BK * 2) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
+                hipLaunchKernelGGL((gemm_ring_kernel<E, 4, 1, 1, 4, NSTV, 0, 0, RV>), dim3((unsigned)((a->N + 63) / 64), (unsigned)((a->M + 63) / 64)), \
                                    dim3(256), NSTV * 128 * BK * 2, s, pr);                                                \
             }
-#define GA_RLAUNCH(E) if (nst_ring == 4) { GA_RLAUNCH_N(E, 4) } else { GA_RLAUNCH_N(E, 3) }
+#define GA_RLAUNCH(E) if (nst_ring == 4 && rem == 0) { GA_RLAUNCH_N(E, 4, 0) } else if (nst_ring == 4) { GA_RLAUNCH_N(E, 4, 2) } else { GA_RLAUNCH_N(E, 3, 0) }
             switch (a->epilogue) {
             case GA_GEMM_EPI_STORE_BF16: GA_RLAUNCH(0) break;
             case GA_GEMM_EPI_GELU_BF16: GA_RLAUNCH(1) break;
             case GA_GEMM_EPI_RESIDUAL: GA_RLAUNCH(2) break;
-            case GA_GEMM_EPI_STORE_F32: if (nst_ring != 4) return GA_DIT_ERR_BAD_SHAPE; GA_RLAUNCH_N(3, 4) break;
+            case GA_GEMM_EPI_STORE_F32: GA_RLAUNCH_N(3, 4, 0) break;     // (odd_k never gets here)
             default: return GA_DIT_ERR_BAD_SHAPE;
             }
 #undef GA_RLAUNCH_N
