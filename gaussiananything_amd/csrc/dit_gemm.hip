@@ -1159,6 +1159,9 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
                 hipLaunchKernelGGL((gemm_ring_kernel<E, 4, 1, 1, 4, NSTV, 0, 0, RV>), dim3((unsigned)((a->N + 63) / 64), (unsigned)((a->M + 63) / 64)), \
                                    dim3(256), NSTV * 128 * BK * 2, s, pr);                                                \
             }
+            // (round 6: a deeper ring -- 6 or 8 slots of the 96 x 64 tile, 120 / 160 KiB -- for the residual GEMMs that run one workgroup per CU
+            //  measured no gain, DiT-L 2.79 -> 2.81 / 2.83 ms per evaluation same-box: unlike the 192 x 128 tile at K = 1152, whose step from three
+            //  slots to four was worth 1.27 x, these are not bound by the tiles in flight)
 #define GA_RLAUNCH(E) if (nst_ring == 4 && rem == 0) { GA_RLAUNCH_N(E, 4, 0) } else if (nst_ring == 4) { GA_RLAUNCH_N(E, 4, 2) } else { GA_RLAUNCH_N(E, 3, 0) }
             switch (a->epilogue) {
             case GA_GEMM_EPI_STORE_BF16: GA_RLAUNCH(0) break;
