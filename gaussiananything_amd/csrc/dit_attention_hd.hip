@@ -148,7 +148,8 @@ __global__ __launch_bounds__(256) void attention_hd_kernel(GaAttentionHdArgs a)
 //   * V^T arrives transposed: both tiles are 16-byte row copies (the 2-byte transposing LDS stores are gone);
 //   * 128-query workgroups of EIGHT waves x 16 queries where they give the chip a round of work (a CFG pair's self-attention: 192): two
 //     waves per SIMD overlap each other's LDS / exponent / MFMA phases; 64-query workgroups of four waves otherwise (one sample's
-//     cross-attention: 192 of those); four waves x 32 queries (QF = 2: every fragment read feeds two MFMAs) measured behind both;
+//     cross-attention: 192 of those) -- there with TWO KEY GROUPS of four waves (KS = 2: alternate tiles, buffers of their own, one merge
+//     of (max, sum, O) through LDS at the end); four waves x 32 queries (QF = 2: every fragment read feeds two MFMAs) measured behind all of them;
 //   * grid (heads * batch, query tiles): the workgroups of one (batch, head) sit on one XCD and share its L2 copy of K / V^T;
 //   * two LDS buffers, tile t + 1 in registers while tile t is multiplied: one barrier per tile;
 //   * the head dim in 16-wide steps, not 32: 72 = two MFMA k-steps of 32 and one of 16 for Q K^T (80 columns, not 96), five d tiles for P V;
@@ -167,10 +168,13 @@ __device__ __forceinline__ void static_for_hd(F &&f)
     }
 }
 
-template <int HD16, int QF, int NW = 4>
+// KS = 2: two key groups of NW / 2 query waves each -- group ks takes the tiles ks, ks + 2, ... through buffers of its own, the groups' (max, sum,
+// O) meet in LDS at the end: where even 64-query workgroups leave the SIMDs one wave each (one sample's attention: 192 workgroups)
+template <int HD16, int QF, int NW = 4, int KS = 1>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2))) void attention_hdv_kernel(GaAttentionHdArgs a)
 {
-    constexpr int NT = 64 * NW;     // NW waves of QF x 16 queries
+    constexpr int NTW = 64 * NW;            // threads of the workgroup
+    constexpr int NWQ = NW / KS, NT = NTW / KS;     // query waves (QF x 16 queries each) and threads of one key group
     constexpr int KB = 64, HDP = HD16 * 16, KROW = HDP + 8, VROW = KB + 8, NK32 = HD16 / 2;
     constexpr bool K16 = (HD16 & 1) != 0;
     // K staging: TPR threads per key row (row tid / TPR), thread q of a row moves its 16-byte chunks q, q + TPR, ... -- a row's chunks sit in
@@ -178,12 +182,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
     constexpr int TPR = NT / KB, KCH = (HD16 * 2 + TPR - 1) / TPR, VCH = (HDP * 8 + NT - 1) / NT;   // chunks per thread and tile (upper bounds)
     constexpr int KT = KB * KROW, VT = HDP * VROW;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem_hd[];     // K[2][key][d] (d >= head_dim zero), V^T[2][d][key] (rows >= head_dim zero)
-    uint16_t *Ks2 = smem_hd, *Vt2 = smem_hd + 2 * KT;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    const int lane = threadIdx.x & 63, wave_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), g = lane >> 4, c16 = lane & 15;
+    const int ks = wave_all / NWQ, wave = wave_all - ks * NWQ, tid = (int)threadIdx.x - ks * NT;     // (tid: inside the key group)
+    uint16_t *Ks2 = smem_hd + ks * (2 * KT + 2 * VT), *Vt2 = Ks2 + 2 * KT;
     const int hd = a.head_dim, cpr = hd >> 3;
-    const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads, q0 = blockIdx.y * (16 * NW * QF) + wave * (16 * QF);
+    const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads, q0 = blockIdx.y * (16 * NWQ * QF) + wave * (16 * QF);
     const int Lq = a.Lq, Lk = a.Lk;
-    for (int i = tid; i < (2 * KT + 2 * VT) / 8; i += NT) reinterpret_cast<uint4 *>(smem_hd)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = threadIdx.x; i < KS * (2 * KT + 2 * VT) / 8; i += NTW) reinterpret_cast<uint4 *>(smem_hd)[i] = make_uint4(0u, 0u, 0u, 0u);
 
     // Q fragments (B operand of S^T = K Q^T): lane holds Q[q][kk*32 + g*8 .. +7] (k-steps of 32) and Q[q][NK32*32 + g*4 .. +3] (the step of 16)
     bf16x8 qf[QF][NK32 > 0 ? NK32 : 1];
@@ -326,19 +331,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
             if (v_lds[i] >= 0) *reinterpret_cast<u32x4_hd *>(Vt2 + buf * VT + v_lds[i]) = vreg[i];
         });
     };
-    issue(0);
+    issue(min(ks, ntiles - 1));
     __syncthreads();                               // the zero fill is done
     commit(0);
     const int krow = 8 * (c16 >> 2) + (c16 & 3);
-    for (int t = 0; t < ntiles; ++t) {
-        issue(min(t + 1, ntiles - 1));             // in flight while tile t is multiplied (past the end: a harmless re-fetch -- unconditional, so
+    const int nit = (ntiles + KS - 1) / KS;
+    for (int it = 0; it < nit; ++it) {
+        const int t = it * KS + ks;                // this key group's tile of the iteration (KS = 2, odd tile count: the last one may not exist)
+        issue(min(t + KS, ntiles - 1));            // in flight while tile t is multiplied (past the end: a harmless re-fetch -- unconditional, so
                                                    // that the staging registers are plain values, not merged paths)
         // tile t is committed by everybody; everybody has left tile t - 1 (the other buffer).  NOT __syncthreads(): its fence waits for
         // vmcnt(0) -- loads and stores share that counter on gfx9 -- i.e. for the tile just requested: every global round trip back on the
         // critical path (the first version of this kernel, and round 6's double-buffering of the kernel above, measured exactly that)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const uint16_t *Ks = Ks2 + (t & 1) * KT, *Vt = Vt2 + (t & 1) * VT;
+        const uint16_t *Ks = Ks2 + (it & 1) * KT, *Vt = Vt2 + (it & 1) * VT;
+        if (KS == 1 || t < ntiles) {               // wave-uniform
         // S^T = K Q^T : s[f][kf][r] <-> key 32 (kf >> 1) + 8 g + 4 (kf & 1) + r of the tile, query c16 of fragment f
         f32x4 s[QF][4];
 #pragma unroll
@@ -403,7 +411,39 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
 #pragma unroll
                 for (int f = 0; f < QF; ++f) o[f][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pf[f][kb], o[f][df], 0, 0, 0);
             }
-        commit((t + 1) & 1);                       // (its last readers passed this iteration's barrier after tile t - 1; after the last tile nobody reads it)
+        }
+        commit((it + 1) & 1);                      // (its last readers passed this iteration's barrier an iteration ago; after the last tile nobody reads it)
+    }
+    if constexpr (KS == 2) {
+        // the second key group hands its (max, lane-partial sum, O) over through LDS; the first merges and stores
+        constexpr int MW = QF * (2 + 4 * HD16);    // floats per lane
+        static_assert(NWQ * 64 * MW * 4 <= (2 * KT + 2 * VT) * 2, "the hand-over fits the first group's buffers");
+        __syncthreads();                           // everybody has left the tiles
+        float *mg = reinterpret_cast<float *>(smem_hd) + (size_t)(wave * 64 + lane) * MW;
+        if (ks == 1) {
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                mg[f * (2 + 4 * HD16)] = m_run[f]; mg[f * (2 + 4 * HD16) + 1] = l_run[f];
+#pragma unroll
+                for (int df = 0; df < HD16; ++df)
+                    *reinterpret_cast<float4 *>(mg + f * (2 + 4 * HD16) + 2 + 4 * df) = make_float4(o[f][df][0], o[f][df][1], o[f][df][2], o[f][df][3]);
+            }
+        }
+        __syncthreads();
+        if (ks == 1) return;
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            const float m1 = mg[f * (2 + 4 * HD16)], l1 = mg[f * (2 + 4 * HD16) + 1];
+            const float m = fmaxf(m_run[f], m1);
+            const float a0 = __builtin_amdgcn_exp2f(m_run[f] - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+            l_run[f] = l_run[f] * a0 + l1 * a1;
+#pragma unroll
+            for (int df = 0; df < HD16; ++df) {
+                const float4 o1 = *reinterpret_cast<const float4 *>(mg + f * (2 + 4 * HD16) + 2 + 4 * df);
+                o[f][df][0] = o[f][df][0] * a0 + o1.x * a1; o[f][df][1] = o[f][df][1] * a0 + o1.y * a1;
+                o[f][df][2] = o[f][df][2] * a0 + o1.z * a1; o[f][df][3] = o[f][df][3] * a0 + o1.w * a1;
+            }
+        }
     }
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
@@ -427,23 +467,25 @@ static int launch_hdv(const GaAttentionHdArgs &a, hipStream_t s)
 {
     constexpr size_t lds = (size_t)(2 * 64 * (HD16 * 16 + 8) + 2 * HD16 * 16 * 72) * 2;
     // configurations: 1 = 4 waves x 16 queries (64-query workgroups), 2 = 4 waves x 32 (128), 3 = 8 waves x 16 (128: two waves per SIMD
-    // hide each other's LDS / exponent latencies).  GA_ATTN_HD_QF forces one (A/B aid)
+    // hide each other's LDS / exponent latencies), 4 = two key groups of 4 waves x 16 (64).  GA_ATTN_HD_QF forces one (A/B aid)
     static const int qf_env = [] { const char *e = getenv("GA_ATTN_HD_QF"); return e ? atoi(e) : 0; }();
     const long long wg128 = (long long)a.batch * a.heads * ((a.Lq + 127) / 128);
-    // same-box (tools/attn_hd_bench.py, 16 heads of 72; us for configurations 1 | 2 | 3): a CFG pair's self-attention 23.4 | 25.2 | 21.4, one
-    // sample's cross-attention 27.9 | 40.3 | 33.6, one sample's self-attention 17.5 | 24.7 | 20.5 -- one wave per SIMD runs its phases back to back,
-    // two overlap; below a round of 128-query workgroups the 64-query ones win by filling more CUs
-    const int cfg = qf_env ? qf_env : (wg128 >= 160 ? 3 : 1);
-    const int qpw = cfg == 1 ? 64 : 128;
+    // same-box (tools/attn_hd_bench.py, 16 heads of 72; us for configurations 1 | 2 | 3 | 4): a CFG pair's self-attention 23.4 | 25.2 | 21.4 | 27.2,
+    // one sample's cross-attention 27.9 | 40.3 | 33.6 | 21.6, one sample's self-attention 17.5 | 24.7 | 20.5 | 14.6 -- one wave per SIMD runs its
+    // phases back to back, two overlap; below a round of 128-query workgroups the 64-query ones fill more CUs, and two key groups give each
+    // SIMD its second wave and halve the tiles a wave walks
+    const int cfg = qf_env ? qf_env : (wg128 >= 160 ? 3 : 4);
+    const int qpw = (cfg == 1 || cfg == 4) ? 64 : 128;
     const dim3 grid((unsigned)(a.batch * a.heads), (unsigned)((a.Lq + qpw - 1) / qpw));
-#define GA_HDV_LAUNCH(QFV, NWV)                                                                                                   \
+#define GA_HDV_LAUNCH(QFV, NWV, KSV)                                                                                              \
     do {                                                                                                                          \
-        if (lds > 65536 && hipFuncSetAttribute((const void *)attention_hdv_kernel<HD16, QFV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
-        hipLaunchKernelGGL((attention_hdv_kernel<HD16, QFV, NWV>), grid, dim3(64 * NWV), lds, s, a);                               \
+        if (KSV * lds > 65536 && hipFuncSetAttribute((const void *)attention_hdv_kernel<HD16, QFV, NWV, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KSV * lds)) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
+        hipLaunchKernelGGL((attention_hdv_kernel<HD16, QFV, NWV, KSV>), grid, dim3(64 * NWV), KSV * lds, s, a);                    \
     } while (0)
-    if (cfg == 2) GA_HDV_LAUNCH(2, 4);
-    else if (cfg == 3) GA_HDV_LAUNCH(1, 8);
-    else GA_HDV_LAUNCH(1, 4);
+    if (cfg == 2) GA_HDV_LAUNCH(2, 4, 1);
+    else if (cfg == 3) GA_HDV_LAUNCH(1, 8, 1);
+    else if (cfg == 4) GA_HDV_LAUNCH(1, 8, 2);
+    else GA_HDV_LAUNCH(1, 4, 1);
 #undef GA_HDV_LAUNCH
     return hipGetLastError() == hipSuccess ? GA_DIT_OK : GA_DIT_ERR_LAUNCH;
 }
