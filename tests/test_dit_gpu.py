@@ -713,6 +713,35 @@ def test_final_layer_statistics_on_rows_with_a_large_common_offset(gpu_device):
     assert rel_l2(y.cpu(), ref) < 1e-2, rel_l2(y.cpu(), ref)
 
 
+@pytest.mark.parametrize("width,heads", [(512, 4), (384, 12), (960, 8), (704, 8)])
+def test_models_with_other_head_dims_against_oracle(gpu_device, width, heads):
+    """Head dims other than 64 and 72 through ga_dit_forward's head-dim-generic branch against the fp32 oracle, depth 2: heads of 128 at a width
+    the four-slot GEMM ring serves (pre-norms folded, 8 partial sums per row), heads of 32 at width 384 (6 K-tiles: the three-slot ring, 6 -> 8
+    floats per row of partial sums), heads of 120 at width 960 (15 K-tiles: three slots again, 15 -> 16 floats) and heads of 88 at width 704
+    (11 K-tiles: neither ring -- the general 2-slot kernel -- and no fold: the pre-norms as launches of their own)."""
+    from gaussiananything_amd.dit import DiT_I23D_PCD_PixelArt_noclip
+    from oracle import dit as od
+    torch.manual_seed(0)
+    model = DiT_I23D_PCD_PixelArt_noclip(input_size=16, patch_size=1, in_channels=3, hidden_size=width, depth=2, num_heads=heads, num_classes=0,
+                                         learn_sigma=False, context_dim=1024, pooling_ctx_dim=768, roll_out=True, use_clay_ca=True)
+    g = torch.Generator().manual_seed(width)
+    with torch.no_grad():
+        for p in model.parameters():
+            if float(p.abs().max()) == 0.0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = torch.randn(2, 768, 3, generator=g)
+    t = torch.tensor([0.4, 0.4])
+    ctx = {"img_crossattn": torch.randn(2, 257, 1024, generator=g), "img_vector": torch.randn(2, 1024, generator=g)}
+    ctx["img_crossattn"][1] = 0
+    ctx["img_vector"][1] = 0
+    ref = od.dit_forward(sd, x, t, ctx)
+    model.to(gpu_device)
+    with torch.no_grad():
+        y = model(x.to(gpu_device), t.to(gpu_device), {k: v.to(gpu_device) for k, v in ctx.items()})
+    assert rel_l2(y.cpu(), ref) < 1.5e-2, rel_l2(y.cpu(), ref)
+
+
 def test_xl_geometry_against_oracle_folded_and_unfolded(gpu_device):
     """DiT-PixArt-PCD-CLAY-XL's geometry (/root/reference/dit/dit_i23d.py:1526-1535: width 1152, 16 heads of 72) at the release shapes, depth 3,
     against the fp32 oracle: the round-6 path -- three-slot GEMM rings (K = 1152 is no multiple of 256), 18 -> 20 partial sums per row behind
