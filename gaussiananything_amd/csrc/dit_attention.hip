@@ -138,16 +138,30 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
 
     // ---- staging, DMA form: piece p (0..15) of a tile is 8 rows (p < 8: K rows 8p .., else V^T rows 8(p-8) ..); wave wq
     // of the key group moves pieces wq*DPW .. +DPW-1; lane l -> row 8p + (l>>3), LDS slot l&7 <- global chunk slot ^ swz
+    // (round 6: the lane's byte offset inside a tile is computed ONCE -- 32 bits -- and a tile's address is a wave-uniform base plus that
+    //  offset: the per-tile 64-bit multiply-adds of the first form were ~30 % of the VALU slots of a step, and the steps are VALU-bound)
+    uint32_t dma_off[DPW];
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+        const int p = wq * DPW + i, r8 = (p & 7) * 8, row = r8 + (lane >> 3), chunk = (lane & 7) ^ swz_of(row);
+        dma_off[i] = (uint32_t)row * (uint32_t)((p < 8 ? a.k_stride : a.vt_ld) * 2) + (uint32_t)chunk * 16u;
+    }
     auto dma_tile = [&](int tile_raw, int slot) {
         const int tile = min(tile_raw, ntiles - 1);  // past the end: a harmless re-fetch (keeps the vmcnt arithmetic exact)
+        const char *kt = reinterpret_cast<const char *>(k_base) + (size_t)tile * KB * (size_t)a.k_stride * 2;     // wave-uniform
+        const char *vtt = reinterpret_cast<const char *>(vt_base) + (size_t)tile * KB * 2;
 #pragma unroll
         for (int i = 0; i < DPW; ++i) {
-            const int p = wq * DPW + i, r8 = (p & 7) * 8, row = r8 + (lane >> 3), chunk = (lane & 7) ^ swz_of(row);
+            const int p = wq * DPW + i, r8 = (p & 7) * 8;
             if (p < 8) {
-                const int key = min(tile * KB + row, Lk - 1);
-                glds16(k_base + (size_t)key * a.k_stride + chunk * 8, sK + slot * TILE + r8 * 64);
+                uint32_t off = dma_off[i];
+                if (tile >= nfull) {      // wave-uniform: the ragged last tile re-reads the last key for the rows behind it (masked below)
+                    const int row = r8 + (lane >> 3), chunk = (lane & 7) ^ swz_of(row);
+                    off = (uint32_t)(min(tile * KB + row, Lk - 1) - tile * KB) * (uint32_t)(a.k_stride * 2) + (uint32_t)chunk * 16u;
+                }
+                glds16(reinterpret_cast<const uint16_t *>(kt + off), sK + slot * TILE + r8 * 64);
             } else {
-                glds16(vt_base + (size_t)row * a.vt_ld + tile * KB + chunk * 8, sV + slot * TILE + r8 * 64);
+                glds16(reinterpret_cast<const uint16_t *>(vtt + dma_off[i]), sV + slot * TILE + r8 * 64);
             }
         }
     };
@@ -202,21 +216,35 @@ __global__ __launch_bounds__(NW * KS * 64) void attention_fwd_kernel(GaAttention
 #pragma unroll
             for (int i = 0; i < 4; ++i) { qnw[4 * i] = w4[i].x; qnw[4 * i + 1] = w4[i].y; qnw[4 * i + 2] = w4[i].z; qnw[4 * i + 3] = w4[i].w; }
         }
+        // (round 6: as in the key walk, a lane's byte offsets once, a slice's address = wave-uniform base + offset)
+        uint32_t qw_off[2], qa_off[2];
+        const char *qw_base[2];
+        const char *qa_base = reinterpret_cast<const char *>(a.qp_a + (size_t)b * Lq * a.qp_lda);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = wq * 2 + i, r8 = p * 8, row = r8 + (lane >> 3), chunk = (lane & 7) ^ swz_of(row);
+            if (a.qp_w_tiled) {    // kernel-uniform
+                qw_base[i] = reinterpret_cast<const char *>(a.qp_w + (size_t)(h * 8 + p) * nsl * 512);
+                qw_off[i] = (uint32_t)((lane >> 3) * 64 + chunk * 8) * 2u;
+            } else {
+                qw_base[i] = reinterpret_cast<const char *>(a.qp_w + (size_t)h * 64 * a.qp_k);
+                qw_off[i] = ((uint32_t)row * (uint32_t)a.qp_k + (uint32_t)chunk * 8u) * 2u;
+            }
+            qa_off[i] = ((uint32_t)min(qbase + row, Lq - 1) * (uint32_t)a.qp_lda + (uint32_t)chunk * 8u) * 2u;
+        }
+        const uint32_t qw_step = a.qp_w_tiled ? 1024u : 128u;     // bytes from one 64-wide K-slice of W to the next
         auto dma_q = [&](int grp, int slot) {
             if (grp >= steps_q) { dma_stage((grp - steps_q) * KS + ks, slot); return; }   // the key walk's stages 0, 1 (workgroup-uniform)
             const int sl = min(grp * KS + ks, nsl - 1);   // past the end: a harmless re-fetch (keeps the vmcnt arithmetic exact)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int p = wq * 2 + i, r8 = p * 8, row = r8 + (lane >> 3), chunk = (lane & 7) ^ swz_of(row);
-                const uint16_t *src = a.qp_w_tiled ? a.qp_w + ((size_t)(h * 8 + p) * nsl + sl) * 512 + (lane >> 3) * 64 + chunk * 8
-                                                   : a.qp_w + (size_t)(h * 64 + row) * a.qp_k + sl * 64 + chunk * 8;
-                glds16(src, sK + slot * TILE + r8 * 64);
+                const int r8 = (wq * 2 + i) * 8;
+                glds16(reinterpret_cast<const uint16_t *>(qw_base[i] + (size_t)sl * qw_step + qw_off[i]), sK + slot * TILE + r8 * 64);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int p = wq * 2 + i, r8 = p * 8, row = r8 + (lane >> 3), chunk = (lane & 7) ^ swz_of(row);
-                const int qrow = min(qbase + row, Lq - 1);
-                glds16(a.qp_a + ((size_t)b * Lq + qrow) * a.qp_lda + sl * 64 + chunk * 8, sV + slot * TILE + r8 * 64);
+                const int r8 = (wq * 2 + i) * 8;
+                glds16(reinterpret_cast<const uint16_t *>(qa_base + (size_t)sl * 128 + qa_off[i]), sV + slot * TILE + r8 * 64);
             }
         };
         f32x4 acc[4];
