@@ -635,6 +635,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmP p)
 
     // DMA sources: instruction i of this wave fills rows q*8 .. q*8+7 of the slot image [W rows | A rows], q = i*NW + wave;
     // slot (row, s) of the 128-byte row receives global chunk s ^ (row & 7)
+    // (round 6: the SADDR form the attention's key walk gained 1 - 2 % from -- wave-uniform base + a 32-bit lane offset computed once -- was
+    //  built here too, bases through readfirstlane and the zero-extension pinned next to its use or LLVM folds it back into one 64-bit pointer
+    //  per lane: all DMA issues in SADDR form, DiT-L 2.776 vs 2.778 ms per evaluation same-box: nothing.  One v_lshl_add_u64 per DMA
+    //  instruction was all there was to save, and these loops are not issue-bound.  Not kept.)
     const uint16_t *src[DPT];
     static_assert(BNT % (8 * NW) == 0, "instruction i of every wave is on the same side of the W | A boundary");
     const int arows = (EPI == GA_GEMM_EPI_RESIDUAL && p.k_rows) ? p.k_rows : M;   // rows of A that exist / take part
