@@ -159,6 +159,13 @@ __global__ __launch_bounds__(256) void attention_hd_kernel(GaAttentionHdArgs a)
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_hd __attribute__((ext_vector_type(4)));
 
+// tail workgroups (dit_common.h: PrefetchJob -- weights of GEMMs a few launches ahead pulled towards the Infinity Cache by the CUs the
+// attention grid leaves idle, as on the 64-wide path)
+struct HdTail {
+    PrefetchJob pf;
+    int y0, nwgs;
+};
+
 template <int B_, int E_, class F>
 __device__ __forceinline__ void static_for_hd(F &&f)
 {
@@ -171,9 +178,14 @@ __device__ __forceinline__ void static_for_hd(F &&f)
 // KS = 2: two key groups of NW / 2 query waves each -- group ks takes the tiles ks, ks + 2, ... through buffers of its own, the groups' (max, sum,
 // O) meet in LDS at the end: where even 64-query workgroups leave the SIMDs one wave each (one sample's attention: 192 workgroups)
 template <int HD16, int QF, int NW = 4, int KS = 1>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2))) void attention_hdv_kernel(GaAttentionHdArgs a)
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2))) void attention_hdv_kernel(GaAttentionHdArgs a, HdTail tail)
 {
     constexpr int NTW = 64 * NW;            // threads of the workgroup
+    if (tail.nwgs > 0 && (int)blockIdx.y >= tail.y0) {      // workgroups behind the attention grid (dispatched last: they land on the CUs it leaves idle)
+        const int idx = ((int)blockIdx.y - tail.y0) * (int)gridDim.x + (int)blockIdx.x;
+        if (idx < tail.nwgs) prefetch_block(tail.pf, idx, tail.nwgs);
+        return;
+    }
     constexpr int NWQ = NW / KS, NT = NTW / KS;     // query waves (QF x 16 queries each) and threads of one key group
     constexpr int KB = 64, HDP = HD16 * 16, KROW = HDP + 8, VROW = KB + 8, NK32 = HD16 / 2;
     constexpr bool K16 = (HD16 & 1) != 0;
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
 }
 
 template <int HD16>
-static int launch_hdv(const GaAttentionHdArgs &a, hipStream_t s)
+static int launch_hdv(const GaAttentionHdArgs &a, hipStream_t s, const PrefetchJob *pf, int pf_wgs)
 {
     constexpr size_t lds = (size_t)(2 * 64 * (HD16 * 16 + 8) + 2 * HD16 * 16 * 72) * 2;
     // configurations: 1 = 4 waves x 16 queries (64-query workgroups), 2 = 4 waves x 32 (128), 3 = 8 waves x 16 (128: two waves per SIMD
@@ -476,11 +488,16 @@ static int launch_hdv(const GaAttentionHdArgs &a, hipStream_t s)
     // SIMD its second wave and halve the tiles a wave walks
     const int cfg = qf_env ? qf_env : (wg128 >= 160 ? 3 : 4);
     const int qpw = (cfg == 1 || cfg == 4) ? 64 : 128;
-    const dim3 grid((unsigned)(a.batch * a.heads), (unsigned)((a.Lq + qpw - 1) / qpw));
+    dim3 grid((unsigned)(a.batch * a.heads), (unsigned)((a.Lq + qpw - 1) / qpw));
+    HdTail tail{};
+    if (pf && pf_wgs > 0) {
+        tail.pf = *pf; tail.y0 = (int)grid.y; tail.nwgs = pf_wgs;
+        grid.y += (unsigned)((pf_wgs + (int)grid.x - 1) / (int)grid.x);
+    }
 #define GA_HDV_LAUNCH(QFV, NWV, KSV)                                                                                              \
     do {                                                                                                                          \
         if (KSV * lds > 65536 && hipFuncSetAttribute((const void *)attention_hdv_kernel<HD16, QFV, NWV, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KSV * lds)) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
-        hipLaunchKernelGGL((attention_hdv_kernel<HD16, QFV, NWV, KSV>), grid, dim3(64 * NWV), KSV * lds, s, a);                    \
+        hipLaunchKernelGGL((attention_hdv_kernel<HD16, QFV, NWV, KSV>), grid, dim3(64 * NWV), KSV * lds, s, a, tail);              \
     } while (0)
     if (cfg == 2) GA_HDV_LAUNCH(2, 4, 1);
     else if (cfg == 3) GA_HDV_LAUNCH(1, 8, 1);
@@ -509,7 +526,20 @@ __global__ __launch_bounds__(256) void head_rmsnorm_kernel(uint16_t *__restrict_
 
 }  // namespace gadit
 
-extern "C" int ga_attention_hd_bf16(const GaAttentionHdArgs *a, void *stream)
+namespace gadit {
+static int attention_hd_dispatch(const GaAttentionHdArgs *a, void *stream, const PrefetchJob *pf, int pf_wgs);
+// the V^T variant with tail workgroups (ga_dit_forward); how many of them the launch leaves room for on `ncu` compute units
+int attention_hd_with_tail(const GaAttentionHdArgs *a, void *stream, const PrefetchJob *pf, int pf_wgs) { return attention_hd_dispatch(a, stream, pf, pf_wgs); }
+int attention_hd_workgroups(const GaAttentionHdArgs *a)
+{
+    const long long wg128 = (long long)a->batch * a->heads * ((a->Lq + 127) / 128);
+    return (int)(wg128 >= 160 ? wg128 : (long long)a->batch * a->heads * ((a->Lq + 63) / 64));
+}
+}  // namespace gadit
+
+extern "C" int ga_attention_hd_bf16(const GaAttentionHdArgs *a, void *stream) { return gadit::attention_hd_dispatch(a, stream, nullptr, 0); }
+
+static int gadit::attention_hd_dispatch(const GaAttentionHdArgs *a, void *stream, const PrefetchJob *pf, int pf_wgs)
 {
     using namespace gadit;
     if (!a || !a->q || !a->k || (!a->v && !a->vt) || !a->out) return GA_DIT_ERR_NULL_ARG;
@@ -523,14 +553,14 @@ extern "C" int ga_attention_hd_bf16(const GaAttentionHdArgs *a, void *stream)
             return GA_DIT_ERR_BAD_SHAPE;
         hipStream_t sv = reinterpret_cast<hipStream_t>(stream);
         switch ((a->head_dim + 15) / 16) {
-        case 1: return launch_hdv<1>(*a, sv);
-        case 2: return launch_hdv<2>(*a, sv);
-        case 3: return launch_hdv<3>(*a, sv);
-        case 4: return launch_hdv<4>(*a, sv);
-        case 5: return launch_hdv<5>(*a, sv);
-        case 6: return launch_hdv<6>(*a, sv);
-        case 7: return launch_hdv<7>(*a, sv);
-        default: return launch_hdv<8>(*a, sv);
+        case 1: return launch_hdv<1>(*a, sv, pf, pf_wgs);
+        case 2: return launch_hdv<2>(*a, sv, pf, pf_wgs);
+        case 3: return launch_hdv<3>(*a, sv, pf, pf_wgs);
+        case 4: return launch_hdv<4>(*a, sv, pf, pf_wgs);
+        case 5: return launch_hdv<5>(*a, sv, pf, pf_wgs);
+        case 6: return launch_hdv<6>(*a, sv, pf, pf_wgs);
+        case 7: return launch_hdv<7>(*a, sv, pf, pf_wgs);
+        default: return launch_hdv<8>(*a, sv, pf, pf_wgs);
         }
     }
     if (a->q_norm_weight || a->k_norm_weight) return GA_DIT_ERR_BAD_SHAPE;     // (the norms inside the kernel belong to the V^T variant)

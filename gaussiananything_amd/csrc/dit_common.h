@@ -167,5 +167,8 @@ __device__ __forceinline__ void prefetch_block(const PrefetchJob &j, int wg, int
 int attention_with_tail(const GaAttentionArgs *a, const ShiftBiasJob *job, void *stream, const PrefetchJob *pf = nullptr, int pf_wgs = 0);
 int attention_workgroups(const GaAttentionArgs *a);
 bool attention_fuses_q(const GaAttentionArgs *a);
+// dit_attention_hd.hip: the V^T variant for head dims other than 64 with prefetch tail workgroups behind its grid
+int attention_hd_with_tail(const GaAttentionHdArgs *a, void *stream, const PrefetchJob *pf, int pf_wgs);
+int attention_hd_workgroups(const GaAttentionHdArgs *a);
 
 }  // namespace gadit

@@ -821,7 +821,25 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
             // (V^T of the image tokens from the cache like the 64-wide path, q's norm inside the attention kernel)
             GaAttentionHdArgs ca{ca_batch, m->heads, L, a->ctx_tokens, hd, w.qkv, a->ca_k + (size_t)i * kv_rows * D, nullptr, D, D, 0, w.att, D,
                                  a->ca_vt + (size_t)i * B * D * Mp, Mp, bw.ca_q_norm_w, nullptr};
-            GA_TRY(ga_attention_hd_bf16(&ca, stream));
+            // the weight prefetch of the 64-wide path (GA_DIT_PREFETCH) behind this grid as well: this block's fc2 and self-attention output
+            // weights, the next block's cross-attention q / output weights, by the CUs the grid leaves idle
+            PrefetchJob pfx{};
+            int pfx_wgs = 0;
+            if (pf_mode > 0) {
+                const unsigned DD = (unsigned)D * (unsigned)D;
+                pfx.ptr[0] = reinterpret_cast<const char *>(bw.fc2_w); pfx.bytes[0] = (8u * DD) / 1024u * 1024u;
+                if (pf_mode >= 3) { pfx.ptr[1] = reinterpret_cast<const char *>(bw.proj_w); pfx.bytes[1] = (2u * DD) / 1024u * 1024u; }
+                if (pf_mode >= 4) {
+                    const int ni = i + 1 < m->depth ? i + 1 : 0;
+                    const GaDitBlockWeights &nb = m->blocks[ni];
+                    pfx.ptr[2] = reinterpret_cast<const char *>(nb.ca_out_w); pfx.bytes[2] = (2u * DD) / 1024u * 1024u;
+                    const uint16_t *qw = (fold_mod && ni > 0 && can_fold(m, ni) && nb.ca_q_w_prenorm) ? nb.ca_q_w_prenorm : nb.ca_q_w;
+                    pfx.ptr[3] = reinterpret_cast<const char *>(qw); pfx.bytes[3] = (2u * DD) / 1024u * 1024u;
+                }
+                pfx_wgs = std::min(64, std::max(0, ncu - attention_hd_workgroups(&ca)));
+                if (pfx_wgs < 16) pfx_wgs = 0;
+            }
+            GA_TRY(attention_hd_with_tail(&ca, stream, pfx_wgs ? &pfx : nullptr, pfx_wgs));
             GaGemmArgs go{};
             go.M = Mca; go.N = D; go.K = D; go.epilogue = GA_GEMM_EPI_RESIDUAL; go.A = w.att; go.lda = D; go.W = bw.ca_out_w; go.w_tiled = m->gemm_weights_tiled;
             go.bias = bw.ca_out_b; go.out = w.xres; go.ldo = D; go.gate = nullptr; go.rows_per_batch = L;
