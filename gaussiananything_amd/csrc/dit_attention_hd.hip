@@ -164,6 +164,8 @@ typedef unsigned u32x4_hd __attribute__((ext_vector_type(4)));
 struct HdTail {
     PrefetchJob pf;
     int y0, nwgs;
+    ShiftBiasJob job;     // sb_wgs > 0: the first sb_wgs tail workgroups compute it (the shift rows of the NEXT block's folded pre-norms)
+    int sb_wgs;
 };
 
 template <int B_, int E_, class F>
@@ -181,9 +183,11 @@ template <int HD16, int QF, int NW = 4, int KS = 1>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2))) void attention_hdv_kernel(GaAttentionHdArgs a, HdTail tail)
 {
     constexpr int NTW = 64 * NW;            // threads of the workgroup
-    if (tail.nwgs > 0 && (int)blockIdx.y >= tail.y0) {      // workgroups behind the attention grid (dispatched last: they land on the CUs it leaves idle)
+    if (tail.nwgs + tail.sb_wgs > 0 && (int)blockIdx.y >= tail.y0) {      // workgroups behind the attention grid (dispatched last: they land on the CUs it leaves idle)
+        extern __shared__ __attribute__((aligned(16))) uint16_t smem_tail[];
         const int idx = ((int)blockIdx.y - tail.y0) * (int)gridDim.x + (int)blockIdx.x;
-        if (idx < tail.nwgs) prefetch_block(tail.pf, idx, tail.nwgs);
+        if (idx < tail.sb_wgs) shift_bias_block<1>(tail.job, idx, reinterpret_cast<float *>(smem_tail));
+        else if (idx - tail.sb_wgs < tail.nwgs) prefetch_block(tail.pf, idx - tail.sb_wgs, tail.nwgs);
         return;
     }
     constexpr int NWQ = NW / KS, NT = NTW / KS;     // query waves (QF x 16 queries each) and threads of one key group
@@ -475,8 +479,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
 }
 
 template <int HD16>
-static int launch_hdv(const GaAttentionHdArgs &a, hipStream_t s, const PrefetchJob *pf, int pf_wgs)
+static int launch_hdv(const GaAttentionHdArgs &a, hipStream_t s, const PrefetchJob *pf, int pf_wgs, const ShiftBiasJob *job)
 {
+    static_assert((size_t)(2 * 64 * (HD16 * 16 + 8) + 2 * HD16 * 16 * 72) * 2 >= kSbLdsFloats * sizeof(float) || HD16 < 2, "the tail's partial sums fit the tile buffers");
     constexpr size_t lds = (size_t)(2 * 64 * (HD16 * 16 + 8) + 2 * HD16 * 16 * 72) * 2;
     // configurations: 1 = 4 waves x 16 queries (64-query workgroups), 2 = 4 waves x 32 (128), 3 = 8 waves x 16 (128: two waves per SIMD
     // hide each other's LDS / exponent latencies), 4 = two key groups of 4 waves x 16 (64).  GA_ATTN_HD_QF forces one (A/B aid)
@@ -490,10 +495,15 @@ static int launch_hdv(const GaAttentionHdArgs &a, hipStream_t s, const PrefetchJ
     const int qpw = (cfg == 1 || cfg == 4) ? 64 : 128;
     dim3 grid((unsigned)(a.batch * a.heads), (unsigned)((a.Lq + qpw - 1) / qpw));
     HdTail tail{};
-    if (pf && pf_wgs > 0) {
-        tail.pf = *pf; tail.y0 = (int)grid.y; tail.nwgs = pf_wgs;
-        grid.y += (unsigned)((pf_wgs + (int)grid.x - 1) / (int)grid.x);
+    tail.y0 = (int)grid.y;
+    if (pf && pf_wgs > 0) { tail.pf = *pf; tail.nwgs = pf_wgs; }
+    if (job) {
+        // the job's waves each own K / 64 / waves K-tiles, at most kSbTilesPerWave (dit_common.h); its partial sums live in the tile buffers
+        const int waves = cfg == 3 || cfg == 4 ? 8 : 4;
+        if (job->K / 64 > kSbTilesPerWave * waves || lds < kSbLdsFloats * sizeof(float)) return GA_DIT_ERR_BAD_SHAPE;
+        tail.job = *job; tail.sb_wgs = shift_bias_wgs(job->N0, job->N1);
     }
+    if (tail.nwgs + tail.sb_wgs > 0) grid.y += (unsigned)((tail.nwgs + tail.sb_wgs + (int)grid.x - 1) / (int)grid.x);
 #define GA_HDV_LAUNCH(QFV, NWV, KSV)                                                                                              \
     do {                                                                                                                          \
         if (KSV * lds > 65536 && hipFuncSetAttribute((const void *)attention_hdv_kernel<HD16, QFV, NWV, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KSV * lds)) != hipSuccess) return GA_DIT_ERR_LAUNCH; \
@@ -527,9 +537,20 @@ __global__ __launch_bounds__(256) void head_rmsnorm_kernel(uint16_t *__restrict_
 }  // namespace gadit
 
 namespace gadit {
-static int attention_hd_dispatch(const GaAttentionHdArgs *a, void *stream, const PrefetchJob *pf, int pf_wgs);
-// the V^T variant with tail workgroups (ga_dit_forward); how many of them the launch leaves room for on `ncu` compute units
-int attention_hd_with_tail(const GaAttentionHdArgs *a, void *stream, const PrefetchJob *pf, int pf_wgs) { return attention_hd_dispatch(a, stream, pf, pf_wgs); }
+static int attention_hd_dispatch(const GaAttentionHdArgs *a, void *stream, const PrefetchJob *pf, int pf_wgs, const ShiftBiasJob *job);
+// the V^T variant with tail workgroups (ga_dit_forward); attention_hd_workgroups: the grid without them
+int attention_hd_with_tail(const GaAttentionHdArgs *a, void *stream, const PrefetchJob *pf, int pf_wgs, const ShiftBiasJob *job)
+{
+    return attention_hd_dispatch(a, stream, pf, pf_wgs, job);
+}
+// can a tail of this launch host a ShiftBiasJob over K columns?  (eight-wave configurations only: the launcher's own choice unless forced)
+bool attention_hd_hosts_shift_bias(const GaAttentionHdArgs *a, int K)
+{
+    static const int qf_env = [] { const char *e = getenv("GA_ATTN_HD_QF"); return e ? atoi(e) : 0; }();
+    const int waves = (qf_env == 1 || qf_env == 2) ? 4 : 8;
+    const size_t lds = (size_t)(2 * 64 * ((a->head_dim + 15) / 16 * 16 + 8) + 2 * ((a->head_dim + 15) / 16 * 16) * 72) * 2;
+    return K / 64 <= kSbTilesPerWave * waves && lds >= kSbLdsFloats * sizeof(float);
+}
 int attention_hd_workgroups(const GaAttentionHdArgs *a)
 {
     const long long wg128 = (long long)a->batch * a->heads * ((a->Lq + 127) / 128);
@@ -537,9 +558,9 @@ int attention_hd_workgroups(const GaAttentionHdArgs *a)
 }
 }  // namespace gadit
 
-extern "C" int ga_attention_hd_bf16(const GaAttentionHdArgs *a, void *stream) { return gadit::attention_hd_dispatch(a, stream, nullptr, 0); }
+extern "C" int ga_attention_hd_bf16(const GaAttentionHdArgs *a, void *stream) { return gadit::attention_hd_dispatch(a, stream, nullptr, 0, nullptr); }
 
-static int gadit::attention_hd_dispatch(const GaAttentionHdArgs *a, void *stream, const PrefetchJob *pf, int pf_wgs)
+static int gadit::attention_hd_dispatch(const GaAttentionHdArgs *a, void *stream, const PrefetchJob *pf, int pf_wgs, const ShiftBiasJob *job)
 {
     using namespace gadit;
     if (!a || !a->q || !a->k || (!a->v && !a->vt) || !a->out) return GA_DIT_ERR_NULL_ARG;
@@ -553,14 +574,14 @@ static int gadit::attention_hd_dispatch(const GaAttentionHdArgs *a, void *stream
             return GA_DIT_ERR_BAD_SHAPE;
         hipStream_t sv = reinterpret_cast<hipStream_t>(stream);
         switch ((a->head_dim + 15) / 16) {
-        case 1: return launch_hdv<1>(*a, sv, pf, pf_wgs);
-        case 2: return launch_hdv<2>(*a, sv, pf, pf_wgs);
-        case 3: return launch_hdv<3>(*a, sv, pf, pf_wgs);
-        case 4: return launch_hdv<4>(*a, sv, pf, pf_wgs);
-        case 5: return launch_hdv<5>(*a, sv, pf, pf_wgs);
-        case 6: return launch_hdv<6>(*a, sv, pf, pf_wgs);
-        case 7: return launch_hdv<7>(*a, sv, pf, pf_wgs);
-        default: return launch_hdv<8>(*a, sv, pf, pf_wgs);
+        case 1: return launch_hdv<1>(*a, sv, pf, pf_wgs, job);
+        case 2: return launch_hdv<2>(*a, sv, pf, pf_wgs, job);
+        case 3: return launch_hdv<3>(*a, sv, pf, pf_wgs, job);
+        case 4: return launch_hdv<4>(*a, sv, pf, pf_wgs, job);
+        case 5: return launch_hdv<5>(*a, sv, pf, pf_wgs, job);
+        case 6: return launch_hdv<6>(*a, sv, pf, pf_wgs, job);
+        case 7: return launch_hdv<7>(*a, sv, pf, pf_wgs, job);
+        default: return launch_hdv<8>(*a, sv, pf, pf_wgs, job);
         }
     }
     if (a->q_norm_weight || a->k_norm_weight) return GA_DIT_ERR_BAD_SHAPE;     // (the norms inside the kernel belong to the V^T variant)

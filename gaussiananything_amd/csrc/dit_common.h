@@ -168,7 +168,8 @@ int attention_with_tail(const GaAttentionArgs *a, const ShiftBiasJob *job, void 
 int attention_workgroups(const GaAttentionArgs *a);
 bool attention_fuses_q(const GaAttentionArgs *a);
 // dit_attention_hd.hip: the V^T variant for head dims other than 64 with prefetch tail workgroups behind its grid
-int attention_hd_with_tail(const GaAttentionHdArgs *a, void *stream, const PrefetchJob *pf, int pf_wgs);
+int attention_hd_with_tail(const GaAttentionHdArgs *a, void *stream, const PrefetchJob *pf, int pf_wgs, const ShiftBiasJob *job = nullptr);
 int attention_hd_workgroups(const GaAttentionHdArgs *a);
+bool attention_hd_hosts_shift_bias(const GaAttentionHdArgs *a, int K);
 
 }  // namespace gadit

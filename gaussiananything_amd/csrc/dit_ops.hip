@@ -738,7 +738,13 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
     static const int ncu = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();
     bool sb_tail = false, sb_tail0 = false;
     const int ca_batch = (a->ca_batch <= 0 || a->ca_batch > B) ? B : a->ca_batch;
-    if (fold_mod && sb_tail_env && hd == 64) {      // (other head dims: all blocks' shift rows in the one launch up front)
+    if (fold_mod && sb_tail_env && hd != 64) {
+        // other head dims (round 6): block i + 1's rows behind the SELF-attention grid of block i where that grid leaves the CUs free and its
+        // workgroups have the waves for the job (block 0's: the launch up front); none behind the cross-attention grid, which carries the prefetch
+        const GaAttentionHdArgs probe{B, m->heads, L, L, hd, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, nullptr, nullptr};
+        sb_tail = attention_hd_workgroups(&probe) + shift_bias_wgs(3 * D, 4 * D) <= ncu && attention_hd_hosts_shift_bias(&probe, D);
+    }
+    if (fold_mod && sb_tail_env && hd == 64) {
         const GaAttentionArgs probe{B, m->heads, L, L, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, 0};
         sb_tail = attention_workgroups(&probe) + shift_bias_wgs(3 * D, 4 * D) <= ncu;
         // round 5: block 0's rows ride the same way behind block 0's CROSS-attention grid (its qkv projection is the first consumer):
@@ -865,7 +871,13 @@ extern "C" int ga_dit_forward(const GaDitModel *m, const GaDitForwardArgs *a, vo
             static const bool knorm_in = [] { const char *e = getenv("GA_DIT_HD_KNORM"); return !e || atoi(e) != 0; }();
             if (!knorm_in) GA_TRY(ga_head_rmsnorm_bf16(w.qkv + D, Mrows, 2 * D, m->heads, hd, bw.k_norm_w, stream));
             GaAttentionHdArgs sa{B, m->heads, L, L, hd, w.qkv, w.qkv + D, nullptr, 2 * D, 2 * D, 0, w.att, D, w.vt, Lp, bw.q_norm_w, knorm_in ? bw.k_norm_w : nullptr};
-            GA_TRY(ga_attention_hd_bf16(&sa, stream));
+            if (fold_mod && sb_tail && i + 1 < m->depth) {
+                const GaDitBlockWeights &nb = m->blocks[i + 1];
+                ShiftBiasJob job{{nb.qkv_w, nb.fc1_w}, {nb.qkv_b, nb.fc1_b}, w.mod + (size_t)(i + 1) * B * 6 * D, w.sbias + (size_t)(i + 1) * B * 7 * D,
+                                 6 * (long long)D, 3 * (long long)D, 3 * D, 4 * D, D, B, m->gemm_weights_tiled};
+                GA_TRY(attention_hd_with_tail(&sa, stream, nullptr, 0, &job));
+            } else
+                GA_TRY(ga_attention_hd_bf16(&sa, stream));
             GaGemmArgs gp{};
             gp.M = Mrows; gp.N = D; gp.K = D; gp.epilogue = GA_GEMM_EPI_RESIDUAL; gp.A = w.att; gp.lda = D; gp.W = bw.proj_w; gp.w_tiled = m->gemm_weights_tiled;
             gp.bias = bw.proj_b; gp.out = w.xres; gp.ldo = D; gp.gate = mod + 2 * D; gp.gate_stride = 6 * (int64_t)D; gp.rows_per_batch = L;

@@ -1112,12 +1112,13 @@ def test_fused_euler_step_without_guidance_equals_eager_loop(gpu_device, stage, 
     assert torch.equal(outs["0"], outs["1"]) and sampler.last_ode.last_stats.get("fused")
 
 
-def test_weight_prefetch_and_tail_placement_are_bit_neutral(gpu_device):
+@pytest.mark.parametrize("width,heads", [(768, 12), (1152, 16)])
+def test_weight_prefetch_and_tail_placement_are_bit_neutral(gpu_device, width, heads):
     """Round 6: the weight prefetch by the idle workgroups of the cross-attention launch (GA_DIT_PREFETCH), the placement of the shift
     rows behind each block's own cross-attention grid (GA_DIT_SB_ON_CA), the tile -> XCD blocking (GA_GEMM_XMAP) and the write-through
     output stores (GA_GEMM_WT) change where and when bytes move, never a result: a DiT-B-shaped model (12 tile columns: the blocking
     applies) evaluated in fresh processes with everything off and everything on gives the same bits.  (The switches are read once per
-    process, hence the subprocesses.)"""
+    process, hence the subprocesses.)  Width 1152 / heads of 72: the same for the prefetch tail of the head-dim-generic cross-attention launch."""
     import subprocess
     import sys
     code = """
@@ -1125,7 +1126,7 @@ import hashlib, sys, torch
 sys.path.insert(0, %r)
 from gaussiananything_amd.dit import DiT_I23D_PCD_PixelArt_noclip
 torch.manual_seed(0)
-m = DiT_I23D_PCD_PixelArt_noclip(input_size=16, patch_size=1, in_channels=3, hidden_size=768, depth=3, num_heads=12, num_classes=0, learn_sigma=False,
+m = DiT_I23D_PCD_PixelArt_noclip(input_size=16, patch_size=1, in_channels=3, hidden_size=%d, depth=3, num_heads=%d, num_classes=0, learn_sigma=False,
                                  context_dim=1024, pooling_ctx_dim=768, roll_out=True, use_clay_ca=True)
 g = torch.Generator().manual_seed(1)
 with torch.no_grad():
@@ -1140,8 +1141,10 @@ with torch.no_grad():
     y = m.forward_with_cfg(x.cuda(), t.cuda(), {k: v.cuda() for k, v in ctx.items()}, 4.0)
     y1 = m.forward(x[:1].cuda(), t[:1].cuda(), {k: v[:1].cuda() for k, v in ctx.items()})
 print(hashlib.sha256(y.cpu().numpy().tobytes() + y1.cpu().numpy().tobytes()).hexdigest())
-""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), width, heads)
     hashes = []
+    # (where the shift rows are computed does change their summation order when a workgroup has fewer waves than the weights have K-tiles -- 18 at
+    #  width 1152, 8 waves behind the self-attention grid, 16 in the launch of their own: GA_DIT_SBTAIL is not toggled here)
     for env in ({"GA_DIT_PREFETCH": "0", "GA_DIT_SB_ON_CA": "0", "GA_GEMM_XMAP": "0", "GA_GEMM_WT": "0"},
                 {"GA_DIT_PREFETCH": "4", "GA_DIT_SB_ON_CA": "1", "GA_GEMM_XMAP": "1", "GA_GEMM_WT": "1"}, {}):
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
