@@ -294,7 +294,8 @@ typedef struct GaDitForwardArgs {
     const float *img_vector;  /* [B', ctx]                                                             */
     const float *fps_xyz;     /* [B', L, 3] (stage 2) or NULL                                          */
     const ga_bf16 *ca_k;      /* [depth][B'*M, D]        cached K projections of the image tokens (ga_dit_cache_context) */
-    const ga_bf16 *ca_vt;     /* [depth][B'*heads*64, Mp] cached V projections, transposed, Mp = M rounded up to 64, zero pad */
+    const ga_bf16 *ca_vt;     /* [depth][B'*D, Mp] cached V projections, transposed (row b*D + h*head_dim + d), Mp = M rounded up to 64,
+                                 zero pad -- the same two images for every head dim since round 6                                     */
     float *out;               /* [B', L, Cout] fp32 (the reference returns x.float())                  */
     void *workspace;          /* ga_dit_workspace_bytes()                                              */
     size_t workspace_bytes;
