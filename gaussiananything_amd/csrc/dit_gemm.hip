@@ -1080,6 +1080,7 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
         static const int ring4_env = [] { const char *e = getenv("GA_GEMM_RING4"); return e ? atoi(e) : 1; }();
         // (a 48 x 64 two-wave tile that would give the N = 1024 residual GEMMs at 768 rows 256 workgroups instead of 192 measured 3 % slower per evaluation: not kept)
         const long long wg_96x128 = (long long)((a->N + 127) / 128) * ((a->M + 95) / 96);
+        static const int ragged3_env = [] { const char *e = getenv("GA_GEMM_RAGGED3"); return e ? atoi(e) : 1; }();
         // round 6: K that is no multiple of 256 but one of 192 (DiT-PixArt-PCD-CLAY-XL: 1152, 4608) runs the same tiles on a ring of THREE slots
         // ... and, better (the same shapes ran 1.5 x longer on three slots: two tiles in flight per DMA latency instead of three): the FOUR-slot
         // ring with two remainder tiles in its peeled tail where K is 2 tiles past a multiple of 4 (1152 = 18 tiles); three slots for what is left
@@ -1107,6 +1108,11 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
             //  DiT-L's qkv at M = 768 13.4 -> 12.1 us; DiT-B's at M = 1536, 576 workgroups, is faster on 64 x 64, same-box A/B)
             // (round 6: a 64 x 128 four-wave tile for the residual GEMMs whose 96 x 64 grid is a little over one round -- width 1152 at 1536 rows:
             //  288 workgroups against 216 -- measured no better: fc2 37.6 us against 37.1, the K = 1152 projections 20.4 against 17.2: not kept)
+            // round 6: a 96 x 64 grid of a little over one round (width 1152 at 1536 rows: 288 workgroups, two to a CU on 32 of them) goes to 64 x 64
+            // tiles instead -- 432 workgroups, two to a CU everywhere: the busiest CU pulls 2 x 16 KB per K-tile instead of 2 x 20.  Same-box, XL per
+            // evaluation 5.07 -> 4.78 ms.  No released model's shape meets the condition.  GA_GEMM_RAGGED3=0: off (A/B aid)
+            else if (ragged3_env && a->epilogue == GA_GEMM_EPI_RESIDUAL && wg_mid > 256 && wg_mid * 4 < ((wg_mid + 255) / 256) * 256 * 3 &&
+                     wg_small <= 512 && rows16) ring = 3;
             else if (wg_mid >= 160 && rows48 && (!(a->qk_cols0 || a->qk_cols1) || wg_mid <= 512)) ring = 2;
             else if (wg_small >= 96 && rows16) ring = 3;
         }
