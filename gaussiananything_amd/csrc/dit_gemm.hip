@@ -1113,6 +1113,8 @@ extern "C" int ga_gemm_bf16(const GaGemmArgs *a, void *stream)
             // evaluation 5.07 -> 4.78 ms.  No released model's shape meets the condition.  GA_GEMM_RAGGED3=0: off (A/B aid)
             else if (ragged3_env && a->epilogue == GA_GEMM_EPI_RESIDUAL && wg_mid > 256 && wg_mid * 4 < ((wg_mid + 255) / 256) * 256 * 3 &&
                      wg_small <= 512 && rows16) ring = 3;
+            // (round 6: a 192 x 64 eight-wave tile for the residual GEMMs at 3072 rows -- 256 workgroups, one to a CU, instead of 512 of 96 x 64, two to
+            //  a CU: 32 KB per K-tile through a CU instead of 2 x 20 -- measured the same, DiT-L at CFG batch 4 5.03 / 5.03 ms per evaluation: not kept)
             else if (wg_mid >= 160 && rows48 && (!(a->qk_cols0 || a->qk_cols1) || wg_mid <= 512)) ring = 2;
             else if (wg_small >= 96 && rows16) ring = 3;
         }

@@ -22,7 +22,9 @@ def rel_l2(a, b):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 384, 128), (1536, 1024, 1024), (77, 260, 192),
                                    # K a multiple of 192 but not of 256 (DiT-PixArt-PCD-CLAY-XL: width 1152): the three-slot ring, all four tiles
-                                   (1536, 3456, 1152), (1536, 1152, 4608), (768, 1152, 1152), (768, 4608, 1152), (200, 136, 384)])
+                                   (1536, 3456, 1152), (1536, 1152, 4608), (768, 1152, 1152), (768, 4608, 1152), (200, 136, 384),
+                                   # CFG batch 4 (the release's stage-1 script): 3072 rows
+                                   (3072, 1024, 1024), (3072, 1024, 4096)])
 def test_gemm_epilogues(gpu_device, M, N, K):
     from gaussiananything_amd import dit_ops as ops
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
