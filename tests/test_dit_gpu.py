@@ -327,7 +327,8 @@ def test_attention_with_the_q_projection_inside_the_workgroup(gpu_device, B, H, 
     assert rel_l2(got.float(), ref) < 1.2e-2, rel_l2(got.float(), ref)
 
 
-@pytest.mark.parametrize("B,H,Lq,Lk,d", [(2, 16, 768, 768, 72), (1, 16, 768, 1369, 72), (2, 3, 100, 137, 40), (1, 2, 50, 64, 128), (1, 4, 33, 200, 8)])
+@pytest.mark.parametrize("B,H,Lq,Lk,d", [(2, 16, 768, 768, 72), (1, 16, 768, 1369, 72), (2, 3, 100, 137, 40), (1, 2, 50, 64, 128), (1, 4, 33, 200, 8),
+                                         (1, 2, 3, 5, 24), (3, 5, 130, 65, 104)])
 def test_attention_for_head_dims_other_than_64(gpu_device, B, H, Lq, Lk, d):
     """ga_attention_hd_bf16 / ga_head_rmsnorm_bf16 (dit_attention_hd.hip): what DiT-PixArt-PCD-CLAY-XL's 16 heads of 72
     (/root/reference/dit/dit_i23d.py:1526-1535) need -- per-head RMSNorm of q and k, softmax(q k^T / sqrt(d)) v -- against fp32, at the XL
